@@ -1,0 +1,400 @@
+/*
+ * qzstd_oracle.c — CPU oracle (plain C).  TEST INFRASTRUCTURE ONLY; see the header
+ * for the scope and parity status ("parity unpinned" at sequence level against the
+ * reference, pinned through libzstd round trips / LZ4s vectors / software sizes).
+ *
+ * Sequential definition of the match-finder the HIP kernel implements
+ * (qat-zstd-plugin_amd/csrc/qzstd_kernels.hip).  The definition is written so a
+ * workgroup can evaluate it in parallel and still get the same bits:
+ *
+ *   1. CANDIDATES, tile by tile (tile = 1<<tileLog consecutive positions):
+ *      every position p of the tile reads the hash-table entry of its 4-byte
+ *      hash as it was BEFORE the tile (=> newest earlier-tile position with that
+ *      hash), then all positions of the tile are inserted; concurrent inserts to
+ *      one slot resolve to the largest position (GPU: ds_max_u32).  Optionally a
+ *      second, tile-local "earliest occurrence" table finds matches whose source
+ *      lies inside the current tile (GPU: ds_min_u32 on a scratch table).
+ *   2. LENGTHS: common-prefix length of candidate and position, capped at capLen.
+ *   3. PARSE: greedy (or one-step lazy) left-to-right selection over the
+ *      per-position (length, offset) array; a chosen match that hit the cap is
+ *      extended to its true end; optional short backward extension into the
+ *      pending literals.
+ *   4. EMISSION: {offset, litLength, matchLength}, then the trailing-literals
+ *      delimiter — the output contract of QZSTD_decLz4s,
+ *      /root/reference/src/qatseqprod.c:1013-1091 (and :1309-1313 for a block
+ *      with no match at all: exactly one {lit=srcSize,0,0}).
+ */
+#include "qzstd_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define QZO_TAG_BITS 14u
+#define QZO_TAG_MASK ((1u << QZO_TAG_BITS) - 1u)
+#define QZO_HASH_PRIME 2654435761u
+#define QZO_NEAR_EMPTY 0xFFFFFFFFu
+
+static inline uint32_t qzo_rd32(const uint8_t *p)
+{
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v; /* little endian hosts only (x86-64 / the GPU) */
+}
+
+/* ---- level table ------------------------------------------------------------
+ * Search effort tiers.  The reference forwards the zstd level 1..12 unchanged as
+ * the QAT "compLevel" (src/qatseqprod.c:1154) and rejects anything else
+ * (:1132-1137); here the level picks the search profile.  Table sizes follow the
+ * kernel's LDS budget: block bytes + table + 8 KiB <= 160 KiB.
+ * MUST match qzstd_hip_profile_for_level() in qat-zstd-plugin_amd/csrc/qzstd_profile.c
+ * (tests/test_profiles.py compares the two tables field by field).
+ */
+int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
+{
+    if (level < 1 || level > 12 || !out) return -1;
+    memset(out, 0, sizeof(*out));
+    out->tableSize = blockSize > (64u << 10) ? 6100u : (blockSize > (32u << 10) ? 16384u : 8192u);
+    out->tileLog = 10;
+    out->capLen = level >= 6 ? 64 : 32;
+    out->minMatch = 4;
+    out->farLog1 = 12;
+    out->farLog2 = 16;
+    out->lazy = 1;
+    out->backExt = 4;
+    out->nearTab = 1;
+    out->window = 0;
+    out->hashBytes = 5;
+    return 0;
+}
+
+/* ---- candidate phase -------------------------------------------------------- */
+
+#define QZO_HASH_PRIME2 0x85EBCA77u
+/* 32-bit mix of the first hashBytes (4..8) bytes at a position: two 32-bit multiplies */
+static inline uint32_t qzo_mix(const uint8_t *p, uint32_t hashBytes)
+{
+    uint32_t lo = qzo_rd32(p), hi = 0;
+    if (hashBytes > 4) hi = qzo_rd32(p + hashBytes - 4) >> (8u * (8u - hashBytes)); /* bytes 4.. */
+    return (lo * QZO_HASH_PRIME) ^ (hi * QZO_HASH_PRIME2);
+}
+/* main table slot: multiply-high range reduction (any table size) */
+static inline uint32_t qzo_slot(uint32_t m, uint32_t tableSize)
+{
+    return (uint32_t)(((uint64_t)m * tableSize) >> 32);
+}
+/* tile-local table slot: top tileLog bits */
+static inline uint32_t qzo_near_slot(uint32_t m, uint32_t tileLog)
+{
+    return tileLog ? m >> (32u - tileLog) : 0u;
+}
+/* 14-bit check tag from bits the slot functions barely use */
+static inline uint32_t qzo_tag(uint32_t m)
+{
+    return (m >> 3) & QZO_TAG_MASK;
+}
+
+static inline uint32_t qzo_prefix_len(const uint8_t *src, uint32_t q, uint32_t p, uint32_t maxLen)
+{
+    uint32_t l = 0;
+    while (l < maxLen && src[q + l] == src[p + l]) l++;
+    return l;
+}
+
+typedef struct {
+    uint32_t len; /* 0 = no match */
+    uint32_t off;
+} qzo_cand_t;
+
+static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t n,
+                           qzo_cand_t *cand, uint32_t *tbl, uint32_t *near)
+{
+    const uint32_t nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0; /* hashable positions */
+    const uint32_t T = 1u << pf->tileLog;
+    uint32_t t0, p;
+
+    memset(tbl, 0, sizeof(uint32_t) * pf->tableSize);
+    for (p = 0; p < n; p++) cand[p].len = 0, cand[p].off = 0;
+
+    for (t0 = 0; t0 < nh; t0 += T) {
+        const uint32_t t1 = t0 + T < nh ? t0 + T : nh;
+        if (pf->nearTab) {
+            /* tile-local table of the EARLIEST position per slot (GPU: ds_min_u32) */
+            memset(near, 0xFF, sizeof(uint32_t) << pf->tileLog);
+            for (p = t0; p < t1; p++) {
+                const uint32_t m = qzo_mix(src + p, pf->hashBytes);
+                const uint32_t hn = qzo_near_slot(m, pf->tileLog);
+                const uint32_t e = ((p - t0) << QZO_TAG_BITS) | qzo_tag(m);
+                if (e < near[hn]) near[hn] = e;
+            }
+        }
+        for (p = t0; p < t1; p++) {
+            const uint32_t v = qzo_rd32(src + p);
+            const uint32_t m = qzo_mix(src + p, pf->hashBytes);
+            const uint32_t cap = pf->capLen < n - p ? pf->capLen : n - p;
+            uint32_t bestLen = 0, bestOff = 0;
+            /* probe 1: newest position of EARLIER tiles in this slot (table as it was before the tile) */
+            const uint32_t e = tbl[qzo_slot(m, pf->tableSize)];
+            if (e != 0 && (e & QZO_TAG_MASK) == qzo_tag(m)) {
+                const uint32_t q = (e >> QZO_TAG_BITS) - 1u;
+                const uint32_t off = p - q;
+                if ((pf->window == 0 || off <= pf->window) && qzo_rd32(src + q) == v) {
+                    bestLen = qzo_prefix_len(src, q, p, cap);
+                    bestOff = off;
+                }
+            }
+            /* probe 2: earliest position of THIS tile in the near slot, if it lies before p */
+            if (pf->nearTab) {
+                const uint32_t en = near[qzo_near_slot(m, pf->tileLog)];
+                if (en != QZO_NEAR_EMPTY && (en & QZO_TAG_MASK) == qzo_tag(m)) {
+                    const uint32_t q = t0 + (en >> QZO_TAG_BITS);
+                    if (q < p && qzo_rd32(src + q) == v) {
+                        const uint32_t l = qzo_prefix_len(src, q, p, cap);
+                        /* longer wins; on a tie the nearer source (this one) wins */
+                        if (l >= bestLen) { bestLen = l; bestOff = p - q; }
+                    }
+                }
+            }
+            cand[p].len = bestLen;
+            cand[p].off = bestOff;
+        }
+        /* insert the tile: ascending order == "largest position wins" (GPU: ds_max_u32) */
+        for (p = t0; p < t1; p++) {
+            const uint32_t m = qzo_mix(src + p, pf->hashBytes);
+            tbl[qzo_slot(m, pf->tableSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m);
+        }
+    }
+}
+
+/* ---- parse + emission ------------------------------------------------------- */
+
+static inline uint32_t qzo_min_len(const qzo_profile_t *pf, uint32_t off)
+{
+    return pf->minMatch + (off >> pf->farLog1 ? 1u : 0u) + (off >> pf->farLog2 ? 1u : 0u);
+}
+static inline int qzo_take(const qzo_profile_t *pf, const qzo_cand_t *c)
+{
+    return c->len != 0 && c->len >= qzo_min_len(pf, c->off);
+}
+
+size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t srcSize,
+                          qzo_seq_t *out, size_t cap)
+{
+    const uint32_t n = (uint32_t)srcSize;
+    uint32_t nh;
+    qzo_cand_t *cand;
+    uint32_t *tbl, *near;
+    uint32_t p = 0, anchor = 0;
+    size_t ns = 0;
+
+    if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
+    if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
+        pf->capLen < pf->minMatch + 2 || pf->hashBytes < 4 || pf->hashBytes > 8)
+        return QZO_ERROR;
+    nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
+
+    cand = (qzo_cand_t *)malloc(sizeof(qzo_cand_t) * (n + 1));
+    tbl = (uint32_t *)malloc(sizeof(uint32_t) * pf->tableSize);
+    near = (uint32_t *)malloc(sizeof(uint32_t) << pf->tileLog);
+    if (!cand || !tbl || !near) { free(cand); free(tbl); free(near); return QZO_ERROR; }
+
+    qzo_candidates(pf, src, n, cand, tbl, near);
+
+    while (p < nh) {
+        uint32_t L, off, q, b = 0;
+        if (!qzo_take(pf, &cand[p])) { p++; continue; }
+        if (pf->lazy && p + 1 < nh && ((p + 1) & ((1u << pf->tileLog) - 1u)) != 0 /* not across a tile edge */ &&
+            qzo_take(pf, &cand[p + 1]) && cand[p + 1].len > cand[p].len) {
+            p++; /* one-step lazy: the next position has a strictly longer match */
+            continue;
+        }
+        L = cand[p].len;
+        off = cand[p].off;
+        q = p - off;
+        if (L == pf->capLen) /* hit the candidate-phase cap: extend to the true end */
+            while (p + L < n && src[q + L] == src[p + L]) L++;
+        while (b < pf->backExt && p - b > anchor && q - b > 0 && src[p - b - 1] == src[q - b - 1]) b++;
+        if (ns + 1 >= cap - 1) { ns = QZO_ERROR; goto done; } /* src/qatseqprod.c:1073-1076 */
+        out[ns].offset = off;
+        out[ns].litLength = p - b - anchor;
+        out[ns].matchLength = L + b;
+        out[ns].rep = 0;
+        ns++;
+        p += L;
+        anchor = p;
+    }
+    /* trailing literals delimiter, src/qatseqprod.c:1037-1045 */
+    out[ns].offset = 0;
+    out[ns].litLength = n - anchor;
+    out[ns].matchLength = 0;
+    out[ns].rep = 0;
+    ns++;
+    if (ns >= cap - 1) ns = QZO_ERROR; /* src/qatseqprod.c:1318 */
+done:
+    free(cand); free(tbl); free(near);
+    return ns;
+}
+
+size_t qzo_sequence_producer(void *state, qzo_seq_t *outSeqs, size_t outSeqsCapacity,
+                             const void *src, size_t srcSize, const void *dict,
+                             size_t dictSize, int compressionLevel, size_t windowSize)
+{
+    qzo_profile_t local;
+    const qzo_profile_t *pf = (const qzo_profile_t *)state;
+    /* guards of src/qatseqprod.c:1123-1137 */
+    if (windowSize < (srcSize < 32 * 1024 ? srcSize : 32 * 1024) || dictSize > 0 || dict) return QZO_ERROR;
+    if (compressionLevel < 1 || compressionLevel > 12) return QZO_ERROR;
+    if (!pf) {
+        if (qzo_profile_for_level(compressionLevel, srcSize, &local)) return QZO_ERROR;
+        pf = &local;
+    }
+    return qzo_find_sequences(pf, (const uint8_t *)src, srcSize, outSeqs, outSeqsCapacity);
+}
+
+/* ---- validator / reconstructor ---------------------------------------------- */
+
+int qzo_validate(const qzo_seq_t *s, size_t nb, size_t srcSize, size_t windowSize)
+{
+    size_t i, pos = 0;
+    if (nb == 0) return -4;
+    for (i = 0; i < nb; i++) {
+        pos += s[i].litLength;
+        if (i + 1 == nb) {
+            if (s[i].matchLength != 0 || s[i].offset != 0) return -4;
+        } else {
+            if (s[i].matchLength < 3) return -3;
+            if (s[i].offset == 0 || s[i].offset > pos) return -2;
+            if (windowSize && s[i].offset > windowSize) return -5;
+        }
+        pos += s[i].matchLength;
+        if (pos > srcSize) return -1;
+    }
+    return pos == srcSize ? 0 : -1;
+}
+
+size_t qzo_reconstruct_check(const qzo_seq_t *s, size_t nb, const uint8_t *src, size_t srcSize)
+{
+    uint8_t *dst = (uint8_t *)malloc(srcSize + 1);
+    size_t i, pos = 0, bad = 0;
+    if (!dst) return 1;
+    for (i = 0; i < nb && !bad; i++) {
+        uint32_t k;
+        if (pos + s[i].litLength > srcSize) { bad = i + 1; break; }
+        memcpy(dst + pos, src + pos, s[i].litLength); /* literals come from the block */
+        pos += s[i].litLength;
+        if (s[i].matchLength) {
+            if (s[i].offset == 0 || s[i].offset > pos || pos + s[i].matchLength > srcSize) { bad = i + 1; break; }
+            for (k = 0; k < s[i].matchLength; k++) dst[pos + k] = dst[pos + k - s[i].offset];
+            pos += s[i].matchLength;
+        }
+    }
+    if (!bad && (pos != srcSize || memcmp(dst, src, srcSize) != 0)) {
+        /* locate the first sequence whose output differs */
+        size_t j, q = 0;
+        bad = nb + 1;
+        for (j = 0; j < nb; j++) {
+            size_t e = q + s[j].litLength + s[j].matchLength;
+            if (e > srcSize || memcmp(dst + q, src + q, e - q) != 0) { bad = j + 1; break; }
+            q = e;
+        }
+    }
+    free(dst);
+    return bad;
+}
+
+void qzo_seq_stats(const qzo_seq_t *s, size_t nb, uint64_t *sumMatch, uint64_t *sumLit, uint64_t *fnv1a)
+{
+    uint64_t m = 0, l = 0, h = 1469598103934665603ull;
+    size_t i;
+    int k;
+    for (i = 0; i < nb; i++) {
+        const uint32_t f[3] = { s[i].offset, s[i].litLength, s[i].matchLength };
+        m += s[i].matchLength;
+        l += s[i].litLength;
+        for (k = 0; k < 3; k++) {
+            int b;
+            for (b = 0; b < 4; b++) { h ^= (f[k] >> (8 * b)) & 0xFF; h *= 1099511628211ull; }
+        }
+    }
+    if (sumMatch) *sumMatch = m;
+    if (sumLit) *sumLit = l;
+    if (fnv1a) *fnv1a = h;
+}
+
+/* ---- LZ4s restatement (QZSTD_decLz4s, src/qatseqprod.c:1013-1091) ------------ */
+
+size_t qzo_lz4s_decode(qzo_seq_t *outSeqs, size_t cap, const uint8_t *buf, size_t size)
+{
+    const uint8_t *ip = buf, *const end = buf + size;
+    uint32_t pendingLit = 0; /* literals of "no match" tokens, merged forward (:1077-1084) */
+    size_t n = 0;
+    while (ip < end && size > 0) {
+        const unsigned token = *ip++;
+        size_t lit = token >> 4, ml;
+        uint32_t off;
+        if (lit == 15) { unsigned s; do { s = *ip++; lit += s; } while (s == 255); }
+        ip += lit;
+        if (ip == end) { /* last token: literals only (:1037-1045) */
+            outSeqs[n].litLength = (uint32_t)lit + pendingLit;
+            outSeqs[n].offset = 0;
+            outSeqs[n].matchLength = 0;
+            outSeqs[n].rep = 0;
+            break;
+        }
+        off = (uint32_t)ip[0] | ((uint32_t)ip[1] << 8);
+        ip += 2;
+        ml = token & 15;
+        if (ml == 15) { unsigned s; do { s = *ip++; ml += s; } while (s == 255); }
+        if (ml != 0) {
+            ml += 2;                      /* LZ4MINMATCH (:104, :1061) */
+            outSeqs[n].offset = off;
+            outSeqs[n].litLength = (uint32_t)lit + pendingLit;
+            outSeqs[n].matchLength = (uint16_t)ml; /* 16-bit truncation (:1062) */
+            outSeqs[n].rep = 0;
+            pendingLit = 0;
+            n++;
+            if (n >= cap - 1) return QZO_ERROR; /* :1073-1076 */
+        } else if (lit > 0) {
+            pendingLit += (uint32_t)lit;
+        }
+    }
+    if (ip != end) return QZO_ERROR; /* :1086-1089 */
+    return n + 1;
+}
+
+static size_t qzo_put_run(uint8_t *dst, size_t pos, size_t cap, size_t v)
+{
+    /* v = length - 15 to spread over 255-run bytes */
+    while (v >= 255) { if (pos >= cap) return QZO_ERROR; dst[pos++] = 255; v -= 255; }
+    if (pos >= cap) return QZO_ERROR;
+    dst[pos++] = (uint8_t)v;
+    return pos;
+}
+
+size_t qzo_lz4s_encode(uint8_t *dst, size_t cap, const qzo_seq_t *s, size_t nb,
+                       const uint8_t *src, size_t srcSize)
+{
+    size_t i, o = 0, pos = 0;
+    for (i = 0; i < nb; i++) {
+        const size_t lit = s[i].litLength;
+        const int last = (i + 1 == nb);
+        size_t mlCode = 0;
+        if (!last) {
+            if (s[i].matchLength < 3 || s[i].matchLength > 65535 || s[i].offset > 65535) return QZO_ERROR;
+            mlCode = s[i].matchLength - 2;
+        }
+        if (o >= cap) return QZO_ERROR;
+        dst[o++] = (uint8_t)(((lit >= 15 ? 15 : lit) << 4) | (mlCode >= 15 ? 15 : mlCode));
+        if (lit >= 15 && (o = qzo_put_run(dst, o, cap, lit - 15)) == QZO_ERROR) return QZO_ERROR;
+        if (pos + lit > srcSize || o + lit > cap) return QZO_ERROR;
+        memcpy(dst + o, src + pos, lit);
+        o += lit;
+        pos += lit;
+        if (last) break;
+        if (o + 2 > cap) return QZO_ERROR;
+        dst[o++] = (uint8_t)(s[i].offset & 0xFF);
+        dst[o++] = (uint8_t)(s[i].offset >> 8);
+        if (mlCode >= 15 && (o = qzo_put_run(dst, o, cap, mlCode - 15)) == QZO_ERROR) return QZO_ERROR;
+        pos += s[i].matchLength;
+    }
+    return o;
+}

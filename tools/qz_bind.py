@@ -1,0 +1,223 @@
+"""ctypes bindings shared by tests/, tools/ and bench.py.
+
+* ``Zstd``     — libzstd >= 1.5.4 (the caller of the sequence producer and the judge of
+                 its output).  Discovery order: $ZSTDLIB, system
+                 libzstd that exports ZSTD_registerSequenceProducer, the copy bundled in
+                 pillow.libs (1.5.7 on the ROCm image).
+* ``Oracle``   — oracle/libqzstd_oracle.so (TEST INFRASTRUCTURE: only tests, smoke() and
+                 bench.py's cpu_baseline leg may use it).
+* ``Plugin``   — the product: libqatseqprod.so (drop-in C surface + qzstd_hip_* C-ABI).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import ctypes.util
+import glob
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "qat-zstd-plugin_amd")
+PLUGIN_SO = os.path.join(PKG_DIR, "lib", "libqatseqprod.so")
+ORACLE_SO = os.path.join(ROOT, "oracle", "libqzstd_oracle.so")
+
+SEQ_ERROR = C.c_size_t(-1).value
+
+
+class Sequence(C.Structure):
+    _fields_ = [("offset", C.c_uint32), ("litLength", C.c_uint32),
+                ("matchLength", C.c_uint32), ("rep", C.c_uint32)]
+
+
+PRODUCER_F = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(Sequence), C.c_size_t, C.c_void_p,
+                         C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t)
+
+# zstd parameter ids (include/qzstd_zstd_abi.h)
+c_compressionLevel = 100
+c_windowLog = 101
+c_enableLongDistanceMatching = 160
+c_checksumFlag = 201
+c_nbWorkers = 400
+c_stableInBuffer = 1006
+c_validateSequences = 1009
+c_enableSeqProducerFallback = 1014
+c_maxBlockSize = 1015
+c_searchForExternalRepcodes = 1016
+c_blockSplitterLevel = 1017
+ps_auto, ps_enable, ps_disable = 0, 1, 2
+e_continue, e_flush, e_end = 0, 1, 2
+
+
+def find_libzstd() -> str:
+    cands = []
+    env = os.environ.get("ZSTDLIB")
+    if env:
+        cands += [env] if os.path.isfile(env) else sorted(glob.glob(os.path.join(env, "libzstd.so*")))
+    sysl = ctypes.util.find_library("zstd")
+    if sysl:
+        cands.append(sysl)
+    cands += sorted(glob.glob("/usr/local/lib/libzstd.so*")) + sorted(glob.glob("/usr/lib/x86_64-linux-gnu/libzstd.so*"))
+    cands += sorted(glob.glob("/usr/local/lib/python3*/dist-packages/pillow.libs/libzstd-*.so*"))
+    cands += sorted(glob.glob("/usr/lib/python3/dist-packages/pillow.libs/libzstd-*.so*"))
+    for c in cands:
+        try:
+            lib = C.CDLL(c)
+            if hasattr(lib, "ZSTD_registerSequenceProducer"):
+                return c
+        except OSError:
+            continue
+    raise OSError("no libzstd >= 1.5.4 (ZSTD_registerSequenceProducer) found; set $ZSTDLIB")
+
+
+class ZBounds(C.Structure):
+    _fields_ = [("error", C.c_size_t), ("lowerBound", C.c_int), ("upperBound", C.c_int)]
+
+
+class Zstd:
+    def __init__(self, path: str | None = None):
+        self.path = path or find_libzstd()
+        L = self.lib = C.CDLL(self.path, mode=C.RTLD_GLOBAL)
+        L.ZSTD_versionString.restype = C.c_char_p
+        L.ZSTD_createCCtx.restype = C.c_void_p
+        L.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+        L.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ZSTD_CCtx_setParameter.restype = C.c_size_t
+        L.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ZSTD_compress2.restype = C.c_size_t
+        L.ZSTD_compressBound.argtypes = [C.c_size_t]
+        L.ZSTD_compressBound.restype = C.c_size_t
+        L.ZSTD_sequenceBound.argtypes = [C.c_size_t]
+        L.ZSTD_sequenceBound.restype = C.c_size_t
+        L.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ZSTD_decompress.restype = C.c_size_t
+        L.ZSTD_isError.argtypes = [C.c_size_t]
+        L.ZSTD_getErrorName.argtypes = [C.c_size_t]
+        L.ZSTD_getErrorName.restype = C.c_char_p
+        L.ZSTD_registerSequenceProducer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ZSTD_registerSequenceProducer.restype = None
+        L.ZSTD_cParam_getBounds.argtypes = [C.c_int]
+        L.ZSTD_cParam_getBounds.restype = ZBounds
+        L.ZSTD_generateSequences.argtypes = [C.c_void_p, C.POINTER(Sequence), C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ZSTD_generateSequences.restype = C.c_size_t
+        L.ZSTD_CCtx_reset.argtypes = [C.c_void_p, C.c_int]
+        L.ZSTD_CCtx_reset.restype = C.c_size_t
+
+    def version(self) -> str:
+        return self.lib.ZSTD_versionString().decode()
+
+    def is_error(self, code: int) -> bool:
+        return bool(self.lib.ZSTD_isError(code))
+
+    def err(self, code: int) -> str:
+        return self.lib.ZSTD_getErrorName(code).decode()
+
+    def cctx(self, level: int, producer=None, state=None, fallback: bool = False,
+             validate: bool = True, ext_repcodes: int | None = None, **params):
+        """Create a CCtx; `producer` is an address/ctypes function pointer or None."""
+        L = self.lib
+        zc = L.ZSTD_createCCtx()
+        assert zc
+        self.set(zc, c_compressionLevel, level)
+        if producer is not None:
+            addr = C.cast(producer, C.c_void_p)
+            L.ZSTD_registerSequenceProducer(zc, state, addr)
+            self.set(zc, c_enableSeqProducerFallback, 1 if fallback else 0)
+            if validate:
+                self.set(zc, c_validateSequences, 1)
+        if ext_repcodes is not None:
+            self.set(zc, c_searchForExternalRepcodes, ext_repcodes)
+        for k, v in params.items():
+            self.set(zc, globals()["c_" + k], v)
+        return zc
+
+    def set(self, zc, pid: int, val: int):
+        r = self.lib.ZSTD_CCtx_setParameter(zc, pid, val)
+        if self.is_error(r):
+            raise RuntimeError("ZSTD_CCtx_setParameter(%d,%d): %s" % (pid, val, self.err(r)))
+        return r
+
+    def free(self, zc):
+        self.lib.ZSTD_freeCCtx(zc)
+
+    def compress2(self, zc, data: bytes | memoryview, dst=None) -> bytes:
+        n = len(data)
+        cap = self.lib.ZSTD_compressBound(n)
+        dst = dst if dst is not None and len(dst) >= cap else C.create_string_buffer(cap)
+        src = (C.c_char * n).from_buffer_copy(data) if n else C.create_string_buffer(1)
+        r = self.lib.ZSTD_compress2(zc, dst, cap, src, n)
+        if self.is_error(r):
+            raise RuntimeError("ZSTD_compress2: " + self.err(r))
+        return dst.raw[:r]
+
+    def compress_chunks(self, zc, data: bytes, chunk: int) -> tuple[int, list[bytes]]:
+        """benchmark.c framing (reference test/benchmark.c:300-321): one frame per chunk."""
+        total = 0
+        frames = []
+        cap = self.lib.ZSTD_compressBound(chunk)
+        dst = C.create_string_buffer(cap)
+        for o in range(0, len(data), chunk):
+            f = self.compress2(zc, data[o:o + chunk], dst)
+            total += len(f)
+            frames.append(f)
+        return total, frames
+
+    def decompress(self, frame: bytes, size: int) -> bytes:
+        dst = C.create_string_buffer(max(size, 1))
+        r = self.lib.ZSTD_decompress(dst, size, frame, len(frame))
+        if self.is_error(r):
+            raise RuntimeError("ZSTD_decompress: " + self.err(r))
+        return dst.raw[:r]
+
+
+class OracleProfile(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("tableSize", "tileLog", "capLen", "minMatch", "farLog1",
+                                          "farLog2", "lazy", "backExt", "nearTab", "window",
+                                          "hashBytes", "reserved")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Oracle:
+    """CPU oracle — checker only (see oracle/qzstd_oracle.h)."""
+
+    def __init__(self, path: str = ORACLE_SO):
+        L = self.lib = C.CDLL(path)
+        L.qzo_profile_for_level.argtypes = [C.c_int, C.c_size_t, C.POINTER(OracleProfile)]
+        L.qzo_find_sequences.argtypes = [C.POINTER(OracleProfile), C.c_void_p, C.c_size_t,
+                                         C.POINTER(Sequence), C.c_size_t]
+        L.qzo_find_sequences.restype = C.c_size_t
+        L.qzo_validate.argtypes = [C.POINTER(Sequence), C.c_size_t, C.c_size_t, C.c_size_t]
+        L.qzo_reconstruct_check.argtypes = [C.POINTER(Sequence), C.c_size_t, C.c_void_p, C.c_size_t]
+        L.qzo_reconstruct_check.restype = C.c_size_t
+        L.qzo_seq_stats.argtypes = [C.POINTER(Sequence), C.c_size_t, C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.qzo_seq_stats.restype = None
+        L.qzo_lz4s_decode.argtypes = [C.POINTER(Sequence), C.c_size_t, C.c_void_p, C.c_size_t]
+        L.qzo_lz4s_decode.restype = C.c_size_t
+        L.qzo_lz4s_encode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Sequence), C.c_size_t,
+                                      C.c_void_p, C.c_size_t]
+        L.qzo_lz4s_encode.restype = C.c_size_t
+        self.producer_addr = C.cast(L.qzo_sequence_producer, C.c_void_p)
+
+    def profile(self, level: int, block: int) -> OracleProfile:
+        p = OracleProfile()
+        if self.lib.qzo_profile_for_level(level, block, C.byref(p)) != 0:
+            raise ValueError("bad level %d" % level)
+        return p
+
+    def find(self, prof: OracleProfile, data: bytes, cap: int | None = None):
+        n = len(data)
+        cap = cap or (n // 3 + 1 + n // 1024 + 1)
+        out = (Sequence * cap)()
+        r = self.lib.qzo_find_sequences(C.byref(prof), data, n, out, cap)
+        return r, out
+
+    def stats(self, seqs, n):
+        a, b, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.lib.qzo_seq_stats(seqs, n, C.byref(a), C.byref(b), C.byref(h))
+        return a.value, b.value, h.value
+
+
+def sequence_bound(n: int) -> int:
+    """ZSTD_sequenceBound (zstd 1.5.x): n/3 + 1 + n/1024 + 1."""
+    return n // 3 + 1 + n // 1024 + 1
