@@ -1,0 +1,102 @@
+/*
+ * qatseqprod.h — public C surface of the MI355X-native ZSTD block-level sequence
+ * producer.  Drop-in for the header of intel/QAT-ZSTD-Plugin: same file name, same
+ * function names, signatures, status values and version macros
+ * (/root/reference/src/qatseqprod.h:50-55 version, :60-65 status enum, :72 version(),
+ * :110-116 producer, :130 start, :137 stop, :145 create state, :151 free state), so
+ * a program that already does
+ *
+ *     QZSTD_startQatDevice();
+ *     void *st = QZSTD_createSeqProdState();
+ *     ZSTD_registerSequenceProducer(cctx, st, qatSequenceProducer);
+ *     ZSTD_compress2(...) / ZSTD_compressStream2(...)
+ *
+ * links against this libqatseqprod.{so,a} unchanged.  "QatDevice" in the names is
+ * kept for source compatibility; the device is an AMD Instinct MI355X (gfx950) and
+ * the match search is a HIP kernel (csrc/qzstd_kernels.hip), not QAT hardware.
+ */
+#ifndef QATSEQPROD_H
+#define QATSEQPROD_H
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#ifndef ZSTD_STATIC_LINKING_ONLY
+#define ZSTD_STATIC_LINKING_ONLY
+#endif
+/* zstd >= 1.5.4 is required for ZSTD_registerSequenceProducer.  When no such zstd.h is
+ * installed (the ROCm build image only ships the 1.5.7 shared object), the
+ * declarations this library needs come from qzstd_zstd_abi.h instead. */
+#if defined(QZSTD_USE_SYSTEM_ZSTD_H)
+#include "zstd.h"
+#else
+#include "qzstd_zstd_abi.h"
+#endif
+
+#define QZSTD_VERSION "0.2.0"
+#define QZSTD_VERSION_MAJOR 0
+#define QZSTD_VERSION_MINOR 2
+#define QZSTD_VERSION_RELEASE 0
+#define QZSTD_VERSION_NUMBER \
+    (QZSTD_VERSION_MAJOR * 100 * 100 + QZSTD_VERSION_MINOR * 100 + QZSTD_VERSION_RELEASE)
+
+/* Status codes of QZSTD_startQatDevice (values as in the reference). */
+typedef enum {
+    QZSTD_OK = 0,          /* device(s) up and usable */
+    QZSTD_STARTED = 1,     /* runtime initialised but no usable device/slot */
+    QZSTD_FAIL = -1,       /* could not initialise */
+    QZSTD_UNSUPPORTED = -2 /* declared for compatibility; never returned */
+} QZSTD_Status_e;
+
+/* Version string of the plugin API this library implements ("0.2.0"). */
+const char *QZSTD_version(void);
+
+/*
+ * Block-level sequence producer (a ZSTD_sequenceProducer_F).  libzstd calls it once
+ * per <=128 KiB block; it returns the number of ZSTD_Sequence entries written to
+ * outSeqs (the last one is the trailing-literals delimiter) or
+ * ZSTD_SEQUENCE_PRODUCER_ERROR.
+ *
+ * Same limits as the reference: levels 1..12; no dictionary (dict must be NULL);
+ * every block is parsed without history; windowSize must cover min(srcSize, 32 KiB);
+ * ZSTD_c_nbWorkers > 0 and long-distance matching are rejected by libzstd itself;
+ * one CCtx + one state per thread.  With ZSTD_c_enableSeqProducerFallback = 1 any
+ * error makes libzstd fall back to its own match-finder for that block.
+ */
+size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs,
+                           size_t outSeqsCapacity, const void *src, size_t srcSize,
+                           const void *dict, size_t dictSize, int compressionLevel,
+                           size_t windowSize);
+
+/* Process-wide, idempotent, thread-safe initialisation of the GPU runtime and slots. */
+int QZSTD_startQatDevice(void);
+
+/* Releases every device resource; call after all states are freed.  Safe if never started. */
+void QZSTD_stopQatDevice(void);
+
+/* One state per CCtx/thread, reusable across compressions.  NULL on allocation failure. */
+void *QZSTD_createSeqProdState(void);
+
+/* NULL-safe. */
+void QZSTD_freeSeqProdState(void *sequenceProducerState);
+
+/* ------------------------------------------------------------------------------------
+ * Additive extension (not in the reference): look-ahead hint.
+ *
+ * The producer API is synchronous per block, which would leave 255 of the 256 CUs idle.
+ * When the caller is about to run ZSTD_compress2 over a contiguous buffer it may tell
+ * the state first; the plugin then match-finds the whole buffer in one batched launch
+ * and serves the following qatSequenceProducer() callbacks whose (src, srcSize) lie on
+ * the announced block grid from that result.  Purely an optimisation: callbacks that do
+ * not match the hint take the normal single-block path.  `blockSize` is the block grid
+ * (131072 for plain ZSTD_compress2; the frame/chunk size when each chunk is its own
+ * frame).  Returns 0 when the hint was accepted.
+ * ------------------------------------------------------------------------------------ */
+int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize,
+                     size_t blockSize, int compressionLevel);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif /* QATSEQPROD_H */

@@ -1,0 +1,111 @@
+/*
+ * qzstd_hip.h — thin C ABI between the plain-C plugin (host/qatseqprod.c) and the
+ * CDNA4 / gfx950 HIP side (csrc/qzstd_kernels.hip).  extern "C", plain pointers and
+ * sizes, no C++ / torch types.
+ *
+ * Which reference interface each entry point replaces (the reference reaches its
+ * accelerator through the Intel QAT driver API; none of that API is reproduced):
+ *
+ *   qzstd_hip_device_count          icp_adf_get_numDevices / icp_sal_userIsQatAvailable
+ *                                   (/root/reference/src/qatseqprod.c:503,514)
+ *   qzstd_hip_device_name           cpaDcInstanceGetInfo2 (:569)
+ *   qzstd_hip_malloc / _free        qaeMemAllocNUMA / qaeMemFreeNUMA device-visible
+ *   qzstd_hip_host_alloc / _free    buffers (:221,:235; QZSTD_calloc :216-246)
+ *   qzstd_hip_stream_create/…       cpaDcStartInstance / cpaDcStopInstance (:835,:316)
+ *   qzstd_hip_memcpy_h2d/_d2h       the DMA the QAT ring performs on submit/response
+ *   qzstd_hip_find_sequences        cpaDcCompressData2 (:1245) + QZSTD_decLz4s
+ *                                   (:1013-1091): the kernel emits ZSTD_Sequence
+ *                                   arrays directly, no LZ4s intermediate
+ *   qzstd_hip_stream_sync / _query  icp_sal_DcPollInstance (:1265)
+ *   qzstd_hip_profile_for_level     CpaDcSessionSetupData.compLevel (:1154, :935-946)
+ *
+ * Every function returns 0 on success and a negative value on failure unless noted;
+ * qzstd_hip_last_error() gives a printable reason (thread-local).
+ */
+#ifndef QZSTD_HIP_H
+#define QZSTD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#define QZSTD_HIP_BLOCK_MAX (1u << 17) /* ZSTD_BLOCKSIZE_MAX */
+#define QZSTD_HIP_NSEQ_ERROR 0xFFFFFFFFu
+#define QZSTD_HIP_SRC_ALIGN 16u        /* every block's srcOff must be a multiple of this */
+
+/* Search profile (what a zstd level means to the match-finder).  Same field layout
+ * as the oracle's qzo_profile_t; tests compare the two level tables. */
+typedef struct {
+    uint32_t tableSize; /* entries of the LDS hash table                                   */
+    uint32_t tileLog;   /* look-up / insert granularity: tiles of 1<<tileLog positions     */
+    uint32_t capLen;    /* candidate-phase match length cap                                */
+    uint32_t minMatch;  /* minimum match length for near offsets                           */
+    uint32_t farLog1;   /* offset >= 1<<farLog1 needs minMatch+1                           */
+    uint32_t farLog2;   /* offset >= 1<<farLog2 needs minMatch+2                           */
+    uint32_t lazy;      /* 0 greedy, 1 one-step lazy                                       */
+    uint32_t backExt;   /* max backward extension of a chosen match                        */
+    uint32_t nearTab;   /* 1 = tile-local "earliest occurrence" probe                      */
+    uint32_t window;    /* max offset, 0 = whole block                                     */
+    uint32_t hashBytes; /* bytes hashed per position (4..8)                                */
+    uint32_t reserved;
+} qzstd_hip_profile_t;
+
+/* One work item = one <=128 KiB block, parsed with no history
+ * (reference contract: src/qatseqprod.h:103-105). */
+typedef struct {
+    uint64_t srcOff;  /* byte offset of the block inside d_src, multiple of QZSTD_HIP_SRC_ALIGN */
+    uint64_t seqOff;  /* index (in ZSTD_Sequence units) of the block's output region inside d_seqs */
+    uint32_t srcLen;  /* <= QZSTD_HIP_BLOCK_MAX                                                  */
+    uint32_t seqCap;  /* capacity of the output region, >= ZSTD_sequenceBound(srcLen)            */
+} qzstd_hip_block_t;
+
+const char *qzstd_hip_last_error(void);
+
+/* ---- level -> profile (pure host function, no GPU needed) ---- */
+int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t *out);
+/* ZSTD_sequenceBound restated (zstd 1.5.x): srcSize/3 + 1 + srcSize/1024 + 1 */
+size_t qzstd_hip_sequence_bound(size_t srcSize);
+/* dynamic LDS bytes the kernel needs for a launch whose largest block is maxBlockLen */
+size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen);
+
+/* ---- device / memory / stream plumbing ---- */
+int qzstd_hip_device_count(void); /* number of usable gfx950-class devices, <0 on error */
+int qzstd_hip_device_name(int device, char *buf, size_t bufLen);
+void *qzstd_hip_malloc(int device, size_t bytes);
+void qzstd_hip_free(int device, void *dptr);
+void *qzstd_hip_host_alloc(size_t bytes); /* pinned, portable across devices */
+void qzstd_hip_host_free(void *hptr);
+void *qzstd_hip_stream_create(int device);
+void qzstd_hip_stream_destroy(int device, void *stream);
+int qzstd_hip_stream_sync(int device, void *stream);
+int qzstd_hip_stream_query(int device, void *stream); /* 0 done, 1 still running, <0 error */
+int qzstd_hip_memcpy_h2d(int device, void *stream, void *dst, const void *src, size_t bytes);
+int qzstd_hip_memcpy_d2h(int device, void *stream, void *dst, const void *src, size_t bytes);
+int qzstd_hip_memset(int device, void *stream, void *dst, int value, size_t bytes);
+
+/*
+ * The hot path.  Asynchronously launches the match-finder on `stream` (NULL = the
+ * device's default stream) over nBlocks independent blocks.  All pointers are DEVICE
+ * pointers (or pinned host pointers mapped into the device).
+ *
+ *   d_src     input bytes; block i occupies [srcOff_i, srcOff_i + srcLen_i); the buffer
+ *             must stay readable up to the next multiple of 16 past each block end
+ *   d_blocks  nBlocks descriptors
+ *   d_seqs    ZSTD_Sequence array; block i writes entries [seqOff_i, seqOff_i + count_i)
+ *   d_nseq    per block: number of sequences INCLUDING the trailing-literals delimiter
+ *             (what qatSequenceProducer returns, src/qatseqprod.c:1090,:1323), or
+ *             QZSTD_HIP_NSEQ_ERROR when count >= seqCap-1 (src/qatseqprod.c:1318)
+ *
+ * One workgroup per block; block bytes, hash table and parse scratch live in LDS.
+ */
+int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_src,
+                             const qzstd_hip_block_t *d_blocks, uint32_t nBlocks,
+                             uint32_t maxBlockLen, void *d_seqs, uint32_t *d_nseq);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif /* QZSTD_HIP_H */

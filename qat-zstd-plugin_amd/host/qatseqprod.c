@@ -1,0 +1,483 @@
+/*
+ * qatseqprod.c — host side of the MI355X-native sequence producer, plain C.
+ *
+ * Mirrors the operator interface of intel/QAT-ZSTD-Plugin for its hot path
+ * (/root/reference/src/qatseqprod.c) — same entry points, same guards, same error
+ * behaviour — over the thin HIP C ABI of include/qzstd_hip.h:
+ *
+ *   reference                                      here
+ *   ---------------------------------------------  -----------------------------------------
+ *   QZSTD_startQatDevice   :948-964                runtime probe + slot table, under a mutex
+ *   instance discovery + round-robin shuffle       slots interleaved across GPUs so that
+ *     :529-663                                       consecutive slots sit on different devices
+ *   QZSTD_grabInstance / releaseInstance :905-933  test-and-set sweep starting at the hint
+ *   QZSTD_allocInstMem (lazy)  :685-822            pinned + device buffers, created on first use
+ *   input staging memcpy       :1222-1227          memcpy into the pinned staging buffer
+ *   cpaDcCompressData2 + poll  :1243-1272          H2D, kernel launch, D2H on the slot's stream,
+ *                                                    stream sync
+ *   QZSTD_decLz4s              :1013-1091          (none: the kernel emits ZSTD_Sequence)
+ *   result / capacity checks   :1293-1322          count == NSEQ_ERROR or >= cap-1 -> ERROR
+ *   device-down counter, retry every 1000 blocks   same (failOffloadCnt)
+ *     :88, :1140-1152
+ *
+ * No QAT / icp_sal / cpa symbol is used or emulated.
+ */
+#include "qatseqprod.h"
+#include "qzstd_hip.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef DEBUGLEVEL
+#define DEBUGLEVEL 0
+#endif
+
+#define QZ_LEVEL_MIN 1
+#define QZ_LEVEL_MAX 12
+#define QZ_RETRY_INTERVAL_BLOCKS 1000 /* re-probe a dead device every N failed blocks */
+#define QZ_GRAB_SWEEPS 10
+#define QZ_MAX_DEVICES 64
+#define QZ_MAX_SLOTS 1024
+#define QZ_DEFAULT_SLOTS_PER_DEVICE 8
+#define QZ_FIRST_COPY_SEQS 16384u /* sequences fetched together with the count */
+
+static int qzLogLevel = DEBUGLEVEL; /* 0 silent, 1 errors, 2 events, 3 every sequence */
+#define QZ_LOG(l, ...)                                       \
+    do {                                                     \
+        if ((l) <= qzLogLevel) {                             \
+            fprintf(stderr, "qatseqprod(hip): " __VA_ARGS__); \
+        }                                                    \
+    } while (0)
+
+/* One slot = one in-flight block on one GPU (the analogue of a QAT DC instance). */
+typedef struct {
+    int device;
+    volatile int lock;
+    int ready; /* buffers + stream exist */
+    void *stream;
+    unsigned char *hSrc; /* pinned staging, QZSTD_HIP_BLOCK_MAX + pad */
+    unsigned char *dSrc;
+    ZSTD_Sequence *hSeqs; /* pinned, seqCap entries */
+    ZSTD_Sequence *dSeqs;
+    qzstd_hip_block_t *hDesc; /* pinned */
+    qzstd_hip_block_t *dDesc;
+    unsigned int *hCount; /* pinned */
+    unsigned int *dCount;
+    size_t seqCap;
+    /* grow-only buffers of the batched (hinted) path */
+    unsigned char *dBatchSrc; size_t dBatchSrcCap;
+    ZSTD_Sequence *dBatchSeqs; size_t dBatchSeqsCap;
+    qzstd_hip_block_t *dBatchDesc; unsigned int *dBatchCount; size_t dBatchBlocksCap;
+} QZSTD_Slot_T;
+
+typedef struct {
+    int status; /* QZSTD_Status_e */
+    int numDevices;
+    int numSlots;
+    QZSTD_Slot_T *slots;
+    pthread_mutex_t mutex;
+} QZSTD_Process_T;
+
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, PTHREAD_MUTEX_INITIALIZER };
+
+/* Per-CCtx state (opaque to the caller). */
+typedef struct {
+    int slotHint;
+    unsigned int failOffloadCnt;
+    /* look-ahead batch served to later callbacks (QZSTD_hintSource) */
+    const unsigned char *hintBase;
+    size_t hintSize, hintBlock;
+    int hintLevel;
+    size_t batchBlocks, batchPitch; /* pitch in sequences */
+    ZSTD_Sequence *batchSeqs;       /* pinned host, batchBlocks * batchPitch */
+    unsigned int *batchCount;       /* pinned host */
+    qzstd_hip_block_t *batchDesc;   /* pinned host */
+    size_t batchSeqsCap, batchDescCap, batchCountCap; /* bytes */
+    unsigned long servedFromBatch, servedSync;
+} QZSTD_Session_T;
+
+const char *QZSTD_version(void)
+{
+    return QZSTD_VERSION;
+}
+
+/* ---------------------------------------------------------------- slots ---------- */
+
+static void qzFreeSlot(QZSTD_Slot_T *s)
+{
+    if (s->stream) (void)qzstd_hip_stream_sync(s->device, s->stream);
+    qzstd_hip_host_free(s->hSrc);
+    qzstd_hip_host_free(s->hSeqs);
+    qzstd_hip_host_free(s->hDesc);
+    qzstd_hip_host_free(s->hCount);
+    qzstd_hip_free(s->device, s->dSrc);
+    qzstd_hip_free(s->device, s->dSeqs);
+    qzstd_hip_free(s->device, s->dDesc);
+    qzstd_hip_free(s->device, s->dCount);
+    qzstd_hip_free(s->device, s->dBatchSrc);
+    qzstd_hip_free(s->device, s->dBatchSeqs);
+    qzstd_hip_free(s->device, s->dBatchDesc);
+    qzstd_hip_free(s->device, s->dBatchCount);
+    if (s->stream) qzstd_hip_stream_destroy(s->device, s->stream);
+    {
+        const int dev = s->device;
+        memset(s, 0, sizeof(*s));
+        s->device = dev;
+    }
+}
+
+/* lazy per-slot setup, first use only (reference: QZSTD_allocInstMem, :685-822) */
+static int qzSetupSlot(QZSTD_Slot_T *s)
+{
+    if (s->ready) return QZSTD_OK;
+    s->seqCap = qzstd_hip_sequence_bound(QZSTD_HIP_BLOCK_MAX);
+    s->stream = qzstd_hip_stream_create(s->device);
+    s->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZSTD_HIP_BLOCK_MAX + 64);
+    s->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(s->seqCap * sizeof(ZSTD_Sequence));
+    s->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(sizeof(qzstd_hip_block_t));
+    s->hCount = (unsigned int *)qzstd_hip_host_alloc(64);
+    s->dSrc = (unsigned char *)qzstd_hip_malloc(s->device, QZSTD_HIP_BLOCK_MAX + 64);
+    s->dSeqs = (ZSTD_Sequence *)qzstd_hip_malloc(s->device, s->seqCap * sizeof(ZSTD_Sequence));
+    s->dDesc = (qzstd_hip_block_t *)qzstd_hip_malloc(s->device, sizeof(qzstd_hip_block_t));
+    s->dCount = (unsigned int *)qzstd_hip_malloc(s->device, 64);
+    if (!s->stream || !s->hSrc || !s->hSeqs || !s->hDesc || !s->hCount || !s->dSrc || !s->dSeqs ||
+        !s->dDesc || !s->dCount) {
+        QZ_LOG(1, "slot setup failed on device %d: %s\n", s->device, qzstd_hip_last_error());
+        qzFreeSlot(s);
+        return QZSTD_FAIL;
+    }
+    s->ready = 1;
+    return QZSTD_OK;
+}
+
+/* test-and-set sweep over the slots, starting at the caller's sticky hint
+ * (reference: QZSTD_grabInstance, :905-928) */
+static int qzGrabSlot(int hint)
+{
+    int sweep, k;
+    const int n = gProc.numSlots;
+    if (n <= 0) return -1;
+    if (hint < 0 || hint >= n) hint = 0;
+    for (sweep = 0; sweep < QZ_GRAB_SWEEPS; sweep++) {
+        for (k = 0; k < n; k++) {
+            const int i = (hint + k) % n;
+            if (__sync_lock_test_and_set(&gProc.slots[i].lock, 1) == 0) return i;
+        }
+    }
+    return -1;
+}
+
+static void qzReleaseSlot(int i)
+{
+    __sync_lock_release(&gProc.slots[i].lock);
+}
+
+/* ---------------------------------------------------------------- lifecycle ------ */
+
+static int qzEnvInt(const char *name, int dflt, int lo, int hi)
+{
+    const char *v = getenv(name);
+    long x;
+    if (!v || !*v) return dflt;
+    x = strtol(v, NULL, 10);
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return (int)x;
+}
+
+/* Enumerate GPUs and lay the slots out round-robin across them, so that threads whose
+ * hints are consecutive land on different devices (reference: the instance shuffle of
+ * QZSTD_getAndShuffleInstance, :601-630). */
+static int qzBuildSlots(void)
+{
+    int nDev = qzstd_hip_device_count();
+    int perDev, i, maxDev;
+    if (nDev <= 0) return QZSTD_FAIL;
+    maxDev = qzEnvInt("QZSTD_HIP_MAX_DEVICES", QZ_MAX_DEVICES, 1, QZ_MAX_DEVICES);
+    if (nDev > maxDev) nDev = maxDev;
+    perDev = qzEnvInt("QZSTD_HIP_SLOTS", QZ_DEFAULT_SLOTS_PER_DEVICE, 1, QZ_MAX_SLOTS / nDev);
+    gProc.slots = (QZSTD_Slot_T *)calloc((size_t)nDev * perDev, sizeof(QZSTD_Slot_T));
+    if (!gProc.slots) return QZSTD_FAIL;
+    gProc.numDevices = nDev;
+    gProc.numSlots = nDev * perDev;
+    for (i = 0; i < gProc.numSlots; i++) gProc.slots[i].device = i % nDev;
+    return QZSTD_OK;
+}
+
+int QZSTD_startQatDevice(void)
+{
+    int status;
+    pthread_mutex_lock(&gProc.mutex);
+    {
+        const char *dbg = getenv("QZSTD_HIP_DEBUG");
+        if (dbg && *dbg) qzLogLevel = atoi(dbg);
+    }
+    if (gProc.status == QZSTD_FAIL) {
+        /* runtime up? (reference: QZSTD_salUserStart, :498-527) */
+        gProc.status = qzstd_hip_device_count() > 0 ? QZSTD_STARTED : QZSTD_FAIL;
+        if (gProc.status == QZSTD_FAIL) QZ_LOG(2, "no HIP device: %s\n", qzstd_hip_last_error());
+    }
+    if (gProc.status == QZSTD_STARTED) {
+        gProc.status = qzBuildSlots() == QZSTD_OK ? QZSTD_OK : QZSTD_STARTED;
+    }
+    QZ_LOG(2, "start: status %d, %d device(s), %d slot(s)\n", gProc.status, gProc.numDevices, gProc.numSlots);
+    status = gProc.status;
+    pthread_mutex_unlock(&gProc.mutex);
+    return status;
+}
+
+void QZSTD_stopQatDevice(void)
+{
+    int i;
+    pthread_mutex_lock(&gProc.mutex);
+    if (gProc.slots) {
+        for (i = 0; i < gProc.numSlots; i++) qzFreeSlot(&gProc.slots[i]);
+        free(gProc.slots);
+    }
+    gProc.slots = NULL;
+    gProc.numSlots = 0;
+    gProc.numDevices = 0;
+    gProc.status = QZSTD_FAIL;
+    pthread_mutex_unlock(&gProc.mutex);
+}
+
+void *QZSTD_createSeqProdState(void)
+{
+    QZSTD_Session_T *s = (QZSTD_Session_T *)calloc(1, sizeof(QZSTD_Session_T));
+    if (!s) return NULL;
+    s->slotHint = -1;
+    return s;
+}
+
+static void qzDropBatch(QZSTD_Session_T *s)
+{
+    s->hintBase = NULL;
+    s->hintSize = 0;
+    s->batchBlocks = 0;
+}
+
+void QZSTD_freeSeqProdState(void *sequenceProducerState)
+{
+    QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
+    if (!s) return;
+    QZ_LOG(2, "state %p: %lu block(s) served from a look-ahead batch, %lu synchronously\n", (void *)s,
+           s->servedFromBatch, s->servedSync);
+    qzstd_hip_host_free(s->batchSeqs);
+    qzstd_hip_host_free(s->batchCount);
+    qzstd_hip_host_free(s->batchDesc);
+    free(s);
+}
+
+/* ---------------------------------------------------------------- hot path ------- */
+
+/* shared by the producer and the hint: is the device usable?  Counts failures and
+ * re-probes every QZ_RETRY_INTERVAL_BLOCKS-th block (reference :1140-1152). */
+static int qzDeviceUsable(QZSTD_Session_T *s)
+{
+    if (gProc.status == QZSTD_OK) return 1;
+    s->failOffloadCnt++;
+    if (s->failOffloadCnt >= QZ_RETRY_INTERVAL_BLOCKS) {
+        s->failOffloadCnt = 0;
+        if (QZSTD_startQatDevice() == QZSTD_OK) return 1;
+        QZ_LOG(1, "tried to restart the device, but failed\n");
+        return 0;
+    }
+    QZ_LOG(1, "the device was not successfully started\n");
+    return 0;
+}
+
+/* one block, synchronously, on slot i */
+static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
+                         size_t srcSize, int level)
+{
+    const size_t cap = outSeqsCapacity < sl->seqCap ? outSeqsCapacity : sl->seqCap;
+    size_t first, count;
+    memcpy(sl->hSrc, src, srcSize); /* staging copy, reference :1223 */
+    sl->hDesc->srcOff = 0;
+    sl->hDesc->seqOff = 0;
+    sl->hDesc->srcLen = (unsigned int)srcSize;
+    sl->hDesc->seqCap = (unsigned int)cap;
+    if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dSrc, sl->hSrc, (srcSize + 15) & ~(size_t)15) ||
+        qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dDesc, sl->hDesc, sizeof(*sl->hDesc)) ||
+        qzstd_hip_find_sequences(sl->device, sl->stream, level, sl->dSrc, sl->dDesc, 1, (unsigned int)srcSize,
+                                 sl->dSeqs, sl->dCount))
+        goto fail;
+    first = cap < QZ_FIRST_COPY_SEQS ? cap : QZ_FIRST_COPY_SEQS;
+    if (qzstd_hip_memcpy_d2h(sl->device, sl->stream, sl->hCount, sl->dCount, sizeof(unsigned int)) ||
+        qzstd_hip_memcpy_d2h(sl->device, sl->stream, sl->hSeqs, sl->dSeqs, first * sizeof(ZSTD_Sequence)) ||
+        qzstd_hip_stream_sync(sl->device, sl->stream))
+        goto fail;
+    count = *sl->hCount;
+    if (count == QZSTD_HIP_NSEQ_ERROR || count == 0 || count >= outSeqsCapacity - 1) {
+        QZ_LOG(1, "sequence count %zu does not fit capacity %zu\n", count, outSeqsCapacity);
+        return ZSTD_SEQUENCE_PRODUCER_ERROR; /* reference :1318-1322 */
+    }
+    if (count > first) {
+        if (qzstd_hip_memcpy_d2h(sl->device, sl->stream, sl->hSeqs + first, sl->dSeqs + first,
+                                 (count - first) * sizeof(ZSTD_Sequence)) ||
+            qzstd_hip_stream_sync(sl->device, sl->stream))
+            goto fail;
+    }
+    memcpy(outSeqs, sl->hSeqs, count * sizeof(ZSTD_Sequence));
+    return count;
+fail:
+    QZ_LOG(1, "device request failed: %s\n", qzstd_hip_last_error());
+    return ZSTD_SEQUENCE_PRODUCER_ERROR;
+}
+
+size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity,
+                           const void *src, size_t srcSize, const void *dict, size_t dictSize,
+                           int compressionLevel, size_t windowSize)
+{
+    QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
+    size_t rc = ZSTD_SEQUENCE_PRODUCER_ERROR;
+    int i;
+
+    /* guards, reference :1123-1137 */
+    if (windowSize < (srcSize < 32 * 1024 ? srcSize : 32 * 1024) || dictSize > 0 || dict) {
+        QZ_LOG(2, "window %zu too small for block %zu, or dictionary given (%zu)\n", windowSize, srcSize, dictSize);
+        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+    }
+    if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) {
+        QZ_LOG(1, "only levels 1-12 can be offloaded, got %d\n", compressionLevel);
+        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+    }
+    if (!s || !outSeqs || !src || srcSize > QZSTD_HIP_BLOCK_MAX || outSeqsCapacity < 3) return ZSTD_SEQUENCE_PRODUCER_ERROR;
+    if (!qzDeviceUsable(s)) return ZSTD_SEQUENCE_PRODUCER_ERROR;
+
+    /* look-ahead batch hit?  (src, srcSize) must sit exactly on the hinted block grid */
+    if (s->batchBlocks && s->hintLevel == compressionLevel) {
+        const unsigned char *p = (const unsigned char *)src;
+        if (p >= s->hintBase && p + srcSize <= s->hintBase + s->hintSize) {
+            const size_t rel = (size_t)(p - s->hintBase);
+            const size_t b = rel / s->hintBlock;
+            if (rel % s->hintBlock == 0 && b < s->batchBlocks && s->batchDesc[b].srcLen == srcSize) {
+                const size_t count = s->batchCount[b];
+                if (count != QZSTD_HIP_NSEQ_ERROR && count != 0 && count < outSeqsCapacity - 1 &&
+                    count <= s->batchPitch) {
+                    memcpy(outSeqs, s->batchSeqs + b * s->batchPitch, count * sizeof(ZSTD_Sequence));
+                    s->servedFromBatch++;
+                    if (rel + srcSize >= s->hintSize) qzDropBatch(s); /* last block consumed */
+                    return count;
+                }
+            }
+        }
+    }
+
+    i = qzGrabSlot(s->slotHint);
+    if (i < 0) {
+        QZ_LOG(1, "failed to grab a slot\n");
+        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+    }
+    s->slotHint = i;
+    if (qzSetupSlot(&gProc.slots[i]) == QZSTD_OK) {
+        rc = qzRunBlock(&gProc.slots[i], outSeqs, outSeqsCapacity, src, srcSize, compressionLevel);
+        if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
+    }
+    QZ_LOG(2, "block %zu B level %d -> %zu sequences (slot %d, device %d)\n", srcSize, compressionLevel, rc, i,
+           gProc.slots[i].device);
+    qzReleaseSlot(i);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- look-ahead ----- */
+
+/* grow-only buffers: returns the (possibly new) pointer, NULL on failure */
+static void *qzGrowHost(void *old, size_t *cap, size_t need)
+{
+    void *p;
+    if (old && *cap >= need) return old;
+    qzstd_hip_host_free(old);
+    p = qzstd_hip_host_alloc(need);
+    *cap = p ? need : 0;
+    return p;
+}
+
+static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need)
+{
+    void *p;
+    if (old && *cap >= need) return old;
+    qzstd_hip_free(dev, old);
+    p = qzstd_hip_malloc(dev, need);
+    *cap = p ? need : 0;
+    return p;
+}
+
+int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
+                     int compressionLevel)
+{
+    QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
+    QZSTD_Slot_T *sl;
+    size_t nb, b, stride, pitch = 0, blocksBytes, srcBytes;
+    int i, rc = -1;
+
+    if (!s || !src || srcSize == 0 || blockSize == 0 || blockSize > QZSTD_HIP_BLOCK_MAX || (blockSize & 15)) return -1;
+    if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) return -1;
+    qzDropBatch(s);
+    if (!qzDeviceUsable(s)) return -1;
+    nb = (srcSize + blockSize - 1) / blockSize;
+    stride = qzstd_hip_sequence_bound(blockSize);
+    i = qzGrabSlot(s->slotHint);
+    if (i < 0) return -1;
+    s->slotHint = i;
+    sl = &gProc.slots[i];
+    if (qzSetupSlot(sl) != QZSTD_OK) goto out;
+
+    blocksBytes = nb * sizeof(qzstd_hip_block_t);
+    srcBytes = (srcSize + 63) & ~(size_t)63;
+    s->batchDesc = (qzstd_hip_block_t *)qzGrowHost(s->batchDesc, &s->batchDescCap, blocksBytes);
+    s->batchCount = (unsigned int *)qzGrowHost(s->batchCount, &s->batchCountCap, nb * sizeof(unsigned int));
+    if (!s->batchDesc || !s->batchCount) goto out;
+    sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, srcBytes);
+    sl->dBatchSeqs = (ZSTD_Sequence *)qzGrowDev(sl->device, sl->dBatchSeqs, &sl->dBatchSeqsCap,
+                                                nb * stride * sizeof(ZSTD_Sequence));
+    if (!sl->dBatchSrc || !sl->dBatchSeqs) goto out;
+    if (sl->dBatchBlocksCap < nb) {
+        qzstd_hip_free(sl->device, sl->dBatchDesc);
+        qzstd_hip_free(sl->device, sl->dBatchCount);
+        sl->dBatchDesc = (qzstd_hip_block_t *)qzstd_hip_malloc(sl->device, blocksBytes);
+        sl->dBatchCount = (unsigned int *)qzstd_hip_malloc(sl->device, nb * sizeof(unsigned int));
+        sl->dBatchBlocksCap = sl->dBatchDesc && sl->dBatchCount ? nb : 0;
+        if (!sl->dBatchBlocksCap) goto out;
+    }
+    for (b = 0; b < nb; b++) {
+        const size_t o = b * blockSize;
+        s->batchDesc[b].srcOff = o;
+        s->batchDesc[b].seqOff = b * stride;
+        s->batchDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
+        s->batchDesc[b].seqCap = (unsigned int)stride;
+    }
+    if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, src, srcSize) ||
+        qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchDesc, s->batchDesc, blocksBytes) ||
+        qzstd_hip_find_sequences(sl->device, sl->stream, compressionLevel, sl->dBatchSrc, sl->dBatchDesc,
+                                 (unsigned int)nb, (unsigned int)blockSize, sl->dBatchSeqs, sl->dBatchCount) ||
+        qzstd_hip_memcpy_d2h(sl->device, sl->stream, s->batchCount, sl->dBatchCount, nb * sizeof(unsigned int)) ||
+        qzstd_hip_stream_sync(sl->device, sl->stream))
+        goto out;
+    for (b = 0; b < nb; b++)
+        if (s->batchCount[b] != QZSTD_HIP_NSEQ_ERROR && s->batchCount[b] > pitch) pitch = s->batchCount[b];
+    if (pitch == 0) goto out;
+    s->batchSeqs = (ZSTD_Sequence *)qzGrowHost(s->batchSeqs, &s->batchSeqsCap, nb * pitch * sizeof(ZSTD_Sequence));
+    if (!s->batchSeqs) goto out;
+    /* gather: every block's used prefix, one D2H per block on the same stream */
+    for (b = 0; b < nb; b++) {
+        const size_t cnt = s->batchCount[b] == QZSTD_HIP_NSEQ_ERROR ? 0 : s->batchCount[b];
+        if (cnt && qzstd_hip_memcpy_d2h(sl->device, sl->stream, s->batchSeqs + b * pitch,
+                                        sl->dBatchSeqs + b * stride, cnt * sizeof(ZSTD_Sequence)))
+            goto out;
+    }
+    if (qzstd_hip_stream_sync(sl->device, sl->stream)) goto out;
+    s->hintBase = (const unsigned char *)src;
+    s->hintSize = srcSize;
+    s->hintBlock = blockSize;
+    s->hintLevel = compressionLevel;
+    s->batchBlocks = nb;
+    s->batchPitch = pitch;
+    rc = 0;
+out:
+    if (rc) QZ_LOG(1, "look-ahead hint not taken: %s\n", qzstd_hip_last_error());
+    qzReleaseSlot(i);
+    return rc;
+}

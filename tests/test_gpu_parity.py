@@ -1,0 +1,84 @@
+"""GPU parity: the HIP match-finder (through the C ABI) must equal the CPU oracle
+sequence-for-sequence, and its output must satisfy the consumer's rules."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import qz_bind as B
+import qz_corpus as K
+
+pytestmark = pytest.mark.gpu
+
+
+def seqs_to_np(seqs, start, n):
+    a = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)
+    return a[start:start + n, :3].copy()
+
+
+def check_blocks(gpu_plugin, oracle, blocks, level=1):
+    counts, seqs, stride = gpu_plugin.find_batch(blocks, level)
+    for i, blk in enumerate(blocks):
+        prof = oracle.profile(level, len(blk))
+        want_n, want = oracle.find(prof, blk, cap=stride)
+        assert counts[i] == (want_n if want_n != B.SEQ_ERROR else B.NSEQ_ERROR), \
+            "block %d (len %d): count %d vs oracle %d" % (i, len(blk), counts[i], want_n)
+        if want_n == B.SEQ_ERROR:
+            continue
+        got = seqs_to_np(seqs, i * stride, want_n)
+        exp = seqs_to_np(want, 0, want_n)
+        if not np.array_equal(got, exp):
+            bad = int(np.nonzero((got != exp).any(axis=1))[0][0])
+            raise AssertionError("block %d (len %d): first differing sequence %d: gpu %s oracle %s" % (
+                i, len(blk), bad, got[bad], exp[bad]))
+        sub = (B.Sequence * want_n).from_buffer_copy(bytes(C.string_at(C.addressof(seqs) + i * stride * 16, want_n * 16)))
+        assert oracle.lib.qzo_validate(sub, want_n, len(blk), 0) == 0
+        assert oracle.lib.qzo_reconstruct_check(sub, want_n, blk, len(blk)) == 0
+
+
+def test_single_text_block(gpu_plugin, oracle):
+    check_blocks(gpu_plugin, oracle, [K.text(1, 131072)])
+
+
+@pytest.mark.parametrize("gen", ["text", "binary", "weblog", "mixed_entropy", "random", "system"])
+def test_corpora_128k(gpu_plugin, oracle, gen):
+    data = K.by_name(gen, 8 * 131072, seed=7)
+    check_blocks(gpu_plugin, oracle, [data[o:o + 131072] for o in range(0, len(data), 131072)])
+
+
+def test_edge_sizes(gpu_plugin, oracle):
+    base = K.text(3, 140000)
+    sizes = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1023, 1024, 1025, 1028, 1029, 2047, 2048, 2053,
+             4096, 10000, 32767, 32768, 32769, 65535, 65536, 65537, 100001, 131071, 131072]
+    check_blocks(gpu_plugin, oracle, [base[:s] for s in sizes])
+
+
+def test_degenerate_blocks(gpu_plugin, oracle):
+    blocks = [bytes(131072), b"\xff" * 70000, b"ab" * 50000, b"abc" * 40000, (b"0123456789" * 13108)[:131072],
+              bytes(range(256)) * 512, b"x" + bytes(5000), K.incompressible(9, 131072)]
+    check_blocks(gpu_plugin, oracle, blocks)
+
+
+@pytest.mark.parametrize("level", [1, 3, 6, 12])
+def test_levels(gpu_plugin, oracle, level):
+    data = K.mix(11, 6 * 131072)
+    check_blocks(gpu_plugin, oracle, [data[o:o + 131072] for o in range(0, len(data), 131072)], level)
+
+
+def test_block_32k_and_64k(gpu_plugin, oracle):
+    data = K.weblog(4, 16 * 32768)
+    check_blocks(gpu_plugin, oracle, [data[o:o + 32768] for o in range(0, len(data), 32768)], 12)
+    check_blocks(gpu_plugin, oracle, [data[o:o + 65536] for o in range(0, len(data), 65536)], 1)
+
+
+def test_capacity_rule(gpu_plugin, oracle):
+    """count >= cap-1 must be reported as an error (reference src/qatseqprod.c:1073-1076, :1318)."""
+    blk = K.text(5, 131072)
+    prof = oracle.profile(1, len(blk))
+    n_full, _ = oracle.find(prof, blk)
+    for cap in (n_full + 2, n_full + 1, n_full, 100, 3):
+        counts, seqs, stride = gpu_plugin.find_batch([blk], 1, caps=[cap])
+        want_n, _ = oracle.find(prof, blk, cap=cap)
+        assert counts[0] == (want_n if want_n != B.SEQ_ERROR else B.NSEQ_ERROR), cap
+    assert oracle.find(prof, blk, cap=n_full + 2)[0] == n_full
+    assert oracle.find(prof, blk, cap=n_full + 1)[0] == B.SEQ_ERROR

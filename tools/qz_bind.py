@@ -221,3 +221,127 @@ class Oracle:
 def sequence_bound(n: int) -> int:
     """ZSTD_sequenceBound (zstd 1.5.x): n/3 + 1 + n/1024 + 1."""
     return n // 3 + 1 + n // 1024 + 1
+
+
+class HipProfile(OracleProfile):
+    """qzstd_hip_profile_t — same 12 x u32 layout as the oracle's profile."""
+
+
+class HipBlock(C.Structure):
+    _fields_ = [("srcOff", C.c_uint64), ("seqOff", C.c_uint64), ("srcLen", C.c_uint32), ("seqCap", C.c_uint32)]
+
+
+NSEQ_ERROR = 0xFFFFFFFF
+
+# every symbol include/qatseqprod.h and include/qzstd_hip.h declare
+PLUGIN_SYMBOLS = [
+    "QZSTD_version", "qatSequenceProducer", "QZSTD_startQatDevice", "QZSTD_stopQatDevice",
+    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource",
+    "qzstd_hip_last_error", "qzstd_hip_profile_for_level", "qzstd_hip_sequence_bound", "qzstd_hip_lds_bytes",
+    "qzstd_hip_device_count", "qzstd_hip_device_name", "qzstd_hip_malloc", "qzstd_hip_free",
+    "qzstd_hip_host_alloc", "qzstd_hip_host_free", "qzstd_hip_stream_create", "qzstd_hip_stream_destroy",
+    "qzstd_hip_stream_sync", "qzstd_hip_stream_query", "qzstd_hip_memcpy_h2d", "qzstd_hip_memcpy_d2h",
+    "qzstd_hip_memset", "qzstd_hip_find_sequences",
+]
+
+
+class Plugin:
+    """The product library, reached only through its C ABI (include/*.h)."""
+
+    def __init__(self, path: str = PLUGIN_SO):
+        if not os.path.isfile(path):
+            raise OSError("%s missing: run `make -C qat-zstd-plugin_amd` (or __graft_entry__.build())" % path)
+        L = self.lib = C.CDLL(path)
+        L.QZSTD_version.restype = C.c_char_p
+        L.QZSTD_createSeqProdState.restype = C.c_void_p
+        L.QZSTD_freeSeqProdState.argtypes = [C.c_void_p]
+        L.QZSTD_hintSource.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.qatSequenceProducer.restype = C.c_size_t
+        L.qatSequenceProducer.argtypes = [C.c_void_p, C.POINTER(Sequence), C.c_size_t, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]
+        L.qzstd_hip_last_error.restype = C.c_char_p
+        L.qzstd_hip_profile_for_level.argtypes = [C.c_int, C.c_size_t, C.POINTER(HipProfile)]
+        L.qzstd_hip_sequence_bound.argtypes = [C.c_size_t]
+        L.qzstd_hip_sequence_bound.restype = C.c_size_t
+        L.qzstd_hip_lds_bytes.argtypes = [C.c_int, C.c_uint32]
+        L.qzstd_hip_lds_bytes.restype = C.c_size_t
+        L.qzstd_hip_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        L.qzstd_hip_malloc.argtypes = [C.c_int, C.c_size_t]
+        L.qzstd_hip_malloc.restype = C.c_void_p
+        L.qzstd_hip_free.argtypes = [C.c_int, C.c_void_p]
+        L.qzstd_hip_free.restype = None
+        L.qzstd_hip_host_alloc.argtypes = [C.c_size_t]
+        L.qzstd_hip_host_alloc.restype = C.c_void_p
+        L.qzstd_hip_host_free.argtypes = [C.c_void_p]
+        L.qzstd_hip_host_free.restype = None
+        L.qzstd_hip_stream_create.argtypes = [C.c_int]
+        L.qzstd_hip_stream_create.restype = C.c_void_p
+        L.qzstd_hip_stream_destroy.argtypes = [C.c_int, C.c_void_p]
+        L.qzstd_hip_stream_destroy.restype = None
+        L.qzstd_hip_stream_sync.argtypes = [C.c_int, C.c_void_p]
+        L.qzstd_hip_stream_query.argtypes = [C.c_int, C.c_void_p]
+        L.qzstd_hip_memcpy_h2d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.qzstd_hip_memcpy_d2h.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.qzstd_hip_memset.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
+        L.qzstd_hip_find_sequences.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32,
+                                               C.c_uint32, C.c_void_p, C.c_void_p]
+        self.producer_addr = C.cast(L.qatSequenceProducer, C.c_void_p)
+
+    def err(self) -> str:
+        return self.lib.qzstd_hip_last_error().decode()
+
+    def profile(self, level: int, block: int) -> HipProfile:
+        p = HipProfile()
+        if self.lib.qzstd_hip_profile_for_level(level, block, C.byref(p)) != 0:
+            raise ValueError("bad level %d" % level)
+        return p
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.err()))
+
+    def find_batch(self, blocks: list[bytes], level: int = 1, device: int = 0, stride: int | None = None,
+                   caps: list[int] | None = None):
+        """Run the HIP match-finder over `blocks` through the C ABI (device memory managed
+        with qzstd_hip_malloc / memcpy).  Returns (counts, list of Sequence arrays)."""
+        L = self.lib
+        nb = len(blocks)
+        maxlen = max([len(b) for b in blocks] + [1])
+        stride = stride or sequence_bound(maxlen)
+        offs, total = [], 0
+        for b in blocks:
+            offs.append(total)
+            total += (len(b) + 15) & ~15
+        total = max(total, 16)
+        host_src = bytearray(total)
+        for o, b in zip(offs, blocks):
+            host_src[o:o + len(b)] = b
+        desc = (HipBlock * nb)()
+        for i, b in enumerate(blocks):
+            desc[i].srcOff = offs[i]
+            desc[i].seqOff = i * stride
+            desc[i].srcLen = len(b)
+            desc[i].seqCap = caps[i] if caps else stride
+        d_src = L.qzstd_hip_malloc(device, total)
+        d_desc = L.qzstd_hip_malloc(device, C.sizeof(desc))
+        d_seqs = L.qzstd_hip_malloc(device, nb * stride * 16)
+        d_cnt = L.qzstd_hip_malloc(device, nb * 4)
+        try:
+            if not (d_src and d_desc and d_seqs and d_cnt):
+                raise RuntimeError("qzstd_hip_malloc: " + self.err())
+            src_buf = (C.c_char * total).from_buffer(host_src)
+            self.check(L.qzstd_hip_memcpy_h2d(device, None, d_src, src_buf, total), "h2d src")
+            self.check(L.qzstd_hip_memcpy_h2d(device, None, d_desc, desc, C.sizeof(desc)), "h2d desc")
+            self.check(L.qzstd_hip_memset(device, None, d_cnt, 0, nb * 4), "memset")
+            self.check(L.qzstd_hip_find_sequences(device, None, level, d_src, d_desc, nb, maxlen, d_seqs, d_cnt),
+                       "qzstd_hip_find_sequences")
+            cnt = (C.c_uint32 * nb)()
+            seqs = (Sequence * (nb * stride))()
+            self.check(L.qzstd_hip_memcpy_d2h(device, None, cnt, d_cnt, nb * 4), "d2h counts")
+            self.check(L.qzstd_hip_memcpy_d2h(device, None, seqs, d_seqs, nb * stride * 16), "d2h seqs")
+            self.check(L.qzstd_hip_stream_sync(device, None), "sync")
+        finally:
+            for p in (d_src, d_desc, d_seqs, d_cnt):
+                if p:
+                    L.qzstd_hip_free(device, p)
+        return list(cnt), seqs, stride
