@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MI355X-native ZSTD block-level sequence producer.
+
+A "step" is one pass of the hot path (the HIP match-finder behind qatSequenceProducer,
+called through the C ABI qzstd_hip_find_sequences) over one batch of blocks that is
+already resident in HBM: BASELINE.json configs[1] = level 1, 128 KiB blocks, 1 GiB
+Silesia-like batch (8192 blocks) per GPU.  One process per GPU (torch.distributed.run);
+blocks are independent, so ranks share nothing on the data path (weak scaling, no
+collective besides the timing barrier / MAX).
+
+Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit, roofline
+(HBM-bound integer kernel: algorithmic bytes = block bytes read + 16 B per sequence
+written), cpu_baseline (the CPU oracle timed on a bounded sample), plus the
+north-star's own CPU baseline (libzstd's internal match-finder, plugin unregistered)
+and the compression ratio of the produced sequences vs software zstd.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import qz_bind as B  # noqa: E402
+import qz_corpus as K  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--block", type=int, default=131072)
+    ap.add_argument("--blocks", type=int, default=8192, help="blocks per GPU per step (8192 x 128 KiB = 1 GiB)")
+    ap.add_argument("--corpus", default="system", help="system | text | mix | weblog | mixed_entropy | /path/to/file")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / end-to-end legs")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def load_corpus(name: str, size: int) -> tuple[bytes, str]:
+    if os.path.isfile(name):
+        with open(name, "rb") as f:
+            raw = f.read()
+        reps = -(-size // len(raw))
+        return (raw * reps)[:size], "file:%s(%d) repeated" % (name, len(raw))
+    if name == "system":
+        return K.system_corpus(size)
+    seed = {"text": 1, "mix": 2, "weblog": 4, "mixed_entropy": 5}.get(name, 1)
+    unit = min(size, 64 * K.MiB)
+    raw = K.by_name(name, unit, seed)
+    reps = -(-size // len(raw))
+    return (raw * reps)[:size], "synthetic:%s(seed=%d,%d B) repeated" % (name, seed, unit)
+
+
+# ----------------------------------------------------------------------------- CPU legs
+def cpu_oracle_leg(data: bytes, block: int, level: int, seconds: float):
+    """cpu_baseline: the CPU restatement of the same match-finder ("port"), 1 thread."""
+    orc = B.Oracle()
+    prof = orc.profile(level, block)
+    cap = B.sequence_bound(block)
+    out = (B.Sequence * cap)()
+    done = 0
+    t0 = time.perf_counter()
+    o = 0
+    while time.perf_counter() - t0 < seconds and o + block <= len(data):
+        orc.lib.qzo_find_sequences(C.byref(prof), data[o:o + block], block, out, cap)
+        o += block
+        done += block
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "oracle/qzstd_oracle.c qzo_find_sequences, first %d blocks of the batch, 1 thread" % (done // block)}
+
+
+def _compress_worker(zpath, data, block, level, lo, hi, producer, res, idx, hint=None):
+    z = B.Zstd(zpath)
+    state = None
+    if producer is not None:
+        state = producer.lib.QZSTD_createSeqProdState()
+        zc = z.cctx(level, producer=producer.producer_addr, state=state, validate=False)
+    else:
+        zc = z.cctx(level)
+    cap = z.lib.ZSTD_compressBound(block)
+    dst = C.create_string_buffer(cap)
+    view = (C.c_char * (hi - lo)).from_buffer_copy(data[lo:hi])
+    base = C.addressof(view)
+    total = 0
+    t0 = time.perf_counter()
+    if producer is not None and hint:
+        producer.lib.QZSTD_hintSource(state, base, hi - lo, block, level)
+    for o in range(0, hi - lo, block):
+        n = min(block, hi - lo - o)
+        r = z.lib.ZSTD_compress2(zc, dst, cap, base + o, n)
+        if z.is_error(r):
+            res[idx] = ("error", z.err(r))
+            return
+        total += r
+    res[idx] = (time.perf_counter() - t0, total)
+    z.free(zc)
+    if state:
+        producer.lib.QZSTD_freeSeqProdState(state)
+
+
+def threaded_compress(zpath, data, block, level, threads, producer=None, hint=False):
+    """benchmark.c shape (reference test/benchmark.c:300-321): T threads, own CCtx each,
+    one ZSTD_compress2 per chunk, each chunk its own frame."""
+    nb = len(data) // block
+    per = (nb // threads) * block
+    res = [None] * threads
+    ths = []
+    t0 = time.perf_counter()
+    for t in range(threads):
+        th = threading.Thread(target=_compress_worker, args=(zpath, data, block, level, t * per, (t + 1) * per,
+                                                             producer, res, t, hint))
+        th.start()
+        ths.append(th)
+    for th in ths:
+        th.join()
+    wall = time.perf_counter() - t0
+    for r in res:
+        if r is None or r[0] == "error":
+            return {"error": str(r)}
+    csize = sum(r[1] for r in res)
+    return {"MBps": round(per * threads / wall / 1e6, 1), "threads": threads, "bytes": per * threads,
+            "csize": csize, "ratio": round(per * threads / csize, 4)}
+
+
+def find_old_libzstd():
+    for p in ("/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"):
+        if os.path.isfile(p):
+            return p
+    return None
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    plug = B.Plugin()
+    L = plug.lib
+    assert L.qzstd_hip_device_count() > local, plug.err()
+
+    block, nb, level = a.block, a.blocks, a.level
+    size = block * nb
+    # every rank gets its own shard: rank r starts r*size/world into the (repeated) corpus
+    data, prov = load_corpus(a.corpus, size + (world - 1) * (size // max(world, 1)) if world > 1 else size)
+    shard = data[rank * (size // world):rank * (size // world) + size] if world > 1 else data
+
+    dev = torch.device("cuda", local)
+    d_src = torch.empty(size + 64, dtype=torch.uint8, device=dev)
+    d_src[:size].copy_(torch.frombuffer(bytearray(shard), dtype=torch.uint8))
+    stride = B.sequence_bound(block)
+    d_seqs = torch.empty((nb * stride, 4), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
+    desc = (B.HipBlock * nb)()
+    for i in range(nb):
+        desc[i].srcOff = i * block
+        desc[i].seqOff = i * stride
+        desc[i].srcLen = block
+        desc[i].seqCap = stride
+    d_desc = torch.empty(C.sizeof(desc), dtype=torch.uint8, device=dev)
+    d_desc.copy_(torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8))
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+
+    def step():
+        rc = L.qzstd_hip_find_sequences(local, C.c_void_p(stream.cuda_stream), level, C.c_void_p(d_src.data_ptr()),
+                                        C.c_void_p(d_desc.data_ptr()), nb, block, C.c_void_p(d_seqs.data_ptr()),
+                                        C.c_void_p(d_cnt.data_ptr()))
+        if rc != 0:
+            raise RuntimeError(plug.err())
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for k in range(a.steps):
+        step()
+        ev[k + 1].record(stream)  # HIP events on the launch stream: per-launch kernel time
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    wall = float(tw.item())
+    kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(a.steps)]
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    cnt = d_cnt.cpu().numpy().astype("uint32")
+    n_err = int((cnt == 0xFFFFFFFF).sum())
+    seq_total = int(cnt[cnt != 0xFFFFFFFF].sum())
+
+    if rank == 0:
+        total_bytes = size * world * a.steps
+        value = total_bytes / wall / 1e6
+        alg_bytes = size + 16 * seq_total  # per launch: block bytes read once + 16 B per sequence written
+        achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "input MB/s via ZSTD_compress2 L1 128KiB blocks @1/2/4/8 GPU; ratio vs sw zstd",
+            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(wall / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "level-%d, %d KiB blocks, %d blocks (%.2f GiB) per GPU, sequence production "
+                                   "(qzstd_hip_find_sequences = the kernel behind qatSequenceProducer), inputs resident in HBM"
+                                   % (level, block >> 10, nb, size / 2 ** 30),
+                       "corpus": prov[:300], "level": level, "block_bytes": block, "blocks_per_gpu": nb,
+                       "parallelism": "block-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "qzstd_find_sequences_kernel", "kernel_ms_avg": round(kern_avg_ms, 3),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "input_read_frac_of_peak": round(size / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "sequences_per_block": round(seq_total / max(nb - n_err, 1), 1), "error_blocks": n_err,
+        }
+        if not a.no_cpu:
+            ncpu = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_oracle_leg(shard, block, level, a.cpu_seconds)
+            # north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape
+            sample = shard[:min(len(shard), 256 * block)]
+            z157 = B.find_libzstd()
+            thr = min(ncpu, 16)
+            sw = threaded_compress(z157, sample, block, level, thr)
+            out["cpu_libzstd_sw"] = {"lib": os.path.basename(z157), "host_cores": ncpu, **(sw or {})}
+            old = find_old_libzstd()
+            if old:
+                sw_old = threaded_compress(old, sample, block, level, thr)
+                out["cpu_libzstd_sw_optimised_build"] = {"lib": os.path.basename(old), "host_cores": ncpu, **(sw_old or {})}
+            # end to end through ZSTD_compress2 with the plugin registered (look-ahead hint on)
+            L.QZSTD_startQatDevice()
+            e2e = threaded_compress(z157, sample, block, level, thr, producer=plug, hint=True)
+            L.QZSTD_stopQatDevice()
+            if e2e and sw and "csize" in e2e and "csize" in sw:
+                out["e2e_zstd_compress2_plugin"] = {**e2e, "csize_vs_sw": round(e2e["csize"] / sw["csize"], 4),
+                                                    "ratio_within_2pct": e2e["csize"] <= sw["csize"] * 1.02}
+            else:
+                out["e2e_zstd_compress2_plugin"] = e2e
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

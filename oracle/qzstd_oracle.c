@@ -53,7 +53,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    out->tableSize = blockSize > (64u << 10) ? 6100u : (blockSize > (32u << 10) ? 16384u : 8192u);
+    out->tableSize = blockSize > (64u << 10) ? 5800u : (blockSize > (32u << 10) ? 16384u : 8192u);
     out->tileLog = 10;
     out->capLen = level >= 6 ? 64 : 32;
     out->minMatch = 4;
@@ -202,7 +202,7 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
     while (p < nh) {
         uint32_t L, off, q, b = 0;
         if (!qzo_take(pf, &cand[p])) { p++; continue; }
-        if (pf->lazy && p + 1 < nh && ((p + 1) & ((1u << pf->tileLog) - 1u)) != 0 /* not across a tile edge */ &&
+        if (pf->lazy && p + 1 < nh && ((p + 1) & 63u) != 0 /* never across a 64-position window edge */ &&
             qzo_take(pf, &cand[p + 1]) && cand[p + 1].len > cand[p].len) {
             p++; /* one-step lazy: the next position has a strictly longer match */
             continue;

@@ -30,6 +30,7 @@
 
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "qzstd_hip.h"
@@ -51,6 +52,7 @@ struct LaunchArgs {
     uint4 *seqs; /* ZSTD_Sequence = 4 x u32 */
     uint32_t *nseq;
     qzstd_hip_profile_t prof[3]; /* by block size class: >64 KiB, >32 KiB, <=32 KiB */
+    uint32_t dbg; /* ablation switches for profiling (QZSTD_HIP_ABLATE), 0 in production */
 };
 
 /* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte_b32 */
@@ -108,7 +110,7 @@ __device__ void parse_tile(const qzstd_hip_profile_t &pf, const uint8_t *lds8, c
         if (st.cur >= w0 + 64) continue; /* window lies inside an already emitted match */
         const uint32_t pin = w0 - t0 + lane;
         const uint32_t r = results[pin];
-        const uint32_t r1 = pin + 1 < T ? results[pin + 1] : 0u; /* no lazy deferral across a tile edge */
+        const uint32_t r1 = lane != 63u ? results[pin + 1] : 0u; /* no lazy deferral across a window edge */
         const uint32_t len = r & 0xFFu, off = r >> 8;
         const uint32_t len1 = r1 & 0xFFu, off1 = r1 >> 8;
         const bool take = len != 0 && len >= min_len(pf, off);
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 atomicMax(&tbl[__umulhi(mix[j], pf.tableSize)], ((p + 1u) << kTagBits) | tag);
                 const uint32_t cap = pf.capLen < n - p ? pf.capLen : n - p;
                 uint32_t bestLen = 0, bestOff = 0;
+                if (args.dbg & 2u) continue;
                 const uint32_t e = old[j];
                 if (e != 0u && (e & kTagMask) == tag) {
                     const uint32_t q = (e >> kTagBits) - 1u;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 res[j] = bestLen ? ((bestOff << 8) | bestLen) : 0u;
             }
             havePrev = true;
-        } else if (t0 != 0u) {
+        } else if (t0 != 0u && !(args.dbg & 1u)) {
             parse_tile(pf, lds8, results, t0 - T, nh, n, lane, st, out, blk.seqCap);
         }
         __syncthreads(); /* B2: inserts done; parse wave finished reading the scratch */
@@ -448,6 +451,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     a.blocks = d_blocks;
     a.seqs = static_cast<uint4 *>(d_seqs);
     a.nseq = d_nseq;
+    { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
     hipLaunchKernelGGL(qzstd_find_sequences_kernel, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;

@@ -23,7 +23,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    if (blockSize > (64u << 10)) out->tableSize = 6100u;
+    if (blockSize > (64u << 10)) out->tableSize = 5800u;
     else if (blockSize > (32u << 10)) out->tableSize = 16384u;
     else out->tableSize = 8192u;
     out->tileLog = 10;

@@ -26,6 +26,7 @@
 #include "qzstd_hip.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,10 +38,10 @@
 #define QZ_LEVEL_MIN 1
 #define QZ_LEVEL_MAX 12
 #define QZ_RETRY_INTERVAL_BLOCKS 1000 /* re-probe a dead device every N failed blocks */
-#define QZ_GRAB_SWEEPS 10
+#define QZ_GRAB_SWEEPS 10000
 #define QZ_MAX_DEVICES 64
 #define QZ_MAX_SLOTS 1024
-#define QZ_DEFAULT_SLOTS_PER_DEVICE 8
+#define QZ_DEFAULT_SLOTS_PER_DEVICE 16
 #define QZ_FIRST_COPY_SEQS 16384u /* sequences fetched together with the count */
 
 static int qzLogLevel = DEBUGLEVEL; /* 0 silent, 1 errors, 2 events, 3 every sequence */
@@ -165,6 +166,7 @@ static int qzGrabSlot(int hint)
             const int i = (hint + k) % n;
             if (__sync_lock_test_and_set(&gProc.slots[i].lock, 1) == 0) return i;
         }
+        sched_yield(); /* every slot busy: more threads than slots; let the holders finish */
     }
     return -1;
 }

@@ -1,0 +1,120 @@
+"""The drop-in surface on a GPU box: ZSTD_compress2 / ZSTD_compressStream2 with
+qatSequenceProducer registered must (a) round-trip bit-exactly, (b) produce exactly the
+frame libzstd produces from the oracle's sequences, (c) stay within 2 % of libzstd's own
+software match-finder at the same level (benchmark.c framing: one frame per chunk)."""
+import ctypes as C
+import threading
+
+import pytest
+
+import qz_bind as B
+import qz_corpus as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def started(gpu_plugin):
+    assert gpu_plugin.lib.QZSTD_startQatDevice() == 0  # QZSTD_OK
+    yield gpu_plugin
+    gpu_plugin.lib.QZSTD_stopQatDevice()
+
+
+def compress_with(zstd, producer_addr, state, data, chunk, level, hint_lib=None):
+    zc = zstd.cctx(level, producer=producer_addr, state=state, fallback=False, validate=True)
+    if hint_lib is not None:
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        assert hint_lib.QZSTD_hintSource(state, buf, len(data), chunk, level) == 0
+        frames = []
+        cap = zstd.lib.ZSTD_compressBound(chunk)
+        dst = C.create_string_buffer(cap)
+        for o in range(0, len(data), chunk):
+            n = min(chunk, len(data) - o)
+            r = zstd.lib.ZSTD_compress2(zc, dst, cap, C.byref(buf, o), n)
+            assert not zstd.is_error(r), zstd.err(r)
+            frames.append(dst.raw[:r])
+    else:
+        _, frames = zstd.compress_chunks(zc, data, chunk)
+    zstd.free(zc)
+    return frames
+
+
+@pytest.mark.parametrize("level,chunk", [(1, 131072), (3, 131072), (6, 131072), (12, 32768), (1, 65536)])
+def test_compress2_matches_oracle_frames(started, zstd, oracle, level, chunk):
+    data = K.mix(21, 12 * 131072 + 4321)
+    st = started.lib.QZSTD_createSeqProdState()
+    got = compress_with(zstd, started.producer_addr, st, data, chunk, level)
+    started.lib.QZSTD_freeSeqProdState(st)
+    want = compress_with(zstd, oracle.producer_addr, None, data, chunk, level)
+    assert got == want  # same sequences in -> same frame bytes out
+    out = b"".join(zstd.decompress(f, chunk) for f in got)
+    assert out == data
+
+
+def test_hint_batch_path_identical(started, zstd, oracle):
+    data = K.by_name("system", 24 * 131072 + 777)
+    st = started.lib.QZSTD_createSeqProdState()
+    got = compress_with(zstd, started.producer_addr, st, data, 131072, 1, hint_lib=started.lib)
+    started.lib.QZSTD_freeSeqProdState(st)
+    want = compress_with(zstd, oracle.producer_addr, None, data, 131072, 1)
+    assert got == want
+    assert b"".join(zstd.decompress(f, 131072) for f in got) == data
+
+
+def test_one_shot_multiblock_frame(started, zstd):
+    """plain ZSTD_compress2 over 1 MiB+: libzstd calls the producer once per 128 KiB block
+    (and 1.5.7 may pre-split); every call is an independent block."""
+    data = K.text(8, (1 << 20) + 300000)
+    st = started.lib.QZSTD_createSeqProdState()
+    zc = zstd.cctx(1, producer=started.producer_addr, state=st, fallback=False, validate=True)
+    frame = zstd.compress2(zc, data)
+    zstd.free(zc)
+    started.lib.QZSTD_freeSeqProdState(st)
+    assert zstd.decompress(frame, len(data)) == data
+
+
+def test_ratio_within_2pct_of_software_l1(started, zstd):
+    data = K.by_name("system", 64 * 131072)
+    st = started.lib.QZSTD_createSeqProdState()
+    got = compress_with(zstd, started.producer_addr, st, data, 131072, 1, hint_lib=started.lib)
+    started.lib.QZSTD_freeSeqProdState(st)
+    zc = zstd.cctx(1)
+    sw, _ = zstd.compress_chunks(zc, data, 131072)
+    zstd.free(zc)
+    ours = sum(len(f) for f in got)
+    assert ours <= sw * 1.02, "compressed %d vs software %d (%.2f %% worse)" % (ours, sw, 100.0 * (ours / sw - 1))
+
+
+def test_guards_match_reference(started):
+    """argument guards of reference src/qatseqprod.c:1123-1137"""
+    L = started.lib
+    st = L.QZSTD_createSeqProdState()
+    seqs = (B.Sequence * 64)()
+    src = C.create_string_buffer(K.incompressible(1, 100))
+    err = B.SEQ_ERROR
+    assert L.qatSequenceProducer(st, seqs, 64, src, 100, None, 0, 0, 1 << 17) == err      # level 0
+    assert L.qatSequenceProducer(st, seqs, 64, src, 100, None, 0, 13, 1 << 17) == err     # level 13
+    assert L.qatSequenceProducer(st, seqs, 64, src, 100, src, 0, 1, 1 << 17) == err       # dict pointer
+    assert L.qatSequenceProducer(st, seqs, 64, src, 100, None, 5, 1, 1 << 17) == err      # dict size
+    assert L.qatSequenceProducer(st, seqs, 64, src, 100, None, 0, 1, 50) == err           # window < srcSize
+    assert L.qatSequenceProducer(st, seqs, 64, src, 100, None, 0, 1, 100) == 1            # incompressible -> 1 delimiter
+    assert (seqs[0].offset, seqs[0].litLength, seqs[0].matchLength) == (0, 100, 0)
+    L.QZSTD_freeSeqProdState(st)
+
+
+def test_threads_each_with_own_cctx(started, zstd, oracle):
+    """reference scaling model: one CCtx + one state per thread (README.md:138, benchmark.c:514-516)"""
+    data = [K.mix(100 + t, 6 * 131072) for t in range(6)]
+    res = [None] * len(data)
+
+    def work(t):
+        z = B.Zstd(zstd.path)
+        st = started.lib.QZSTD_createSeqProdState()
+        res[t] = compress_with(z, started.producer_addr, st, data[t], 131072, 1)
+        started.lib.QZSTD_freeSeqProdState(st)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(len(data))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for t in range(len(data)):
+        assert res[t] == compress_with(zstd, oracle.producer_addr, None, data[t], 131072, 1)

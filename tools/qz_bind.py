@@ -85,13 +85,16 @@ class Zstd:
         L.ZSTD_compress2.restype = C.c_size_t
         L.ZSTD_compressBound.argtypes = [C.c_size_t]
         L.ZSTD_compressBound.restype = C.c_size_t
-        L.ZSTD_sequenceBound.argtypes = [C.c_size_t]
-        L.ZSTD_sequenceBound.restype = C.c_size_t
         L.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ZSTD_decompress.restype = C.c_size_t
         L.ZSTD_isError.argtypes = [C.c_size_t]
         L.ZSTD_getErrorName.argtypes = [C.c_size_t]
         L.ZSTD_getErrorName.restype = C.c_char_p
+        self.has_producer_api = hasattr(L, "ZSTD_registerSequenceProducer")
+        if not self.has_producer_api:  # libzstd 1.4.x: software baseline timing only
+            return
+        L.ZSTD_sequenceBound.argtypes = [C.c_size_t]
+        L.ZSTD_sequenceBound.restype = C.c_size_t
         L.ZSTD_registerSequenceProducer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ZSTD_registerSequenceProducer.restype = None
         L.ZSTD_cParam_getBounds.argtypes = [C.c_int]
