@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Debug helper (GPU box): first differing sequence between the HIP path and the oracle."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import qz_bind as B, qz_corpus as K
+
+def main():
+    plug, orc = B.Plugin(), B.Oracle()
+    sizes = [int(a) for a in sys.argv[1:]] or [600, 1500, 3000, 9000, 131072]
+    base = K.text(1, 140000)
+    for n in sizes:
+        blk = base[:n]
+        counts, seqs, stride = plug.find_batch([blk], 1)
+        want_n, want = orc.find(orc.profile(1, n), blk, cap=stride)
+        g = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)[:max(counts[0], 1) if counts[0] != B.NSEQ_ERROR else 1, :3]
+        w = np.frombuffer(want, dtype=np.uint32).reshape(-1, 4)[:want_n, :3]
+        m = min(len(g), len(w))
+        diff = np.nonzero((g[:m] != w[:m]).any(axis=1))[0]
+        print("n=%d gpu_count=%d oracle_count=%d first_diff=%s" % (n, counts[0], want_n, diff[:1]))
+        if len(diff):
+            i = int(diff[0])
+            pos_g = int(g[:i, 1].sum() + g[:i, 2].sum())
+            print("  at seq %d (block pos %d, window %d lane %d):" % (i, pos_g, pos_g // 64, pos_g % 64))
+            for k in range(max(0, i - 2), min(m, i + 4)):
+                print("   %5d gpu %-22s oracle %-22s" % (k, g[k].tolist(), w[k].tolist()))
+main()
+
+def dump(n=3000, first=14, count=12):
+    plug, orc = B.Plugin(os.path.join(B.PKG_DIR, "lib", "libqatseqprod_dbg.so")), B.Oracle()
+    blk = K.text(1, 140000)[:n]
+    counts, seqs, stride = plug.find_batch([blk], 1)
+    a = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)
+    for wi in range(first, first + count):
+        s = a[stride - 1 - 2 * wi]; c = a[stride - 2 - 2 * wi]
+        print("win %3d (pos %5d): chosen %08x%08x curIn %d (rel %d) anchorIn %d | vis %08x%08x chainLo %08x exit %d" % (
+            wi, wi * 64, s[1], s[0], s[2], int(s[2]) - wi * 64, s[3], c[1], c[0], c[2], c[3]))
+if os.environ.get("QZ_DUMP"):
+    dump()
