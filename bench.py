@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import qz_bind as B  # noqa: E402
 import qz_corpus as K  # noqa: E402
+import qz_shard as S  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -165,8 +166,9 @@ def main():
     block, nb, level = a.block, a.blocks, a.level
     size = block * nb
     # every rank gets its own shard: rank r starts r*size/world into the (repeated) corpus
-    data, prov = load_corpus(a.corpus, size + (world - 1) * (size // max(world, 1)) if world > 1 else size)
-    shard = data[rank * (size // world):rank * (size // world) + size] if world > 1 else data
+    off = S.weak_offset(size, world, rank)
+    data, prov = load_corpus(a.corpus, size + S.weak_offset(size, world, world - 1))
+    shard = data[off:off + size]
 
     dev = torch.device("cuda", local)
     d_src = torch.empty(size + 64, dtype=torch.uint8, device=dev)
@@ -209,10 +211,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    tw = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-    wall = float(tw.item())
+    wall = S.reduce_max_seconds(wall, dist if world > 1 else None, dev)
     kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(a.steps)]
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
@@ -248,7 +247,7 @@ def main():
             # north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape
             sample = shard[:min(len(shard), 256 * block)]
             z157 = B.find_libzstd()
-            thr = min(ncpu, 16)
+            thr = min(ncpu, 16)  # <= QZ_DEFAULT_SLOTS_PER_DEVICE: one slot per thread
             sw = threaded_compress(z157, sample, block, level, thr)
             out["cpu_libzstd_sw"] = {"lib": os.path.basename(z157), "host_cores": ncpu, **(sw or {})}
             old = find_old_libzstd()

@@ -57,6 +57,7 @@ struct LaunchArgs {
     uint4 *seqs; /* ZSTD_Sequence = 4 x u32 */
     uint32_t *nseq;
     qzstd_hip_profile_t prof[3]; /* by block size class: >64 KiB, >32 KiB, <=32 KiB */
+    uint32_t dbg; /* profiling ablation switches (QZSTD_HIP_ABLATE); 0 in production */
 };
 
 typedef unsigned long long u64;
@@ -405,14 +406,14 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 
         /* ================= interval 1 ================= */
         if (matcher) {
-            if (it >= 2u && it - 2u < nTiles) { /* emit(it-2) */
+            if (it >= 2u && it - 2u < nTiles && !(args.dbg & 8u)) { /* emit(it-2) */
 #pragma unroll
                 for (int j = 0; j < kMaxPosPerThread; j++) {
                     const uint32_t w = wave + (uint32_t)j * kMatchWaves;
                     if (w < nWin) emit_window(pf, lds32, srec + w * 8u, resOld[j], t0 - 2u * T + 64u * w, lane, out, blk.seqCap);
                 }
             }
-            if (it >= 1u && it - 1u < nTiles) { /* speculative chains(it-1) */
+            if (it >= 1u && it - 1u < nTiles && !(args.dbg & 4u)) { /* speculative chains(it-1) */
 #pragma unroll
                 for (int j = 0; j < kMaxPosPerThread; j++) {
                     const uint32_t w = wave + (uint32_t)j * kMatchWaves;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                         if (q < p) q2 = q;
                     }
                     uint32_t bestLen = 0, bestOff = 0;
-                    if (q1 != kNone || q2 != kNone) {
+                    if ((q1 != kNone || q2 != kNone) && !(args.dbg & 2u)) {
                         uint32_t own[9];
                         const uint32_t pd = p >> 2;
 #pragma unroll
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                     if (pin >= T - 64u) save[(it & 1u) * 64u + (pin - (T - 64u))] = resNew[j];
                 }
             }
-        } else if (it >= 1u && it - 1u < nTiles) {
+        } else if (it >= 1u && it - 1u < nTiles && !(args.dbg & 1u)) {
             serial_pass(pf, lds32, R, crec, srec, t0 - T, nWin, n, lane, st, out + blk.seqCap);
         }
         __syncthreads(); /* B2 */
@@ -662,6 +663,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     a.blocks = d_blocks;
     a.seqs = static_cast<uint4 *>(d_seqs);
     a.nseq = d_nseq;
+    { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
     hipLaunchKernelGGL(qzstd_find_sequences_kernel, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;
