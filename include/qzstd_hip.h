@@ -50,7 +50,7 @@ typedef struct {
     uint32_t nearTab;   /* 1 = tile-local "earliest occurrence" probe                      */
     uint32_t window;    /* max offset, 0 = whole block                                     */
     uint32_t hashBytes; /* bytes hashed per position (4..8)                                */
-    uint32_t reserved;
+    uint32_t extLog;    /* a match never extends past the end of the next 1<<extLog cell       */
 } qzstd_hip_profile_t;
 
 /* One work item = one <=128 KiB block, parsed with no history

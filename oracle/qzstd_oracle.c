@@ -17,7 +17,7 @@
  *   2. LENGTHS: common-prefix length of candidate and position, capped at capLen.
  *   3. PARSE: greedy (or one-step lazy) left-to-right selection over the
  *      per-position (length, offset) array; a chosen match that hit the cap is
- *      extended to its true end; optional short backward extension into the
+ *      extended to its true end (bounded by extLog); optional short backward extension into the
  *      pending literals.
  *   4. EMISSION: {offset, litLength, matchLength}, then the trailing-literals
  *      delimiter — the output contract of QZSTD_decLz4s,
@@ -53,8 +53,8 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    out->tableSize = blockSize > (64u << 10) ? 5700u : (blockSize > (32u << 10) ? 16384u : 8192u);
-    out->tileLog = 10;
+    out->tableSize = blockSize > (64u << 10) ? 6600u : (blockSize > (32u << 10) ? 16384u : 8192u);
+    out->tileLog = 9;
     out->capLen = level >= 6 ? 64 : 32;
     out->minMatch = 4;
     out->farLog1 = 12;
@@ -64,6 +64,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->nearTab = 1;
     out->window = 0;
     out->hashBytes = 5;
+    out->extLog = 11;
     return 0;
 }
 
@@ -188,7 +189,7 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
 
     if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
-        pf->capLen < pf->minMatch + 2 || pf->hashBytes < 4 || pf->hashBytes > 8)
+        pf->capLen < pf->minMatch + 2 || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17)
         return QZO_ERROR;
     nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
 
@@ -210,8 +211,13 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
         L = cand[p].len;
         off = cand[p].off;
         q = p - off;
-        if (L == pf->capLen) /* hit the candidate-phase cap: extend to the true end */
-            while (p + L < n && src[q + L] == src[p + L]) L++;
+        if (L == pf->capLen) { /* hit the candidate-phase cap: extend to the true end */
+            /* ... but never past the end of the NEXT 1<<extLog cell: bounds the parallel extension
+             * work (a longer repeat simply continues as another sequence) */
+            const uint32_t l0 = ((p >> pf->extLog) + 2u) << pf->extLog;
+            const uint32_t lim = l0 < n ? l0 : n;
+            while (p + L < lim && src[q + L] == src[p + L]) L++;
+        }
         while (b < pf->backExt && p - b > anchor && q - b > 0 && src[p - b - 1] == src[q - b - 1]) b++;
         if (ns + 1 >= cap - 1) { ns = QZO_ERROR; goto done; } /* src/qatseqprod.c:1073-1076 */
         out[ns].offset = off;

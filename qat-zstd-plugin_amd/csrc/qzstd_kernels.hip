@@ -38,18 +38,20 @@
 namespace {
 
 constexpr int kMatchWaves = 8;
-constexpr int kMatchThreads = kMatchWaves * 64;
-constexpr int kThreads = kMatchThreads + 64; /* + 1 parse wave */
-constexpr int kMaxPosPerThread = 2;          /* tileLog <= 10 -> <= 1024 / 512 */
-constexpr int kMaxWindows = 16;              /* 64-position windows per tile */
+constexpr int kMatchThreads = kMatchWaves * 64; /* one position per matcher thread per tile */
+constexpr int kThreads = kMatchThreads + 64;     /* + 1 parse wave */
+constexpr uint32_t kTileLog = 9;                 /* tile = 512 positions = kMatchThreads */
+constexpr uint32_t kTile = 1u << kTileLog;
+constexpr uint32_t kWin = kTile >> 6;            /* 64-position windows per tile (one per matcher wave) */
+constexpr uint32_t kGroups = kTile >> 4;         /* 16-position groups per tile: one parse chain each */
+constexpr uint32_t kSlots = 3;                   /* tiles in flight between matchers and the parse wave */
 constexpr uint32_t kTagBits = 14;
 constexpr uint32_t kTagMask = (1u << kTagBits) - 1u;
 constexpr uint32_t kPrime1 = 2654435761u;
 constexpr uint32_t kPrime2 = 0x85EBCA77u;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-/* LDS words behind the per-position scratch: see layout in the kernel */
-constexpr uint32_t kSaveWords = 128;              /* last window of a tile, double buffered */
-constexpr uint32_t kRecWords = kMaxWindows * 8;   /* per-window records, two kinds */
+/* per-window parse record (8 words): start mask, stop mask, chosen mask, last chosen end, max reach */
+enum { W_START = 0, W_STOP = 2, W_CHOSEN = 4, W_LASTEND = 6, W_REACH = 7, W_WORDS = 8 };
 
 struct LaunchArgs {
     const uint8_t *src;
@@ -57,15 +59,15 @@ struct LaunchArgs {
     uint4 *seqs; /* ZSTD_Sequence = 4 x u32 */
     uint32_t *nseq;
     qzstd_hip_profile_t prof[3]; /* by block size class: >64 KiB, >32 KiB, <=32 KiB */
-    uint32_t dbg; /* profiling ablation switches (QZSTD_HIP_ABLATE); 0 in production */
 };
 
 typedef unsigned long long u64;
 
 /* v_readlane_b32 with an unsigned result (the builtin returns int: a set bit 31 would sign-extend) */
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-
 __device__ __forceinline__ u64 below(uint32_t c) { return c >= 64u ? ~0ull : ((1ull << c) - 1ull); }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 /* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte_b32 */
 __device__ __forceinline__ uint32_t lds_rd32u(const uint32_t *lds32, uint32_t a)
@@ -113,36 +115,18 @@ __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint3
     return pf.minMatch + ((off >> pf.farLog1) ? 1u : 0u) + ((off >> pf.farLog2) ? 1u : 0u);
 }
 
-/* which positions of a 64-position window may start a match (the lazy rule never looks
- * across the window edge), and which of those hit the candidate cap */
-struct WinFlags { u64 start, capped; };
-__device__ __forceinline__ WinFlags window_flags(const qzstd_hip_profile_t &pf, uint32_t r, uint32_t lane)
-{
-    const uint32_t len = r & 0xFFu, off = r >> 8;
-    const uint32_t r1 = __shfl_down(r, 1);
-    const uint32_t len1 = r1 & 0xFFu, off1 = r1 >> 8;
-    const bool take = len != 0u && len >= min_len(pf, off);
-    const bool take1 = len1 != 0u && len1 >= min_len(pf, off1);
-    const bool start = take && !(pf.lazy && lane != 63u && take1 && len1 > len);
-    WinFlags w;
-    w.start = __ballot(start);
-    w.capped = __ballot(start && len == pf.capLen);
-    return w;
-}
-
-/* cooperative forward extension of a chosen match that hit the candidate cap:
- * 64 lanes x 4 bytes per step */
+/* cooperative forward extension of a match that hit the candidate cap: 64 lanes x 4 bytes
+ * per step, never past `lim` */
 __device__ __forceinline__ uint32_t extend_match(const uint32_t *lds32, uint32_t p, uint32_t off, uint32_t L,
-                                                 uint32_t n, uint32_t lane)
+                                                 uint32_t lim, uint32_t lane)
 {
     for (;;) {
         const uint32_t a = p + L + 4u * lane;
-        uint32_t ok = 0; /* bytes of this lane's dword that match and lie inside the block */
-        if (a < n) {
+        uint32_t ok = 0; /* bytes of this lane's dword that match and lie below lim */
+        if (a < lim) {
             const uint32_t x = lds_rd32u(lds32, a) ^ lds_rd32u(lds32, a - off);
             ok = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
-            const uint32_t room = n - a;
-            ok = ok < room ? ok : room;
+            ok = umin(ok, lim - a);
         }
         const u64 bad = __ballot(ok < 4u);
         if (bad) {
@@ -153,196 +137,156 @@ __device__ __forceinline__ uint32_t extend_match(const uint32_t *lds32, uint32_t
     }
 }
 
-/*
- * Speculative chain of one window (run by the wave that owns the window, all windows
- * of a tile in parallel).  The chain is warmed up over the previous window so that it
- * has (almost always) merged with the true parse before it enters this one.  Lengths
- * are the capped candidate lengths; capped starts on the chain are flagged so that the
- * serial pass can extend them.  Record (8 words): visited mask, chain-start mask,
- * capped-on-chain mask, exit cursor (window relative, >= 64), end of the last chain match.
- */
-__device__ __forceinline__ void spec_chain(const qzstd_hip_profile_t &pf, uint32_t rPrev, bool havePrev,
-                                           uint32_t r, uint32_t lane, uint32_t *rec)
+/* inclusive max-scan across the 64 lanes of a wave */
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x, uint32_t lane)
 {
-    uint32_t c = 0;
-    if (havePrev) {
-        const WinFlags fp = window_flags(pf, rPrev, lane);
-        const uint32_t lenP = rPrev & 0xFFu;
-        for (;;) {
-            const u64 m = c < 64u ? (fp.start >> c) << c : 0ull;
-            if (!m) { c = 64u; break; }
-            const uint32_t j = (uint32_t)__builtin_ctzll(m);
-            c = j + rdlane(lenP, j);
-            if (c >= 64u) break;
-        }
-        c -= 64u;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t t = __shfl_up(x, d);
+        if (lane >= d) x = umax(x, t);
     }
-    const WinFlags f = window_flags(pf, r, lane);
-    const uint32_t len = r & 0xFFu;
-    u64 visited = 0, chain = 0;
-    uint32_t lastEnd = kNone, exitC = c;
-    while (c < 64u) {
-        const u64 m = (f.start >> c) << c;
-        if (!m) { visited |= ~below(c); exitC = 64u; break; }
-        const uint32_t j = (uint32_t)__builtin_ctzll(m);
-        visited |= below(j + 1u) & ~below(c);
-        chain |= 1ull << j;
-        c = j + rdlane(len, j);
-        lastEnd = c;
-        exitC = c;
-    }
-    const u64 cap = chain & f.capped;
-    uint32_t v = 0;
-    v = lane == 0 ? (uint32_t)visited : v;
-    v = lane == 1 ? (uint32_t)(visited >> 32) : v;
-    v = lane == 2 ? (uint32_t)chain : v;
-    v = lane == 3 ? (uint32_t)(chain >> 32) : v;
-    v = lane == 4 ? (uint32_t)cap : v;
-    v = lane == 5 ? (uint32_t)(cap >> 32) : v;
-    v = lane == 6 ? exitC : v;
-    v = lane == 7 ? lastEnd : v;
-    if (lane < 8u) rec[lane] = v;
+    return x;
 }
 
 /* parse-wave state, uniform across the wave */
 struct ParseState {
-    uint32_t cur;    /* next position the parse looks at */
-    uint32_t anchor; /* end of the last chosen match = start of pending literals */
-    uint32_t nseq;   /* matches chosen so far */
+    uint32_t anchor;  /* end of the last chosen match = start of pending literals */
+    uint32_t nseq;    /* matches chosen so far */
+    uint32_t pending; /* standing position a chain reached beyond the data available to its pass */
 };
 
 /*
- * Serial pass over the windows of one tile (parse wave).  O(1) per window when the true
- * cursor lies on the window's speculative chain; otherwise it steps manually (readlane
- * over the preloaded candidates) until it merges.  Capped matches are extended here.
- * Output record per window (8 words): chosen mask, anchor at entry, sequence index base,
- * up to two (lane, extended length) pairs.
+ * The parse of one tile, by the parse wave, all chains of the tile in parallel.
+ *
+ * A position is a SYNC point when no potential match start before it reaches beyond it; the
+ * (lazy) greedy parse provably stands on every sync point, so the stretches between sync
+ * points can be parsed independently.  One lane per 16-position group starts at the group's
+ * first sync point ("stop point") and follows next-start / jump-by-length until it stands on
+ * another stop point; lane 32 continues a chain that an earlier pass had to suspend.  Chosen
+ * starts are OR-ed into the per-window masks (ds_or), match ends MAX-ed (ds_max).  Then the
+ * per-window sequence index bases and literal anchors of tile k are prefix-summed and
+ * published for the emitting waves.
  */
-__device__ void serial_pass(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t (&R)[kMaxWindows],
-                            const uint32_t *crec, uint32_t *srec, uint32_t t0, uint32_t nWin, uint32_t n,
-                            uint32_t lane, ParseState &st, uint4 *dbg)
+__device__ void parse_pass(uint32_t *wrec, const uint16_t *lens, uint32_t *srecOut, uint32_t k, uint32_t nTiles,
+                           uint32_t lane, ParseState &st)
 {
-    const uint32_t c0 = crec[lane], c1 = crec[64u + lane]; /* 16 windows x 8 words */
-#pragma unroll
-    for (int w = 0; w < kMaxWindows; w++) {
-        if ((uint32_t)w >= nWin) break;
-        const uint32_t w0 = t0 + 64u * (uint32_t)w;
-        u64 chosen = 0;
-        uint32_t ext0 = kNone, ext1 = kNone;
-        const uint32_t anchorIn = st.anchor, seqBase = st.nseq;
-#ifdef QZ_DEBUG_DUMP
-        const uint32_t curIn = st.cur;
-#endif
-        if (st.cur < w0 + 64u) {
-            const uint32_t cv = w < 8 ? c0 : c1;
-            const int b = (w & 7) * 8;
-            const u64 vis = (u64)rdlane(cv, (uint32_t)b) | ((u64)rdlane(cv, (uint32_t)b + 1u) << 32);
-            const u64 chain = (u64)rdlane(cv, (uint32_t)b + 2u) | ((u64)rdlane(cv, (uint32_t)b + 3u) << 32);
-            const u64 capc = (u64)rdlane(cv, (uint32_t)b + 4u) | ((u64)rdlane(cv, (uint32_t)b + 5u) << 32);
-            const uint32_t exitC = rdlane(cv, (uint32_t)b + 6u);
-            const uint32_t lastEnd = rdlane(cv, (uint32_t)b + 7u);
-            uint32_t c = st.cur - w0;
-            bool haveFlags = false;
-            WinFlags f = { 0ull, 0ull };
-            const uint32_t rw = R[w];
-            for (;;) {
-                uint32_t j, L;
-                if ((vis >> c) & 1ull) {
-                    /* on the speculative chain: everything from c on is already known */
-                    const u64 cc = capc & ~below(c);
-                    if (!cc) {
-                        const u64 sel = chain & ~below(c);
-                        chosen |= sel;
-                        if (sel) st.anchor = w0 + lastEnd;
-                        st.cur = w0 + exitC;
-                        break;
-                    }
-                    j = (uint32_t)__builtin_ctzll(cc);
-                    chosen |= chain & ~below(c) & below(j);
-                    L = pf.capLen;
+    const uint32_t base = k << kTileLog;
+    const uint32_t limit = umin(k + 2u, nTiles) << kTileLog; /* tiles k and k+1 are complete */
+    const uint32_t slotK = k % kSlots;
+    uint32_t c = 0;
+    bool active = false, first = true;
+    if (lane < kGroups) {
+        const uint32_t w = lane >> 2, sub = lane & 3u;
+        const uint32_t *r = wrec + (slotK * kWin + w) * W_WORDS;
+        const uint32_t bits = ((sub & 2u ? r[W_STOP + 1] : r[W_STOP]) >> (16u * (sub & 1u))) & 0xFFFFu;
+        if (bits) { active = true; c = base + 64u * w + 16u * sub + (uint32_t)__builtin_ctz(bits); }
+    } else if (lane == kGroups && st.pending != kNone && (st.pending >> kTileLog) == k) {
+        active = true; first = false; c = st.pending;
+    }
+    if (st.pending != kNone && (st.pending >> kTileLog) == k) st.pending = kNone;
+    bool suspended = false;
+    while (__any(active)) {
+        if (active) {
+            const uint32_t tile = c >> kTileLog, w = (c >> 6) & (kWin - 1u), rel = c & 63u;
+            uint32_t *r = wrec + ((tile % kSlots) * kWin + w) * W_WORDS;
+            const u64 start = (u64)r[W_START] | ((u64)r[W_START + 1] << 32);
+            const u64 stop = (u64)r[W_STOP] | ((u64)r[W_STOP + 1] << 32);
+            const u64 ms = start >> rel, ss = stop >> rel;
+            if (!first && (ss & 1ull)) {
+                active = false; /* standing on another chain's starting point */
+            } else {
+                const u64 ss1 = ss & ~1ull;
+                const uint32_t jrel = ms ? (uint32_t)__builtin_ctzll(ms) : 64u;
+                const uint32_t srel = ss1 ? (uint32_t)__builtin_ctzll(ss1) : 64u;
+                if (srel <= jrel && srel != 64u) {
+                    active = false; /* literals up to the next stop point */
+                } else if (jrel == 64u) {
+                    c = (c | 63u) + 1u; /* no start left in this window: walk into the next one */
+                    if (c >= limit) { active = false; suspended = true; }
                 } else {
-                    if (!haveFlags) { f = window_flags(pf, rw, lane); haveFlags = true; }
-                    const u64 m = (f.start >> c) << c;
-                    if (!m) { st.cur = w0 + 64u; break; }
-                    j = (uint32_t)__builtin_ctzll(m);
-                    L = rdlane(rw, j) & 0xFFu;
+                    const uint32_t j = c + jrel, jpos = j & 63u;
+                    const uint32_t L = lens[(tile % kSlots) * kTile + (j & (kTile - 1u))];
+                    atomicOr(&r[W_CHOSEN + (jpos >> 5)], 1u << (jpos & 31u));
+                    atomicMax(&r[W_LASTEND], j + L);
+                    c = j + L;
+                    if (c >= limit) { active = false; suspended = true; }
                 }
-                chosen |= 1ull << j;
-                if (L == pf.capLen) {
-                    L = extend_match(lds32, w0 + j, rdlane(rw, j) >> 8, L, n, lane);
-                    const uint32_t e = (j << 24) | L;
-                    if (ext0 == kNone) ext0 = e; else ext1 = e;
-                }
-                c = j + L;
-                st.anchor = w0 + c;
-                if (c >= 64u) { st.cur = w0 + c; break; }
+                first = false;
             }
-            st.nseq += (uint32_t)__popcll(chosen);
         }
-        uint32_t v = 0;
-        v = lane == 0 ? (uint32_t)chosen : v;
-        v = lane == 1 ? (uint32_t)(chosen >> 32) : v;
-        v = lane == 2 ? anchorIn : v;
-        v = lane == 3 ? seqBase : v;
-        v = lane == 4 ? ext0 : v;
-        v = lane == 5 ? ext1 : v;
-        if (lane < 8u) srec[w * 8 + (int)lane] = v;
-#ifdef QZ_DEBUG_DUMP
-        if (lane == 0) {
-            const uint32_t wi = (w0 >> 6);
-            dbg[-(int)(2 * wi) - 1] = make_uint4((uint32_t)chosen, (uint32_t)(chosen >> 32), curIn, anchorIn);
-            dbg[-(int)(2 * wi) - 2] = make_uint4(crec[w * 8 + 0], crec[w * 8 + 1], crec[w * 8 + 2], crec[w * 8 + 6]);
+    }
+    {
+        const u64 sm = __ballot(suspended);
+        if (sm) st.pending = rdlane(c, 63u - (uint32_t)__builtin_clzll(sm));
+    }
+    /* finalize tile k: lanes 0..kWin-1 = windows */
+    {
+        const uint32_t w = lane < kWin ? lane : 0u;
+        const uint32_t *r = wrec + (slotK * kWin + w) * W_WORDS;
+        const uint32_t cLo = lane < kWin ? r[W_CHOSEN] : 0u, cHi = lane < kWin ? r[W_CHOSEN + 1] : 0u;
+        const uint32_t le = lane < kWin ? r[W_LASTEND] : 0u;
+        const uint32_t cnt = (uint32_t)__popc(cLo) + (uint32_t)__popc(cHi);
+        uint32_t ps = cnt, pm = le; /* inclusive prefix sum / max over the kWin window lanes */
+#pragma unroll
+        for (uint32_t d = 1; d < kWin; d <<= 1) {
+            const uint32_t a = __shfl_up(ps, d), b = __shfl_up(pm, d);
+            if (lane >= d) { ps += a; pm = umax(pm, b); }
         }
-#endif
+        const uint32_t exm = __shfl_up(pm, 1);
+        if (lane < kWin) {
+            uint4 o;
+            o.x = cLo; o.y = cHi;
+            o.z = umax(st.anchor, lane ? exm : 0u); /* anchor when the parse enters the window */
+            o.w = st.nseq + ps - cnt;               /* index of the window's first sequence */
+            reinterpret_cast<uint4 *>(srecOut)[lane] = o;
+        }
+        st.nseq += rdlane(ps, kWin - 1u);
+        st.anchor = umax(st.anchor, rdlane(pm, kWin - 1u));
     }
 }
 
 /* emission of one window's chosen matches by the wave that owns the window */
 __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t *srec,
-                                            uint32_t r, uint32_t w0, uint32_t lane, uint4 *out, uint32_t seqCap)
+                                            uint32_t off, uint32_t len, uint32_t w0, uint32_t lane, uint4 *out,
+                                            uint32_t seqCap)
 {
-    const u64 chosen = (u64)srec[0] | ((u64)srec[1] << 32);
+    const uint4 rec = *reinterpret_cast<const uint4 *>(srec);
+    const u64 chosen = (u64)rec.x | ((u64)rec.y << 32);
     if (!chosen) return;
-    const uint32_t anchorIn = srec[2], seqBase = srec[3], ext0 = srec[4], ext1 = srec[5];
-    const uint32_t off = r >> 8;
-    uint32_t Lfin = r & 0xFFu;
-    if (ext0 != kNone && (ext0 >> 24) == lane) Lfin = ext0 & 0xFFFFFFu;
-    if (ext1 != kNone && (ext1 >> 24) == lane) Lfin = ext1 & 0xFFFFFFu;
+    const uint32_t anchorIn = rec.z, seqBase = rec.w;
     const bool ch = (chosen >> lane) & 1ull;
     const u64 lower = chosen & below(lane);
     const uint32_t rank = (uint32_t)__popcll(lower);
-    const uint32_t myEnd = w0 + lane + Lfin;
+    const uint32_t myEnd = w0 + lane + len;
     const int jprev = lower ? 63 - __builtin_clzll(lower) : 0;
     uint32_t prevEnd = __shfl(myEnd, jprev);
     if (!lower) prevEnd = anchorIn;
     if (ch) {
         const uint32_t p = w0 + lane, q = p - off;
         const uint32_t lit = p - prevEnd;
-        uint32_t maxb = pf.backExt < lit ? pf.backExt : lit;
-        maxb = maxb < q ? maxb : q;
+        uint32_t maxb = umin(umin(pf.backExt, lit), q);
         uint32_t b = 0;
         if (maxb) {
             /* the 4 bytes before p and before q, top byte = nearest; count equal bytes from the top */
             const uint32_t pb = p >= 4u ? lds_rd32u(lds32, p - 4u) : lds32[0] << (8u * (4u - p));
             const uint32_t qb = q >= 4u ? lds_rd32u(lds32, q - 4u) : lds32[0] << (8u * (4u - q));
             const uint32_t x = pb ^ qb;
-            b = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u;
-            b = b < maxb ? b : maxb;
+            b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
         }
         const uint32_t idx = seqBase + rank;
-        if (idx < seqCap) out[idx] = make_uint4(off, lit - b, Lfin + b, 0u);
+        if (idx < seqCap) out[idx] = make_uint4(off, lit - b, len + b, 0u);
     }
 }
 
 /*
- * One workgroup = one block.  8 matcher waves + 1 parse wave, software-pipelined over
- * tiles with two barriers per tile:
+ * One workgroup = one block.  8 matcher waves (one position per thread per 512-position tile)
+ * + 1 parse wave, software-pipelined over tiles with two barriers per iteration:
  *
- *   interval 1 of iteration it      matchers: emit(it-2), speculative chains(it-1), phase A(it)
- *                                   parse wave: preload candidates(it-1) into registers
+ *   interval 1 of iteration it   matchers: sync/stop masks of tile it-1, phase A(it) (table look-up)
  *   barrier
- *   interval 2                      matchers: phase B(it) + candidate lengths(it)
- *                                   parse wave: serial pass(it-1)
+ *   interval 2                   matchers: emit(it-3), phase B(it) (insert), candidate lengths,
+ *                                          run extension, start flags, reach of tile it
+ *                                parse wave: chains + prefix sums of tile it-2
  *   barrier
  */
 __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
@@ -354,11 +298,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     const bool matcher = tid < (uint32_t)kMatchThreads;
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     const uint32_t n = blk.srcLen;
-    const qzstd_hip_profile_t &pf = args.prof[n > (64u << 10) ? 0 : (n > (32u << 10) ? 1 : 2)];
-    const uint32_t T = 1u << pf.tileLog;
-    const uint32_t nWin = T >> 6;
+    const qzstd_hip_profile_t pf = args.prof[n > (64u << 10) ? 0 : (n > (32u << 10) ? 1 : 2)];
     const uint32_t nh = n >= pf.hashBytes ? n - pf.hashBytes + 1u : 0u; /* hashable positions */
-    const uint32_t nTiles = (nh + T - 1u) >> pf.tileLog;
+    const uint32_t nTiles = (nh + kTile - 1u) >> kTileLog;
 
     /* ---- LDS layout for THIS block ---- */
     const uint32_t region = ((n + 15u) & ~15u) + 16u;
@@ -366,10 +308,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + region);
     uint32_t *nearTab = tbl + pf.tableSize;
-    uint32_t *results = nearTab + T;     /* packed candidates of the tile being parsed */
-    uint32_t *save = results + T;        /* last window of the previous tile (x2) */
-    uint32_t *crec = save + kSaveWords;  /* speculative-chain records */
-    uint32_t *srec = crec + kRecWords;   /* serial-pass records */
+    uint32_t *wrec = nearTab + kTile;                                  /* [kSlots][kWin][8]          */
+    uint32_t *srec = wrec + kSlots * kWin * W_WORDS;                   /* [2][kWin][4]               */
+    uint16_t *lens = reinterpret_cast<uint16_t *>(srec + 2u * kWin * 4u); /* [kSlots][kTile] u16     */
 
     /* ---- stage the block: HBM -> LDS, 16 B per lane, coalesced ---- */
     {
@@ -380,123 +321,158 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         for (uint32_t i = tid; i < nvec; i += kThreads) l4[i] = g4[i];
         for (uint32_t i = (nvec << 4) + tid; i < region; i += kThreads) lds8[i] = i < n ? g[i] : (uint8_t)0;
         for (uint32_t i = tid; i < pf.tableSize; i += kThreads) tbl[i] = 0u;
-        for (uint32_t i = tid; i < T; i += kThreads) { nearTab[i] = 0xFFFFFFFFu; results[i] = 0u; }
+        for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
+        for (uint32_t i = tid; i < kSlots * kWin * W_WORDS + 2u * kWin * 4u; i += kThreads) wrec[i] = 0u;
+        for (uint32_t i = tid; i < kSlots * kTile / 2u; i += kThreads) reinterpret_cast<uint32_t *>(lens)[i] = 0u;
     }
     __syncthreads();
 
-    ParseState st = { 0u, 0u, 0u };
+    ParseState st = { 0u, 0u, kNone };
     uint4 *out = args.seqs + blk.seqOff;
     const uint32_t hiMask = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
-    const uint32_t nearShift = 32u - pf.tileLog;
-    const uint32_t stampShift = pf.tileLog + kTagBits;
-    const uint32_t nTilesMax = (QZSTD_HIP_BLOCK_MAX >> pf.tileLog);
+    const uint32_t nearShift = 32u - kTileLog;
+    const uint32_t stampShift = kTileLog + kTagBits;
+    const uint32_t nTilesMax = QZSTD_HIP_BLOCK_MAX >> kTileLog;
 
-    /* matcher registers: packed candidates of the two most recent tiles this thread matched */
-    uint32_t resNew[kMaxPosPerThread] = { 0u, 0u };  /* tile it-1 after interval 2 */
-    uint32_t resOld[kMaxPosPerThread] = { 0u, 0u };  /* tile it-2 */
-    uint32_t R[kMaxWindows];                         /* parse wave: candidates of tile it-1 */
-#pragma unroll
-    for (int w = 0; w < kMaxWindows; w++) R[w] = 0u;
+    /* matcher registers: (offset, full length) of the four most recent tiles of this position slot */
+    uint32_t offG0 = 0, offG1 = 0, offG2 = 0, offG3 = 0; /* G0 = tile it (after interval 2), G3 = tile it-3 */
+    uint32_t lenG0 = 0, lenG1 = 0, lenG2 = 0, lenG3 = 0;
+    uint32_t exReach = 0;  /* exclusive in-window prefix max of reach, tile it-1 (for the sync phase) */
+    u64 startMask = 0;     /* start flags of the own window, tile it-1 */
+    uint32_t tileCarry = 0; /* max reach of all tiles before it-1 */
 
-    for (uint32_t it = 0; it < nTiles + 2u; it++) {
-        const uint32_t t0 = it << pf.tileLog;
+    for (uint32_t it = 0; it < nTiles + 3u; it++) {
+        const uint32_t t0 = it << kTileLog;
+        const uint32_t p = t0 + tid; /* matcher: own position in tile it */
         const uint32_t stamp = (nTilesMax - 1u - (it & (nTilesMax - 1u))) << stampShift;
-        uint32_t v[kMaxPosPerThread], mix[kMaxPosPerThread], old[kMaxPosPerThread];
-        bool valid[kMaxPosPerThread];
+        uint32_t v = 0, mix = 0, old = 0;
+        const bool valid = matcher && it < nTiles && p < nh;
 
         /* ================= interval 1 ================= */
         if (matcher) {
-            if (it >= 2u && it - 2u < nTiles && !(args.dbg & 8u)) { /* emit(it-2) */
+            if (it >= 1u && it - 1u < nTiles) {
+                /* sync / stop masks of tile it-1: a position is a sync point when no start before it
+                 * (in the whole block) reaches beyond it */
+                const uint32_t slot = (it - 1u) % kSlots;
+                uint32_t *rw = wrec + (slot * kWin) * W_WORDS;
+                const uint32_t wm = lane < kWin ? rw[lane * W_WORDS + W_REACH] : 0u;
+                uint32_t carry = tileCarry, all = tileCarry;
 #pragma unroll
-                for (int j = 0; j < kMaxPosPerThread; j++) {
-                    const uint32_t w = wave + (uint32_t)j * kMatchWaves;
-                    if (w < nWin) emit_window(pf, lds32, srec + w * 8u, resOld[j], t0 - 2u * T + 64u * w, lane, out, blk.seqCap);
+                for (uint32_t w = 0; w < kWin; w++) {
+                    const uint32_t x = rdlane(wm, w);
+                    if (w < wave) carry = umax(carry, x);
+                    all = umax(all, x);
                 }
+                tileCarry = all;
+                const uint32_t pos = t0 - kTile + tid;
+                const bool sync = umax(carry, exReach) <= pos;
+                const u64 sm = __ballot(sync);
+                /* stop point = first sync point of each 16-position group */
+                const u64 grp = 0xFFFFull << (lane & 48u);
+                const bool stopb = sync && (sm & grp & below(lane)) == 0ull;
+                const u64 stm = __ballot(stopb);
+                uint32_t val = 0;
+                val = lane == 0 ? (uint32_t)startMask : val;
+                val = lane == 1 ? (uint32_t)(startMask >> 32) : val;
+                val = lane == 2 ? (uint32_t)stm : val;
+                val = lane == 3 ? (uint32_t)(stm >> 32) : val;
+                if (lane < 7u) rw[wave * W_WORDS + lane] = val; /* words 4..6 (chosen, lastEnd) := 0 */
             }
-            if (it >= 1u && it - 1u < nTiles && !(args.dbg & 4u)) { /* speculative chains(it-1) */
-#pragma unroll
-                for (int j = 0; j < kMaxPosPerThread; j++) {
-                    const uint32_t w = wave + (uint32_t)j * kMatchWaves;
-                    if (w < nWin) {
-                        const bool havePrev = w != 0u || it >= 2u;
-                        uint32_t rPrev = 0u;
-                        if (havePrev) rPrev = w != 0u ? results[64u * (w - 1u) + lane] : save[((it - 2u) & 1u) * 64u + lane];
-                        spec_chain(pf, rPrev, havePrev, resNew[j], lane, crec + w * 8u);
-                    }
-                }
+            if (valid) { /* phase A(it) */
+                const uint32_t d = p >> 2, s = p & 3u;
+                const uint32_t w0 = lds32[d], w1 = lds32[d + 1];
+                v = __builtin_amdgcn_alignbyte(w1, w0, s);
+                uint32_t hi = 0;
+                if (pf.hashBytes > 4) hi = __builtin_amdgcn_alignbyte(lds32[d + 2], w1, s) & hiMask;
+                mix = (v * kPrime1) ^ (hi * kPrime2);
+                old = tbl[__umulhi(mix, pf.tableSize)];
+                if (pf.nearTab)
+                    atomicMin(&nearTab[mix >> nearShift], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
             }
-#pragma unroll
-            for (int j = 0; j < kMaxPosPerThread; j++) { /* phase A(it) */
-                const uint32_t pin = tid + (uint32_t)j * kMatchThreads;
-                const uint32_t p = t0 + pin;
-                valid[j] = it < nTiles && pin < T && p < nh;
-                v[j] = 0; mix[j] = 0; old[j] = 0;
-                if (valid[j]) {
-                    const uint32_t d = p >> 2, s = p & 3u;
-                    const uint32_t w0 = lds32[d], w1 = lds32[d + 1];
-                    v[j] = __builtin_amdgcn_alignbyte(w1, w0, s);
-                    uint32_t hi = 0;
-                    if (pf.hashBytes > 4) hi = __builtin_amdgcn_alignbyte(lds32[d + 2], w1, s) & hiMask;
-                    mix[j] = (v[j] * kPrime1) ^ (hi * kPrime2);
-                    old[j] = tbl[__umulhi(mix[j], pf.tableSize)];
-                    if (pf.nearTab)
-                        atomicMin(&nearTab[mix[j] >> nearShift], stamp | (pin << kTagBits) | ((mix[j] >> 3) & kTagMask));
-                }
-            }
-        } else if (it >= 1u && it - 1u < nTiles) {
-#pragma unroll
-            for (int w = 0; w < kMaxWindows; w++) R[w] = (uint32_t)w < nWin ? results[64 * w + (int)lane] : 0u;
         }
         __syncthreads(); /* B1 */
 
         /* ================= interval 2 ================= */
         if (matcher) {
-#pragma unroll
-            for (int j = 0; j < kMaxPosPerThread; j++) { resOld[j] = resNew[j]; resNew[j] = 0u; }
-#pragma unroll
-            for (int j = 0; j < kMaxPosPerThread; j++) {
-                const uint32_t pin = tid + (uint32_t)j * kMatchThreads;
-                if (valid[j]) {
-                    const uint32_t p = t0 + pin;
-                    const uint32_t tag = (mix[j] >> 3) & kTagMask;
-                    const uint32_t en = pf.nearTab ? nearTab[mix[j] >> nearShift] : 0xFFFFFFFFu;
-                    atomicMax(&tbl[__umulhi(mix[j], pf.tableSize)], ((p + 1u) << kTagBits) | tag);
-                    const uint32_t cap = pf.capLen < n - p ? pf.capLen : n - p;
-                    /* candidate 1: newest position of earlier tiles; candidate 2: earliest of this tile */
-                    uint32_t q1 = kNone, q2 = kNone;
-                    const uint32_t e = old[j];
-                    if (e != 0u && (e & kTagMask) == tag) {
-                        const uint32_t q = (e >> kTagBits) - 1u;
-                        if (pf.window == 0u || p - q <= pf.window) q1 = q;
-                    }
-                    if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
-                        const uint32_t q = t0 + ((en >> kTagBits) & (T - 1u));
-                        if (q < p) q2 = q;
-                    }
-                    uint32_t bestLen = 0, bestOff = 0;
-                    if ((q1 != kNone || q2 != kNone) && !(args.dbg & 2u)) {
-                        uint32_t own[9];
-                        const uint32_t pd = p >> 2;
-#pragma unroll
-                        for (int i = 0; i < 9; i++) own[i] = lds32[pd + i];
-                        if (q1 != kNone) {
-                            const uint32_t l = match_len(lds32, own, p, q1, cap);
-                            if (l >= 4u) { bestLen = l; bestOff = p - q1; }
-                        }
-                        if (q2 != kNone) {
-                            const uint32_t l = match_len(lds32, own, p, q2, cap);
-                            if (l >= 4u && l >= bestLen) { bestLen = l; bestOff = p - q2; }
-                        }
-                    }
-                    resNew[j] = bestLen ? ((bestOff << 8) | bestLen) : 0u;
+            if (it >= 3u && it - 3u < nTiles) /* emit(it-3) */
+                emit_window(pf, lds32, srec + (((it - 3u) & 1u) * kWin + wave) * 4u, offG2, lenG2,
+                            t0 - 3u * kTile + 64u * wave, lane, out, blk.seqCap);
+            offG3 = offG2; offG2 = offG1; offG1 = offG0; lenG3 = lenG2; lenG2 = lenG1; lenG1 = lenG0;
+            (void)offG3; (void)lenG3;
+            uint32_t cl = 0, off = 0; /* capped candidate length, offset */
+            if (valid) {
+                const uint32_t tag = (mix >> 3) & kTagMask;
+                const uint32_t en = pf.nearTab ? nearTab[mix >> nearShift] : 0xFFFFFFFFu;
+                atomicMax(&tbl[__umulhi(mix, pf.tableSize)], ((p + 1u) << kTagBits) | tag);
+                const uint32_t cap = umin(pf.capLen, n - p);
+                /* candidate 1: newest position of earlier tiles; candidate 2: earliest of this tile */
+                uint32_t q1 = kNone, q2 = kNone;
+                if (old != 0u && (old & kTagMask) == tag) {
+                    const uint32_t q = (old >> kTagBits) - 1u;
+                    if (pf.window == 0u || p - q <= pf.window) q1 = q;
                 }
-                if (it < nTiles && pin < T) {
-                    results[pin] = resNew[j];
-                    if (pin >= T - 64u) save[(it & 1u) * 64u + (pin - (T - 64u))] = resNew[j];
+                if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
+                    const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
+                    if (q < p) q2 = q;
+                }
+                if (q1 != kNone || q2 != kNone) {
+                    uint32_t own[9];
+                    const uint32_t pd = p >> 2;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) own[i] = lds32[pd + i];
+                    if (q1 != kNone) {
+                        const uint32_t l = match_len(lds32, own, p, q1, cap);
+                        if (l >= 4u) { cl = l; off = p - q1; }
+                    }
+                    if (q2 != kNone) {
+                        const uint32_t l = match_len(lds32, own, p, q2, cap);
+                        if (l >= 4u && l >= cl) { cl = l; off = p - q2; }
+                    }
                 }
             }
-        } else if (it >= 1u && it - 1u < nTiles && !(args.dbg & 1u)) {
-            serial_pass(pf, lds32, R, crec, srec, t0 - T, nWin, n, lane, st, out + blk.seqCap);
+            uint32_t full = cl;
+            if (it < nTiles) {
+                /* runs of capped candidates with one offset are one long match: its end comes from the
+                 * run's tail (visible in the window, or found by a bounded cooperative extension) */
+                const uint32_t clN = __shfl_down(cl, 1), offN = __shfl_down(off, 1);
+                const bool capped = cl == pf.capLen;
+                const bool cont = capped && lane != 63u && clN == pf.capLen && offN == off;
+                const bool tail = capped && !cont;
+                const u64 tailMask = __ballot(tail);
+                const bool visible = tail && lane != 63u && clN != 0u && offN == off;
+                uint32_t E = visible ? p + 1u + clN : 0u;
+                u64 ext = __ballot(tail && !visible);
+                while (ext) {
+                    const uint32_t t = (uint32_t)__builtin_ctzll(ext);
+                    ext &= ext - 1ull;
+                    const uint32_t pt = t0 + 64u * wave + t, ot = rdlane(off, t);
+                    const uint32_t lim = umin(n, ((pt >> pf.extLog) + 2u) << pf.extLog);
+                    const uint32_t Lt = extend_match(lds32, pt, ot, pf.capLen, lim, lane);
+                    if (lane == t) E = pt + Lt;
+                }
+                if (tailMask) {
+                    const u64 mine = tailMask & ~below(lane);
+                    const uint32_t tl = mine ? (uint32_t)__builtin_ctzll(mine) : 0u;
+                    const uint32_t Et = __shfl(E, (int)tl);
+                    if (capped) full = umin(Et, ((p >> pf.extLog) + 2u) << pf.extLog) - p;
+                }
+                /* start flags: the lazy rule compares capped lengths and never looks across the window edge */
+                const bool take = cl != 0u && cl >= min_len(pf, off);
+                const bool take1 = clN != 0u && clN >= min_len(pf, offN);
+                const bool start = take && !(pf.lazy && lane != 63u && take1 && clN > cl);
+                startMask = __ballot(start);
+                const uint32_t reach = start ? p + full : 0u;
+                const uint32_t inc = wave_scan_max(reach, lane);
+                exReach = __shfl_up(inc, 1);
+                if (lane == 0u) exReach = 0u;
+                const uint32_t slot = it % kSlots;
+                lens[slot * kTile + tid] = (uint16_t)full;
+                if (lane == 63u) wrec[(slot * kWin + wave) * W_WORDS + W_REACH] = inc;
+            }
+            offG0 = off;
+            lenG0 = full;
+        } else if (it >= 2u && it - 2u < nTiles) {
+            parse_pass(wrec, lens, srec + ((it - 2u) & 1u) * kWin * 4u, it - 2u, nTiles, lane, st);
         }
         __syncthreads(); /* B2 */
     }
@@ -646,7 +622,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         qzstd_hip_profile_for_level(level, 32u << 10, &a.prof[2]))
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12");
     for (int c = 0; c < 3; c++)
-        if (a.prof[c].tileLog > 10 || a.prof[c].tileLog < 6 || a.prof[c].capLen > 128 || a.prof[c].capLen < 32 || a.prof[c].minMatch < 4 || a.prof[c].hashBytes < 4 ||
+        if (a.prof[c].tileLog != kTileLog || a.prof[c].extLog < 8 || a.prof[c].extLog > 15 || a.prof[c].capLen > 128 || a.prof[c].capLen < 32 || a.prof[c].minMatch < 4 || a.prof[c].hashBytes < 4 ||
             a.prof[c].hashBytes > 8)
             return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
@@ -663,7 +639,6 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     a.blocks = d_blocks;
     a.seqs = static_cast<uint4 *>(d_seqs);
     a.nseq = d_nseq;
-    { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
     hipLaunchKernelGGL(qzstd_find_sequences_kernel, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;

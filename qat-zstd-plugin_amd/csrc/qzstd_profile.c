@@ -8,8 +8,8 @@
  *
  * LDS budget per workgroup (gfx950: 160 KiB = 163840 B per CU):
  *     block bytes (<=128 KiB, +16 pad) + 4*tableSize + near table 4<<tileLog
- *     + candidate scratch 4<<tileLog + 1.5 KiB parse records + 64 B control
- * so a full 128 KiB block leaves room for 5700 table entries at tileLog 10; smaller
+ *     + 3 tiles of u16 match lengths + per-window parse/emission records + 64 B control
+ * so a full 128 KiB block leaves room for 6600 table entries at tileLog 9; smaller
  * blocks get bigger tables and more workgroups per CU.
  */
 #include "qzstd_hip.h"
@@ -18,16 +18,16 @@
 
 #define QZ_LDS_MAX 163840u
 #define QZ_LDS_CTRL 64u
-#define QZ_LDS_PARSE (4u * (128u + 2u * 16u * 8u)) /* saved window x2 + two record arrays */
+
 
 int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t *out)
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    if (blockSize > (64u << 10)) out->tableSize = 5700u;
+    if (blockSize > (64u << 10)) out->tableSize = 6600u;
     else if (blockSize > (32u << 10)) out->tableSize = 16384u;
     else out->tableSize = 8192u;
-    out->tileLog = 10;
+    out->tileLog = 9;
     out->capLen = level >= 6 ? 64 : 32;
     out->minMatch = 4;
     out->farLog1 = 12;
@@ -37,6 +37,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     out->nearTab = 1;
     out->window = 0;
     out->hashBytes = 5;
+    out->extLog = 11;
     return 0;
 }
 
@@ -50,7 +51,12 @@ static size_t qz_need(int level, uint32_t len)
     qzstd_hip_profile_t p;
     if (qzstd_hip_profile_for_level(level, len, &p)) return 0;
     /* block bytes (+16 B pad for dword over-reads) + table + near table + parse scratch + control */
-    return (size_t)(((len + 15u) & ~15u) + 16u) + 4u * p.tableSize + (4u << p.tileLog) * 2u + QZ_LDS_PARSE + QZ_LDS_CTRL;
+    return (size_t)(((len + 15u) & ~15u) + 16u) + 4u * p.tableSize        /* hash table                                    */
+           + (4u << p.tileLog)     /* tile-local near table                         */
+           + 3u * (2u << p.tileLog) /* u16 match lengths of 3 tiles in flight       */
+           + 3u * ((1u << p.tileLog) >> 6) * 32u /* per-window parse records x3     */
+           + 2u * ((1u << p.tileLog) >> 6) * 16u /* per-window emission records x2  */
+           + QZ_LDS_CTRL;
 }
 
 /* A launch may mix block sizes; each workgroup lays out LDS for ITS block, so the
