@@ -53,9 +53,9 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    out->tableSize = blockSize > (64u << 10) ? 6600u : (blockSize > (32u << 10) ? 16384u : 8192u);
+    out->tableSize = blockSize > (64u << 10) ? 6400u : (blockSize > (32u << 10) ? 16384u : 8192u);
     out->tileLog = 9;
-    out->capLen = level >= 6 ? 64 : 32;
+    out->capLen = 128;
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;

@@ -43,15 +43,11 @@ constexpr int kThreads = kMatchThreads + 64;     /* + 1 parse wave */
 constexpr uint32_t kTileLog = 9;                 /* tile = 512 positions = kMatchThreads */
 constexpr uint32_t kTile = 1u << kTileLog;
 constexpr uint32_t kWin = kTile >> 6;            /* 64-position windows per tile (one per matcher wave) */
-constexpr uint32_t kGroups = kTile >> 4;         /* 16-position groups per tile: one parse chain each */
-constexpr uint32_t kSlots = 3;                   /* tiles in flight between matchers and the parse wave */
 constexpr uint32_t kTagBits = 14;
 constexpr uint32_t kTagMask = (1u << kTagBits) - 1u;
 constexpr uint32_t kPrime1 = 2654435761u;
 constexpr uint32_t kPrime2 = 0x85EBCA77u;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-/* per-window parse record (8 words): start mask, stop mask, chosen mask, last chosen end, max reach */
-enum { W_START = 0, W_STOP = 2, W_CHOSEN = 4, W_LASTEND = 6, W_REACH = 7, W_WORDS = 8 };
 
 struct LaunchArgs {
     const uint8_t *src;
@@ -59,12 +55,14 @@ struct LaunchArgs {
     uint4 *seqs; /* ZSTD_Sequence = 4 x u32 */
     uint32_t *nseq;
     qzstd_hip_profile_t prof[3]; /* by block size class: >64 KiB, >32 KiB, <=32 KiB */
+    uint32_t dbg; /* profiling ablation switches (QZSTD_HIP_ABLATE); 0 in production */
 };
 
 typedef unsigned long long u64;
 
 /* v_readlane_b32 with an unsigned result (the builtin returns int: a set bit 31 would sign-extend) */
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 below(uint32_t c) { return c >= 64u ? ~0ull : ((1ull << c) - 1ull); }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -76,38 +74,33 @@ __device__ __forceinline__ uint32_t lds_rd32u(const uint32_t *lds32, uint32_t a)
     return __builtin_amdgcn_alignbyte(lds32[d + 1], lds32[d], a & 3u);
 }
 
-/*
- * Common prefix length of [p..) and [q..), capped at cap (<= 128).  Works in 32-byte
- * chunks: 9 aligned dwords per side are fetched with independent ds_reads (one LDS
- * round trip per chunk instead of one per dword), then compared in registers.
- * `own` holds the 9 dwords of the position's own first chunk (shared by both candidates).
- */
-__device__ __forceinline__ uint32_t match_len(const uint32_t *lds32, const uint32_t (&own)[9], uint32_t p,
-                                              uint32_t q, uint32_t cap)
+/* first mismatching byte (0..32) of the 32 bytes at p and at q: 9 aligned dwords per side are
+ * fetched with independent ds_reads (ONE LDS round trip), then compared in registers */
+__device__ __forceinline__ uint32_t chunk_len(const uint32_t *lds32, uint32_t p, uint32_t q)
 {
-    const uint32_t ps = p & 3u, qs = q & 3u;
-    uint32_t L = cap;
-    {
-        uint32_t Q[9];
-        const uint32_t qd = q >> 2;
+    const uint32_t pd = p >> 2, qd = q >> 2, ps = p & 3u, qs = q & 3u;
+    uint32_t P[9], Q[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) Q[i] = lds32[qd + i];
+    for (int i = 0; i < 9; i++) { P[i] = lds32[pd + i]; Q[i] = lds32[qd + i]; }
+    uint32_t L = 32u;
 #pragma unroll
-        for (int i = 7; i >= 0; i--) {
-            const uint32_t x = __builtin_amdgcn_alignbyte(own[i + 1], own[i], ps) ^
-                               __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
-            if (x) L = 4u * (uint32_t)i + ((uint32_t)__builtin_ctz(x) >> 3);
-        }
+    for (int i = 7; i >= 0; i--) {
+        const uint32_t x = __builtin_amdgcn_alignbyte(P[i + 1], P[i], ps) ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
+        if (x) L = 4u * (uint32_t)i + ((uint32_t)__builtin_ctz(x) >> 3);
     }
-    if (L >= 32u && cap > 32u) { /* rare: long candidate, level >= 6 caps */
-        L = 32u;
-        while (L < cap) {
-            const uint32_t x = lds_rd32u(lds32, p + L) ^ lds_rd32u(lds32, q + L);
-            if (x) { L += (uint32_t)__builtin_ctz(x) >> 3; break; }
-            L += 4u;
-        }
+    return L;
+}
+
+/* common prefix length of [p..) and [q..), capped at cap (<= 128), 32 bytes per LDS round trip */
+__device__ __forceinline__ uint32_t match_len(const uint32_t *lds32, uint32_t p, uint32_t q, uint32_t cap)
+{
+    uint32_t L = 0;
+    for (;;) {
+        const uint32_t l = chunk_len(lds32, p + L, q + L);
+        L += l;
+        if (l < 32u || L >= cap) break;
     }
-    return L < cap ? L : cap;
+    return umin(L, cap);
 }
 
 __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint32_t off)
@@ -115,133 +108,97 @@ __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint3
     return pf.minMatch + ((off >> pf.farLog1) ? 1u : 0u) + ((off >> pf.farLog2) ? 1u : 0u);
 }
 
-/* cooperative forward extension of a match that hit the candidate cap: 64 lanes x 4 bytes
- * per step, never past `lim` */
+/* cooperative forward extension of a match that hit the candidate cap: 64 lanes x 16 bytes
+ * (1 KiB) per step, never past `lim` */
 __device__ __forceinline__ uint32_t extend_match(const uint32_t *lds32, uint32_t p, uint32_t off, uint32_t L,
                                                  uint32_t lim, uint32_t lane)
 {
     for (;;) {
-        const uint32_t a = p + L + 4u * lane;
-        uint32_t ok = 0; /* bytes of this lane's dword that match and lie below lim */
+        const uint32_t a = p + L + 16u * lane;
+        uint32_t ok = 0; /* bytes of this lane's 16 that match and lie below lim */
         if (a < lim) {
-            const uint32_t x = lds_rd32u(lds32, a) ^ lds_rd32u(lds32, a - off);
-            ok = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+            const uint32_t b = a - off, ad = a >> 2, bd = b >> 2, as = a & 3u, bs = b & 3u;
+            uint32_t A[5], B[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) { A[i] = lds32[ad + i]; B[i] = lds32[bd + i]; }
+            ok = 16u;
+#pragma unroll
+            for (int i = 3; i >= 0; i--) {
+                const uint32_t x = __builtin_amdgcn_alignbyte(A[i + 1], A[i], as) ^ __builtin_amdgcn_alignbyte(B[i + 1], B[i], bs);
+                if (x) ok = 4u * (uint32_t)i + ((uint32_t)__builtin_ctz(x) >> 3);
+            }
             ok = umin(ok, lim - a);
         }
-        const u64 bad = __ballot(ok < 4u);
+        const u64 bad = __ballot(ok < 16u);
         if (bad) {
             const uint32_t f = (uint32_t)__builtin_ctzll(bad);
-            return L + 4u * f + rdlane(ok, f);
+            return L + 16u * f + rdlane(ok, f);
         }
-        L += 256u;
+        L += 1024u;
     }
-}
-
-/* inclusive max-scan across the 64 lanes of a wave */
-__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x, uint32_t lane)
-{
-#pragma unroll
-    for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const uint32_t t = __shfl_up(x, d);
-        if (lane >= d) x = umax(x, t);
-    }
-    return x;
 }
 
 /* parse-wave state, uniform across the wave */
 struct ParseState {
-    uint32_t anchor;  /* end of the last chosen match = start of pending literals */
-    uint32_t nseq;    /* matches chosen so far */
-    uint32_t pending; /* standing position a chain reached beyond the data available to its pass */
+    uint32_t cur;    /* next position the parse stands on */
+    uint32_t anchor; /* end of the last chosen match = start of pending literals */
+    uint32_t nseq;   /* matches chosen so far */
 };
 
 /*
- * The parse of one tile, by the parse wave, all chains of the tile in parallel.
- *
- * A position is a SYNC point when no potential match start before it reaches beyond it; the
- * (lazy) greedy parse provably stands on every sync point, so the stretches between sync
- * points can be parsed independently.  One lane per 16-position group starts at the group's
- * first sync point ("stop point") and follows next-start / jump-by-length until it stands on
- * another stop point; lane 32 continues a chain that an earlier pass had to suspend.  Chosen
- * starts are OR-ed into the per-window masks (ds_or), match ends MAX-ed (ds_max).  Then the
- * per-window sequence index bases and literal anchors of tile k are prefix-summed and
- * published for the emitting waves.
+ * The (lazy) greedy parse of one tile, by the parse wave: a lean scalar chase.  The matcher
+ * waves have already reduced every position to a 64-bit start mask per window and one word per
+ * position: its jump length, or (bit 31 set) the offset of a candidate that hit the length cap.
+ * One step is shift / find-first-set / readlane / add with a single backward branch.  A capped
+ * match is extended here, cooperatively, only when the parse actually takes it (it then leaves
+ * the window, so there is at most one per window).  All of the tile's windows are fetched up
+ * front (one LDS wait).  Per window it publishes {chosen mask, literal anchor at entry, index of
+ * the first sequence, extended length of the last chosen match or 0} for the emitting wave.
  */
-__device__ void parse_pass(uint32_t *wrec, const uint16_t *lens, uint32_t *srecOut, uint32_t k, uint32_t nTiles,
-                           uint32_t lane, ParseState &st)
+constexpr uint32_t kCappedBit = 0x80000000u;
+constexpr uint32_t kSrecWords = 8;
+
+__device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t *wmask,
+                                           const uint32_t *lens, uint32_t *srecOut, uint32_t base, uint32_t n,
+                                           uint32_t lane, ParseState &st)
 {
-    const uint32_t base = k << kTileLog;
-    const uint32_t limit = umin(k + 2u, nTiles) << kTileLog; /* tiles k and k+1 are complete */
-    const uint32_t slotK = k % kSlots;
-    uint32_t c = 0;
-    bool active = false, first = true;
-    if (lane < kGroups) {
-        const uint32_t w = lane >> 2, sub = lane & 3u;
-        const uint32_t *r = wrec + (slotK * kWin + w) * W_WORDS;
-        const uint32_t bits = ((sub & 2u ? r[W_STOP + 1] : r[W_STOP]) >> (16u * (sub & 1u))) & 0xFFFFu;
-        if (bits) { active = true; c = base + 64u * w + 16u * sub + (uint32_t)__builtin_ctz(bits); }
-    } else if (lane == kGroups && st.pending != kNone && (st.pending >> kTileLog) == k) {
-        active = true; first = false; c = st.pending;
-    }
-    if (st.pending != kNone && (st.pending >> kTileLog) == k) st.pending = kNone;
-    bool suspended = false;
-    while (__any(active)) {
-        if (active) {
-            const uint32_t tile = c >> kTileLog, w = (c >> 6) & (kWin - 1u), rel = c & 63u;
-            uint32_t *r = wrec + ((tile % kSlots) * kWin + w) * W_WORDS;
-            const u64 start = (u64)r[W_START] | ((u64)r[W_START + 1] << 32);
-            const u64 stop = (u64)r[W_STOP] | ((u64)r[W_STOP + 1] << 32);
-            const u64 ms = start >> rel, ss = stop >> rel;
-            if (!first && (ss & 1ull)) {
-                active = false; /* standing on another chain's starting point */
-            } else {
-                const u64 ss1 = ss & ~1ull;
-                const uint32_t jrel = ms ? (uint32_t)__builtin_ctzll(ms) : 64u;
-                const uint32_t srel = ss1 ? (uint32_t)__builtin_ctzll(ss1) : 64u;
-                if (srel <= jrel && srel != 64u) {
-                    active = false; /* literals up to the next stop point */
-                } else if (jrel == 64u) {
-                    c = (c | 63u) + 1u; /* no start left in this window: walk into the next one */
-                    if (c >= limit) { active = false; suspended = true; }
-                } else {
-                    const uint32_t j = c + jrel, jpos = j & 63u;
-                    const uint32_t L = lens[(tile % kSlots) * kTile + (j & (kTile - 1u))];
-                    atomicOr(&r[W_CHOSEN + (jpos >> 5)], 1u << (jpos & 31u));
-                    atomicMax(&r[W_LASTEND], j + L);
-                    c = j + L;
-                    if (c >= limit) { active = false; suspended = true; }
-                }
-                first = false;
-            }
-        }
-    }
-    {
-        const u64 sm = __ballot(suspended);
-        if (sm) st.pending = rdlane(c, 63u - (uint32_t)__builtin_clzll(sm));
-    }
-    /* finalize tile k: lanes 0..kWin-1 = windows */
-    {
-        const uint32_t w = lane < kWin ? lane : 0u;
-        const uint32_t *r = wrec + (slotK * kWin + w) * W_WORDS;
-        const uint32_t cLo = lane < kWin ? r[W_CHOSEN] : 0u, cHi = lane < kWin ? r[W_CHOSEN + 1] : 0u;
-        const uint32_t le = lane < kWin ? r[W_LASTEND] : 0u;
-        const uint32_t cnt = (uint32_t)__popc(cLo) + (uint32_t)__popc(cHi);
-        uint32_t ps = cnt, pm = le; /* inclusive prefix sum / max over the kWin window lanes */
+    uint32_t lenV[kWin];
 #pragma unroll
-        for (uint32_t d = 1; d < kWin; d <<= 1) {
-            const uint32_t a = __shfl_up(ps, d), b = __shfl_up(pm, d);
-            if (lane >= d) { ps += a; pm = umax(pm, b); }
+    for (uint32_t w = 0; w < kWin; w++) lenV[w] = lens[64u * w + lane];
+    const uint32_t mv = wmask[lane & (2u * kWin - 1u)]; /* lanes 0..15: {lo,hi} of windows 0..7 */
+#pragma unroll
+    for (uint32_t w = 0; w < kWin; w++) {
+        const uint32_t w0 = base + 64u * w;
+        const uint32_t anchorIn = st.anchor, seqBase = st.nseq;
+        u64 chosen = 0;
+        uint32_t extLen = 0;
+        if (st.cur < w0 + 64u) {
+            const u64 start = (u64)rdlane(mv, 2u * w) | ((u64)rdlane(mv, 2u * w + 1u) << 32);
+            uint32_t c = rdfirst(st.cur - w0), e = 0, j, L;
+            do {
+                const u64 m = (start >> c) << c;
+                j = m ? (uint32_t)__builtin_ctzll(m) : 63u;
+                L = rdlane(lenV[w], j);
+                chosen |= m ? 1ull << j : 0ull;
+                c = m ? j + (L & 0xFFFFu) : 64u;
+                e = m ? c : e;
+            } while (c < 64u && !(L & kCappedBit));
+            if ((L & kCappedBit) && ((chosen >> j) & 1ull)) {
+                /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
+                const uint32_t pj = w0 + j, off = L & 0x7FFFFFFFu;
+                const uint32_t lim = umin(n, ((pj >> pf.extLog) + 2u) << pf.extLog);
+                extLen = extend_match(lds32, pj, off, pf.capLen, lim, lane);
+                c = e = j + extLen;
+            }
+            st.cur = w0 + umax(c, 64u);
+            if (chosen) st.anchor = w0 + e;
+            st.nseq += (uint32_t)__popcll(chosen);
         }
-        const uint32_t exm = __shfl_up(pm, 1);
-        if (lane < kWin) {
-            uint4 o;
-            o.x = cLo; o.y = cHi;
-            o.z = umax(st.anchor, lane ? exm : 0u); /* anchor when the parse enters the window */
-            o.w = st.nseq + ps - cnt;               /* index of the window's first sequence */
-            reinterpret_cast<uint4 *>(srecOut)[lane] = o;
+        if (lane == 0u) {
+            uint4 *o = reinterpret_cast<uint4 *>(srecOut + w * kSrecWords);
+            o[0] = make_uint4((uint32_t)chosen, (uint32_t)(chosen >> 32), anchorIn, seqBase);
+            srecOut[w * kSrecWords + 4u] = extLen;
         }
-        st.nseq += rdlane(ps, kWin - 1u);
-        st.anchor = umax(st.anchor, rdlane(pm, kWin - 1u));
     }
 }
 
@@ -253,7 +210,8 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
     const uint4 rec = *reinterpret_cast<const uint4 *>(srec);
     const u64 chosen = (u64)rec.x | ((u64)rec.y << 32);
     if (!chosen) return;
-    const uint32_t anchorIn = rec.z, seqBase = rec.w;
+    const uint32_t anchorIn = rec.z, seqBase = rec.w, extLen = srec[4];
+    if (extLen && lane == 63u - (uint32_t)__builtin_clzll(chosen)) len = extLen; /* extended by the parse wave */
     const bool ch = (chosen >> lane) & 1ull;
     const u64 lower = chosen & below(lane);
     const uint32_t rank = (uint32_t)__popcll(lower);
@@ -264,7 +222,7 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
     if (ch) {
         const uint32_t p = w0 + lane, q = p - off;
         const uint32_t lit = p - prevEnd;
-        uint32_t maxb = umin(umin(pf.backExt, lit), q);
+        const uint32_t maxb = umin(umin(pf.backExt, lit), q);
         uint32_t b = 0;
         if (maxb) {
             /* the 4 bytes before p and before q, top byte = nearest; count equal bytes from the top */
@@ -282,11 +240,11 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
  * One workgroup = one block.  8 matcher waves (one position per thread per 512-position tile)
  * + 1 parse wave, software-pipelined over tiles with two barriers per iteration:
  *
- *   interval 1 of iteration it   matchers: sync/stop masks of tile it-1, phase A(it) (table look-up)
+ *   interval 1 of iteration it   matchers: emit(it-2), phase A(it) (hash, table look-up, near-table min)
  *   barrier
- *   interval 2                   matchers: emit(it-3), phase B(it) (insert), candidate lengths,
- *                                          run extension, start flags, reach of tile it
- *                                parse wave: chains + prefix sums of tile it-2
+ *   interval 2                   matchers: phase B(it) (insert), candidate lengths, run-tail
+ *                                          extension, start flags of tile it
+ *                                parse wave: greedy chain over tile it-1
  *   barrier
  */
 __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
@@ -294,8 +252,10 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    const uint32_t wave = tid >> 6;
-    const bool matcher = tid < (uint32_t)kMatchThreads;
+    /* the wave index is wave-uniform: say so (readfirstlane), so that the role branch below is a
+     * scalar branch and the parse wave's chain state lives in SGPRs instead of exec-masked VGPRs */
+    const uint32_t wave = rdfirst(tid >> 6);
+    const bool matcher = wave < (uint32_t)kMatchWaves;
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     const uint32_t n = blk.srcLen;
     const qzstd_hip_profile_t pf = args.prof[n > (64u << 10) ? 0 : (n > (32u << 10) ? 1 : 2)];
@@ -308,9 +268,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + region);
     uint32_t *nearTab = tbl + pf.tableSize;
-    uint32_t *wrec = nearTab + kTile;                                  /* [kSlots][kWin][8]          */
-    uint32_t *srec = wrec + kSlots * kWin * W_WORDS;                   /* [2][kWin][4]               */
-    uint16_t *lens = reinterpret_cast<uint16_t *>(srec + 2u * kWin * 4u); /* [kSlots][kTile] u16     */
+    uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
+    uint32_t *wmask = srec + 2u * kWin * kSrecWords;   /* [2][kWin][2]  start masks                       */
+    uint32_t *lens = wmask + 2u * kWin * 2u;           /* [2][kTile]    jump length | capped bit + offset */
 
     /* ---- stage the block: HBM -> LDS, 16 B per lane, coalesced ---- */
     {
@@ -322,167 +282,137 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         for (uint32_t i = (nvec << 4) + tid; i < region; i += kThreads) lds8[i] = i < n ? g[i] : (uint8_t)0;
         for (uint32_t i = tid; i < pf.tableSize; i += kThreads) tbl[i] = 0u;
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
-        for (uint32_t i = tid; i < kSlots * kWin * W_WORDS + 2u * kWin * 4u; i += kThreads) wrec[i] = 0u;
-        for (uint32_t i = tid; i < kSlots * kTile / 2u; i += kThreads) reinterpret_cast<uint32_t *>(lens)[i] = 0u;
+        for (uint32_t i = tid; i < 2u * kWin * (kSrecWords + 2u) + 2u * kTile; i += kThreads) srec[i] = 0u; /* srec, wmask, lens */
     }
     __syncthreads();
 
-    ParseState st = { 0u, 0u, kNone };
     uint4 *out = args.seqs + blk.seqOff;
+
+    if (!matcher) {
+        /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
+        __builtin_amdgcn_s_setprio(3); /* it is the serial critical path: win issue arbitration on its SIMD */
+        ParseState st = { 0u, 0u, 0u };
+#ifdef QZ_DEBUG_DUMP
+        u64 dbgCycles = 0, dbgWait = 0, dbgWait1 = 0;
+        const u64 tStart = __builtin_amdgcn_s_memtime();
+#endif
+        for (uint32_t it = 0; it < nTiles + 2u; it++) {
+#ifdef QZ_DEBUG_DUMP
+            const u64 tC = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads(); /* B1 */
+#ifdef QZ_DEBUG_DUMP
+            dbgWait1 += __builtin_amdgcn_s_memtime() - tC;
+#endif
+            if (it >= 1u && it - 1u < nTiles && !(args.dbg & 1u)) {
+                const uint32_t k = it - 1u;
+#ifdef QZ_DEBUG_DUMP
+                const u64 tA = __builtin_amdgcn_s_memtime();
+#endif
+                parse_tile(pf, lds32, wmask + (k & 1u) * kWin * 2u, lens + (k & 1u) * kTile,
+                           srec + (k & 1u) * kWin * kSrecWords, k << kTileLog, n, lane, st);
+#ifdef QZ_DEBUG_DUMP
+                dbgCycles += __builtin_amdgcn_s_memtime() - tA;
+#endif
+            }
+#ifdef QZ_DEBUG_DUMP
+            const u64 tB = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads(); /* B2 */
+#ifdef QZ_DEBUG_DUMP
+            dbgWait += __builtin_amdgcn_s_memtime() - tB;
+#endif
+        }
+        if (lane == 0) {
+            /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
+            uint32_t count = st.nseq + 1u;
+            if (st.nseq < blk.seqCap) out[st.nseq] = make_uint4(0u, n - st.anchor, 0u, 0u);
+            if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
+            args.nseq[blockIdx.x] = count;
+#ifdef QZ_DEBUG_DUMP
+            out[blk.seqCap - 1u] = make_uint4((uint32_t)dbgCycles, (uint32_t)dbgWait, (uint32_t)dbgWait1,
+                                              (uint32_t)(__builtin_amdgcn_s_memtime() - tStart));
+#endif
+        }
+        return;
+    }
+
+    /* ---------------- the 8 matcher waves ---------------- */
     const uint32_t hiMask = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
     const uint32_t nearShift = 32u - kTileLog;
     const uint32_t stampShift = kTileLog + kTagBits;
     const uint32_t nTilesMax = QZSTD_HIP_BLOCK_MAX >> kTileLog;
 
-    /* matcher registers: (offset, full length) of the four most recent tiles of this position slot */
-    uint32_t offG0 = 0, offG1 = 0, offG2 = 0, offG3 = 0; /* G0 = tile it (after interval 2), G3 = tile it-3 */
-    uint32_t lenG0 = 0, lenG1 = 0, lenG2 = 0, lenG3 = 0;
-    uint32_t exReach = 0;  /* exclusive in-window prefix max of reach, tile it-1 (for the sync phase) */
-    u64 startMask = 0;     /* start flags of the own window, tile it-1 */
-    uint32_t tileCarry = 0; /* max reach of all tiles before it-1 */
+    /* (offset, jump length) of this thread's position in tiles it-1 and it-2 */
+    uint32_t offA = 0, lenA = 0, offB = 0, lenB = 0;
 
-    for (uint32_t it = 0; it < nTiles + 3u; it++) {
+    for (uint32_t it = 0; it < nTiles + 2u; it++) {
         const uint32_t t0 = it << kTileLog;
-        const uint32_t p = t0 + tid; /* matcher: own position in tile it */
+        const uint32_t p = t0 + tid; /* own position in tile it */
         const uint32_t stamp = (nTilesMax - 1u - (it & (nTilesMax - 1u))) << stampShift;
-        uint32_t v = 0, mix = 0, old = 0;
-        const bool valid = matcher && it < nTiles && p < nh;
+        uint32_t mix = 0, old = 0;
+        const bool valid = it < nTiles && p < nh;
 
         /* ================= interval 1 ================= */
-        if (matcher) {
-            if (it >= 1u && it - 1u < nTiles) {
-                /* sync / stop masks of tile it-1: a position is a sync point when no start before it
-                 * (in the whole block) reaches beyond it */
-                const uint32_t slot = (it - 1u) % kSlots;
-                uint32_t *rw = wrec + (slot * kWin) * W_WORDS;
-                const uint32_t wm = lane < kWin ? rw[lane * W_WORDS + W_REACH] : 0u;
-                uint32_t carry = tileCarry, all = tileCarry;
-#pragma unroll
-                for (uint32_t w = 0; w < kWin; w++) {
-                    const uint32_t x = rdlane(wm, w);
-                    if (w < wave) carry = umax(carry, x);
-                    all = umax(all, x);
-                }
-                tileCarry = all;
-                const uint32_t pos = t0 - kTile + tid;
-                const bool sync = umax(carry, exReach) <= pos;
-                const u64 sm = __ballot(sync);
-                /* stop point = first sync point of each 16-position group */
-                const u64 grp = 0xFFFFull << (lane & 48u);
-                const bool stopb = sync && (sm & grp & below(lane)) == 0ull;
-                const u64 stm = __ballot(stopb);
-                uint32_t val = 0;
-                val = lane == 0 ? (uint32_t)startMask : val;
-                val = lane == 1 ? (uint32_t)(startMask >> 32) : val;
-                val = lane == 2 ? (uint32_t)stm : val;
-                val = lane == 3 ? (uint32_t)(stm >> 32) : val;
-                if (lane < 7u) rw[wave * W_WORDS + lane] = val; /* words 4..6 (chosen, lastEnd) := 0 */
-            }
-            if (valid) { /* phase A(it) */
-                const uint32_t d = p >> 2, s = p & 3u;
-                const uint32_t w0 = lds32[d], w1 = lds32[d + 1];
-                v = __builtin_amdgcn_alignbyte(w1, w0, s);
-                uint32_t hi = 0;
-                if (pf.hashBytes > 4) hi = __builtin_amdgcn_alignbyte(lds32[d + 2], w1, s) & hiMask;
-                mix = (v * kPrime1) ^ (hi * kPrime2);
-                old = tbl[__umulhi(mix, pf.tableSize)];
-                if (pf.nearTab)
-                    atomicMin(&nearTab[mix >> nearShift], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
-            }
+        if (it >= 2u && !(args.dbg & 8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
+            emit_window(pf, lds32, srec + ((it & 1u) * kWin + wave) * kSrecWords, offB, lenB, t0 - 2u * kTile + 64u * wave,
+                        lane, out, blk.seqCap);
+        if (valid) { /* phase A(it) */
+            const uint32_t d = p >> 2, s = p & 3u;
+            const uint32_t w0 = lds32[d], w1 = lds32[d + 1];
+            const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, s);
+            uint32_t hi = 0;
+            if (pf.hashBytes > 4) hi = __builtin_amdgcn_alignbyte(lds32[d + 2], w1, s) & hiMask;
+            mix = (v * kPrime1) ^ (hi * kPrime2);
+            old = tbl[__umulhi(mix, pf.tableSize)];
+            if (pf.nearTab)
+                atomicMin(&nearTab[mix >> nearShift], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
         }
         __syncthreads(); /* B1 */
 
         /* ================= interval 2 ================= */
-        if (matcher) {
-            if (it >= 3u && it - 3u < nTiles) /* emit(it-3) */
-                emit_window(pf, lds32, srec + (((it - 3u) & 1u) * kWin + wave) * 4u, offG2, lenG2,
-                            t0 - 3u * kTile + 64u * wave, lane, out, blk.seqCap);
-            offG3 = offG2; offG2 = offG1; offG1 = offG0; lenG3 = lenG2; lenG2 = lenG1; lenG1 = lenG0;
-            (void)offG3; (void)lenG3;
-            uint32_t cl = 0, off = 0; /* capped candidate length, offset */
-            if (valid) {
-                const uint32_t tag = (mix >> 3) & kTagMask;
-                const uint32_t en = pf.nearTab ? nearTab[mix >> nearShift] : 0xFFFFFFFFu;
-                atomicMax(&tbl[__umulhi(mix, pf.tableSize)], ((p + 1u) << kTagBits) | tag);
-                const uint32_t cap = umin(pf.capLen, n - p);
-                /* candidate 1: newest position of earlier tiles; candidate 2: earliest of this tile */
-                uint32_t q1 = kNone, q2 = kNone;
-                if (old != 0u && (old & kTagMask) == tag) {
-                    const uint32_t q = (old >> kTagBits) - 1u;
-                    if (pf.window == 0u || p - q <= pf.window) q1 = q;
+        offB = offA; lenB = lenA;
+        uint32_t cl = 0, off = 0; /* capped candidate length, offset */
+        if (valid) {
+            const uint32_t tag = (mix >> 3) & kTagMask;
+            const uint32_t en = pf.nearTab ? nearTab[mix >> nearShift] : 0xFFFFFFFFu;
+            atomicMax(&tbl[__umulhi(mix, pf.tableSize)], ((p + 1u) << kTagBits) | tag);
+            const uint32_t cap = umin(pf.capLen, n - p);
+            /* candidate 1: newest position of earlier tiles; candidate 2: earliest of this tile */
+            uint32_t q1 = kNone, q2 = kNone;
+            if (old != 0u && (old & kTagMask) == tag) {
+                const uint32_t q = (old >> kTagBits) - 1u;
+                if (pf.window == 0u || p - q <= pf.window) q1 = q;
+            }
+            if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
+                const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
+                if (q < p) q2 = q;
+            }
+            if (!(args.dbg & 2u)) {
+                if (q1 != kNone) {
+                    const uint32_t l = match_len(lds32, p, q1, cap);
+                    if (l >= 4u) { cl = l; off = p - q1; }
                 }
-                if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
-                    const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
-                    if (q < p) q2 = q;
-                }
-                if (q1 != kNone || q2 != kNone) {
-                    uint32_t own[9];
-                    const uint32_t pd = p >> 2;
-#pragma unroll
-                    for (int i = 0; i < 9; i++) own[i] = lds32[pd + i];
-                    if (q1 != kNone) {
-                        const uint32_t l = match_len(lds32, own, p, q1, cap);
-                        if (l >= 4u) { cl = l; off = p - q1; }
-                    }
-                    if (q2 != kNone) {
-                        const uint32_t l = match_len(lds32, own, p, q2, cap);
-                        if (l >= 4u && l >= cl) { cl = l; off = p - q2; }
-                    }
+                if (q2 != kNone) {
+                    const uint32_t l = match_len(lds32, p, q2, cap);
+                    if (l >= 4u && l >= cl) { cl = l; off = p - q2; }
                 }
             }
-            uint32_t full = cl;
-            if (it < nTiles) {
-                /* runs of capped candidates with one offset are one long match: its end comes from the
-                 * run's tail (visible in the window, or found by a bounded cooperative extension) */
-                const uint32_t clN = __shfl_down(cl, 1), offN = __shfl_down(off, 1);
-                const bool capped = cl == pf.capLen;
-                const bool cont = capped && lane != 63u && clN == pf.capLen && offN == off;
-                const bool tail = capped && !cont;
-                const u64 tailMask = __ballot(tail);
-                const bool visible = tail && lane != 63u && clN != 0u && offN == off;
-                uint32_t E = visible ? p + 1u + clN : 0u;
-                u64 ext = __ballot(tail && !visible);
-                while (ext) {
-                    const uint32_t t = (uint32_t)__builtin_ctzll(ext);
-                    ext &= ext - 1ull;
-                    const uint32_t pt = t0 + 64u * wave + t, ot = rdlane(off, t);
-                    const uint32_t lim = umin(n, ((pt >> pf.extLog) + 2u) << pf.extLog);
-                    const uint32_t Lt = extend_match(lds32, pt, ot, pf.capLen, lim, lane);
-                    if (lane == t) E = pt + Lt;
-                }
-                if (tailMask) {
-                    const u64 mine = tailMask & ~below(lane);
-                    const uint32_t tl = mine ? (uint32_t)__builtin_ctzll(mine) : 0u;
-                    const uint32_t Et = __shfl(E, (int)tl);
-                    if (capped) full = umin(Et, ((p >> pf.extLog) + 2u) << pf.extLog) - p;
-                }
-                /* start flags: the lazy rule compares capped lengths and never looks across the window edge */
-                const bool take = cl != 0u && cl >= min_len(pf, off);
-                const bool take1 = clN != 0u && clN >= min_len(pf, offN);
-                const bool start = take && !(pf.lazy && lane != 63u && take1 && clN > cl);
-                startMask = __ballot(start);
-                const uint32_t reach = start ? p + full : 0u;
-                const uint32_t inc = wave_scan_max(reach, lane);
-                exReach = __shfl_up(inc, 1);
-                if (lane == 0u) exReach = 0u;
-                const uint32_t slot = it % kSlots;
-                lens[slot * kTile + tid] = (uint16_t)full;
-                if (lane == 63u) wrec[(slot * kWin + wave) * W_WORDS + W_REACH] = inc;
-            }
-            offG0 = off;
-            lenG0 = full;
-        } else if (it >= 2u && it - 2u < nTiles) {
-            parse_pass(wrec, lens, srec + ((it - 2u) & 1u) * kWin * 4u, it - 2u, nTiles, lane, st);
         }
+        if (it < nTiles && !(args.dbg & 4u)) {
+            /* start flags: the lazy rule compares capped lengths and never looks across the window edge */
+            const uint32_t clN = __shfl_down(cl, 1), offN = __shfl_down(off, 1);
+            const bool take = cl != 0u && cl >= min_len(pf, off);
+            const bool take1 = clN != 0u && clN >= min_len(pf, offN);
+            const bool start = take && !(pf.lazy && lane != 63u && take1 && clN > cl);
+            const u64 startMask = __ballot(start);
+            /* what the parse wave needs: the jump length, or the offset when the length hit the cap */
+            lens[(it & 1u) * kTile + tid] = cl == pf.capLen ? (kCappedBit | off) : cl;
+            if (lane < 2u) wmask[((it & 1u) * kWin + wave) * 2u + lane] = lane ? (uint32_t)(startMask >> 32) : (uint32_t)startMask;
+        }
+        offA = off;
+        lenA = cl;
         __syncthreads(); /* B2 */
-    }
-
-    if (!matcher && lane == 0) {
-        /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
-        uint32_t count = st.nseq + 1u;
-        if (st.nseq < blk.seqCap) out[st.nseq] = make_uint4(0u, n - st.anchor, 0u, 0u);
-        if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
-        args.nseq[blockIdx.x] = count;
     }
 }
 
@@ -639,6 +569,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     a.blocks = d_blocks;
     a.seqs = static_cast<uint4 *>(d_seqs);
     a.nseq = d_nseq;
+    { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
     hipLaunchKernelGGL(qzstd_find_sequences_kernel, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;

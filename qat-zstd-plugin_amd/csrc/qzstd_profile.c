@@ -8,8 +8,8 @@
  *
  * LDS budget per workgroup (gfx950: 160 KiB = 163840 B per CU):
  *     block bytes (<=128 KiB, +16 pad) + 4*tableSize + near table 4<<tileLog
- *     + 3 tiles of u16 match lengths + per-window parse/emission records + 64 B control
- * so a full 128 KiB block leaves room for 6600 table entries at tileLog 9; smaller
+ *     + 2 tiles of u16 jump lengths + per-window start masks / emission records + 64 B control
+ * so a full 128 KiB block leaves room for 6400 table entries at tileLog 9; smaller
  * blocks get bigger tables and more workgroups per CU.
  */
 #include "qzstd_hip.h"
@@ -24,11 +24,11 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    if (blockSize > (64u << 10)) out->tableSize = 6600u;
+    if (blockSize > (64u << 10)) out->tableSize = 6400u;
     else if (blockSize > (32u << 10)) out->tableSize = 16384u;
     else out->tableSize = 8192u;
     out->tileLog = 9;
-    out->capLen = level >= 6 ? 64 : 32;
+    out->capLen = 128;
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;
@@ -53,9 +53,8 @@ static size_t qz_need(int level, uint32_t len)
     /* block bytes (+16 B pad for dword over-reads) + table + near table + parse scratch + control */
     return (size_t)(((len + 15u) & ~15u) + 16u) + 4u * p.tableSize        /* hash table                                    */
            + (4u << p.tileLog)     /* tile-local near table                         */
-           + 3u * (2u << p.tileLog) /* u16 match lengths of 3 tiles in flight       */
-           + 3u * ((1u << p.tileLog) >> 6) * 32u /* per-window parse records x3     */
-           + 2u * ((1u << p.tileLog) >> 6) * 16u /* per-window emission records x2  */
+           + 2u * (4u << p.tileLog) /* jump length / capped offset words, 2 tiles in flight */
+           + 2u * ((1u << p.tileLog) >> 6) * (32u + 8u) /* per-window emission records + start masks, x2 */
            + QZ_LDS_CTRL;
 }
 

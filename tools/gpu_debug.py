@@ -37,3 +37,18 @@ def dump(n=3000, first=14, count=12):
             wi, wi * 64, s[1], s[0], s[2], int(s[2]) - wi * 64, s[3], c[1], c[0], c[2], c[3]))
 if os.environ.get("QZ_DUMP"):
     dump()
+
+
+def timing():
+    plug = B.Plugin(os.path.join(B.PKG_DIR, "lib", "libqatseqprod_dbg.so"))
+    data = K.system_corpus(256 * 131072)[0]
+    blocks = [data[o:o + 131072] for o in range(0, len(data), 131072)]
+    counts, seqs, stride = plug.find_batch(blocks, 1)
+    a = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)
+    rows = np.array([a[(i + 1) * stride - 1] for i in range(len(blocks))], dtype=np.float64)
+    c = np.array(counts, dtype=np.float64)
+    print("blocks %d  seq/block %.0f" % (len(blocks), c.mean()))
+    print("per block (memtime ticks @100MHz?): parse %.0f  waitB2 %.0f  waitB1 %.0f  total %.0f" % tuple(rows.mean(axis=0)))
+    print("parse ticks per sequence %.2f, per tile %.1f" % (rows[:, 0].sum() / c.sum(), rows[:, 0].mean() / 256))
+if os.environ.get("QZ_TIMING"):
+    timing()
