@@ -158,6 +158,12 @@ struct ParseState {
 constexpr uint32_t kCappedBit = 0x80000000u;
 constexpr uint32_t kSrecWords = 8;
 
+/* vec with lane l replaced by the (uniform) val: the compiler turns this into v_writelane_b32 */
+__device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val, uint32_t l, uint32_t lane)
+{
+    return lane == l ? val : vec;
+}
+
 __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t *wmask,
                                            const uint32_t *lens, uint32_t *srecOut, uint32_t base, uint32_t n,
                                            uint32_t lane, ParseState &st)
@@ -166,6 +172,7 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
 #pragma unroll
     for (uint32_t w = 0; w < kWin; w++) lenV[w] = lens[64u * w + lane];
     const uint32_t mv = wmask[lane & (2u * kWin - 1u)]; /* lanes 0..15: {lo,hi} of windows 0..7 */
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0; /* lane w collects window w's record */
 #pragma unroll
     for (uint32_t w = 0; w < kWin; w++) {
         const uint32_t w0 = base + 64u * w;
@@ -174,31 +181,56 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
         uint32_t extLen = 0;
         if (st.cur < w0 + 64u) {
             const u64 start = (u64)rdlane(mv, 2u * w) | ((u64)rdlane(mv, 2u * w + 1u) << 32);
-            uint32_t c = rdfirst(st.cur - w0), e = 0, j, L;
-            do {
-                const u64 m = (start >> c) << c;
-                j = m ? (uint32_t)__builtin_ctzll(m) : 63u;
-                L = rdlane(lenV[w], j);
-                chosen |= m ? 1ull << j : 0ull;
-                c = m ? j + (L & 0xFFFFu) : 64u;
-                e = m ? c : e;
-            } while (c < 64u && !(L & kCappedBit));
-            if ((L & kCappedBit) && ((chosen >> j) & 1ull)) {
-                /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
-                const uint32_t pj = w0 + j, off = L & 0x7FFFFFFFu;
-                const uint32_t lim = umin(n, ((pj >> pf.extLog) + 2u) << pf.extLog);
-                extLen = extend_match(lds32, pj, off, pf.capLen, lim, lane);
-                c = e = j + extLen;
+            const uint32_t c0 = rdfirst(st.cur - w0);
+            const u64 t0 = (start >> c0) << c0;
+            if (t0) {
+                /* every lane: where does the parse stand after taking a match that starts here?
+                 * next start at/after the match end (< 64), or the exit cursor (>= 64), or
+                 * "capped" (0xFFFFFFFF) when the match must first be extended */
+                const uint32_t Lw = lenV[w];
+                const uint32_t endj = lane + Lw; /* garbage for capped lanes, fixed below */
+                const u64 rest = endj < 64u ? start >> endj : 0ull;
+                uint32_t nx = endj >= 64u ? endj : (rest ? endj + (uint32_t)__builtin_ctzll(rest) : 64u);
+                nx = (Lw & kCappedBit) ? 0xFFFFFFFFu : nx;
+                uint32_t j = (uint32_t)__builtin_ctzll(t0), jn;
+                /* the chase: 4 scalar instructions + 1 taken branch per sequence */
+                asm volatile(
+                    "1:\n"
+                    "s_bitset1_b64 %[ch], %[j]\n"
+                    "v_readlane_b32 %[jn], %[nx], %[j]\n"
+                    "s_cmp_lt_u32 %[jn], 64\n"
+                    "s_cselect_b32 %[j], %[jn], %[j]\n"
+                    "s_cbranch_scc1 1b\n"
+                    : [ch] "+s"(chosen), [j] "+s"(j), [jn] "=&s"(jn)
+                    : [nx] "v"(nx)
+                    : "scc");
+                uint32_t c, e;
+                if (jn == 0xFFFFFFFFu) {
+                    /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
+                    const uint32_t pj = w0 + j, off = rdlane(Lw, j) & 0x7FFFFFFFu;
+                    const uint32_t lim = umin(n, ((pj >> pf.extLog) + 2u) << pf.extLog);
+                    extLen = extend_match(lds32, pj, off, pf.capLen, lim, lane);
+                    c = e = j + extLen;
+                } else {
+                    c = jn;
+                    e = j + rdlane(Lw, j);
+                }
+                st.cur = w0 + umax(c, 64u);
+                st.anchor = w0 + e;
+                st.nseq += (uint32_t)__popcll(chosen);
+            } else {
+                st.cur = w0 + 64u;
             }
-            st.cur = w0 + umax(c, 64u);
-            if (chosen) st.anchor = w0 + e;
-            st.nseq += (uint32_t)__popcll(chosen);
         }
-        if (lane == 0u) {
-            uint4 *o = reinterpret_cast<uint4 *>(srecOut + w * kSrecWords);
-            o[0] = make_uint4((uint32_t)chosen, (uint32_t)(chosen >> 32), anchorIn, seqBase);
-            srecOut[w * kSrecWords + 4u] = extLen;
-        }
+        r0 = wrlane(r0, (uint32_t)chosen, w, lane);
+        r1 = wrlane(r1, (uint32_t)(chosen >> 32), w, lane);
+        r2 = wrlane(r2, anchorIn, w, lane);
+        r3 = wrlane(r3, seqBase, w, lane);
+        r4 = wrlane(r4, extLen, w, lane);
+    }
+    if (lane < kWin) {
+        *reinterpret_cast<uint4 *>(srecOut + lane * kSrecWords) = make_uint4(r0, r1, r2, r3);
+        srecOut[lane * kSrecWords + 4u] = r4;
     }
 }
 
