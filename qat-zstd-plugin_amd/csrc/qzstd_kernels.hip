@@ -65,7 +65,6 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 below(uint32_t c) { return c >= 64u ? ~0ull : ((1ull << c) - 1ull); }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 /* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte_b32 */
 __device__ __forceinline__ uint32_t lds_rd32u(const uint32_t *lds32, uint32_t a)
@@ -91,14 +90,30 @@ __device__ __forceinline__ uint32_t chunk_len(const uint32_t *lds32, uint32_t p,
     return L;
 }
 
-/* common prefix length of [p..) and [q..), capped at cap (<= 128), 32 bytes per LDS round trip */
-__device__ __forceinline__ uint32_t match_len(const uint32_t *lds32, uint32_t p, uint32_t q, uint32_t cap)
+/* first mismatching byte (0..16) of the 16 bytes at p (5 aligned dwords already in `own`) and at q */
+__device__ __forceinline__ uint32_t head_len(const uint32_t *lds32, const uint32_t (&own)[5], uint32_t ps, uint32_t q)
 {
-    uint32_t L = 0;
-    for (;;) {
+    const uint32_t qd = q >> 2, qs = q & 3u;
+    uint32_t Q[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) Q[i] = lds32[qd + i];
+    uint32_t L = 16u;
+#pragma unroll
+    for (int i = 3; i >= 0; i--) {
+        const uint32_t x = __builtin_amdgcn_alignbyte(own[i + 1], own[i], ps) ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
+        if (x) L = 4u * (uint32_t)i + ((uint32_t)__builtin_ctz(x) >> 3);
+    }
+    return L;
+}
+
+/* the rest of a candidate whose first 16 bytes matched: 32 bytes per LDS round trip up to cap */
+__device__ __forceinline__ uint32_t tail_len(const uint32_t *lds32, uint32_t p, uint32_t q, uint32_t cap)
+{
+    uint32_t L = 16u;
+    while (L < cap) {
         const uint32_t l = chunk_len(lds32, p + L, q + L);
         L += l;
-        if (l < 32u || L >= cap) break;
+        if (l < 32u) break;
     }
     return umin(L, cap);
 }
@@ -146,17 +161,25 @@ struct ParseState {
 };
 
 /*
- * The (lazy) greedy parse of one tile, by the parse wave: a lean scalar chase.  The matcher
- * waves have already reduced every position to a 64-bit start mask per window and one word per
- * position: its jump length, or (bit 31 set) the offset of a candidate that hit the length cap.
- * One step is shift / find-first-set / readlane / add with a single backward branch.  A capped
- * match is extended here, cooperatively, only when the parse actually takes it (it then leaves
- * the window, so there is at most one per window).  All of the tile's windows are fetched up
- * front (one LDS wait).  Per window it publishes {chosen mask, literal anchor at entry, index of
- * the first sequence, extended length of the last chosen match or 0} for the emitting wave.
+ * The (lazy) greedy parse of one tile, by the parse wave: a lean scalar pointer chase.  The
+ * matcher waves have reduced every position to ONE word (kept in LDS for two tiles):
+ *     bits  0..7   nx   where the parse stands after taking the match that starts here: the next
+ *                       start at/after its end (< 64), the exit cursor (64..191), or 255 = the
+ *                       candidate hit the length cap and must be extended first
+ *     bits  8..14  ns   the next start at/after this position (64 = none left in the window)
+ *     bits 15..31       the match length, or for a capped candidate its offset
+ * so one parse step is bitset / readlane / compare / select with a single taken branch.  A
+ * capped match is extended here, cooperatively, only when the parse actually takes it.  All of
+ * the tile's windows are fetched up front (one LDS wait).  Per window it publishes {chosen mask,
+ * literal anchor at entry, index of the first sequence, up to two (lane, extended length)}.
  */
-constexpr uint32_t kCappedBit = 0x80000000u;
 constexpr uint32_t kSrecWords = 8;
+constexpr uint32_t kNxCapped = 255u;
+
+__device__ __forceinline__ uint32_t pack_pos(uint32_t nx, uint32_t ns, uint32_t payload)
+{
+    return nx | (ns << 8) | (payload << 15);
+}
 
 /* vec with lane l replaced by the (uniform) val: the compiler turns this into v_writelane_b32 */
 __device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val, uint32_t l, uint32_t lane)
@@ -164,58 +187,55 @@ __device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val, uint32_t 
     return lane == l ? val : vec;
 }
 
-__device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t *wmask,
-                                           const uint32_t *lens, uint32_t *srecOut, uint32_t base, uint32_t n,
-                                           uint32_t lane, ParseState &st)
+__device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t *pv,
+                                           uint32_t *srecOut, uint32_t base, uint32_t n, uint32_t lane, ParseState &st)
 {
-    uint32_t lenV[kWin];
+    uint32_t word[kWin];
 #pragma unroll
-    for (uint32_t w = 0; w < kWin; w++) lenV[w] = lens[64u * w + lane];
-    const uint32_t mv = wmask[lane & (2u * kWin - 1u)]; /* lanes 0..15: {lo,hi} of windows 0..7 */
-    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0; /* lane w collects window w's record */
+    for (uint32_t w = 0; w < kWin; w++) word[w] = pv[64u * w + lane];
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0; /* lane w collects window w's record */
 #pragma unroll
     for (uint32_t w = 0; w < kWin; w++) {
         const uint32_t w0 = base + 64u * w;
         const uint32_t anchorIn = st.anchor, seqBase = st.nseq;
         u64 chosen = 0;
-        uint32_t extLen = 0;
+        uint32_t ext0 = 0, ext1 = 0; /* (lane << 24 | extended length) of up to two taken capped matches */
         if (st.cur < w0 + 64u) {
-            const u64 start = (u64)rdlane(mv, 2u * w) | ((u64)rdlane(mv, 2u * w + 1u) << 32);
-            const uint32_t c0 = rdfirst(st.cur - w0);
-            const u64 t0 = (start >> c0) << c0;
-            if (t0) {
-                /* every lane: where does the parse stand after taking a match that starts here?
-                 * next start at/after the match end (< 64), or the exit cursor (>= 64), or
-                 * "capped" (0xFFFFFFFF) when the match must first be extended */
-                const uint32_t Lw = lenV[w];
-                const uint32_t endj = lane + Lw; /* garbage for capped lanes, fixed below */
-                const u64 rest = endj < 64u ? start >> endj : 0ull;
-                uint32_t nx = endj >= 64u ? endj : (rest ? endj + (uint32_t)__builtin_ctzll(rest) : 64u);
-                nx = (Lw & kCappedBit) ? 0xFFFFFFFFu : nx;
-                uint32_t j = (uint32_t)__builtin_ctzll(t0), jn;
-                /* the chase: 4 scalar instructions + 1 taken branch per sequence */
-                asm volatile(
-                    "1:\n"
-                    "s_bitset1_b64 %[ch], %[j]\n"
-                    "v_readlane_b32 %[jn], %[nx], %[j]\n"
-                    "s_cmp_lt_u32 %[jn], 64\n"
-                    "s_cselect_b32 %[j], %[jn], %[j]\n"
-                    "s_cbranch_scc1 1b\n"
-                    : [ch] "+s"(chosen), [j] "+s"(j), [jn] "=&s"(jn)
-                    : [nx] "v"(nx)
-                    : "scc");
-                uint32_t c, e;
-                if (jn == 0xFFFFFFFFu) {
+            uint32_t c = rdfirst(st.cur - w0);
+            uint32_t j = (rdlane(word[w], c) >> 8) & 0x7Fu; /* first start at/after the cursor */
+            if (j < 64u) {
+                const uint32_t nx = word[w] & 0xFFu;
+                uint32_t e = 0;
+                for (;;) {
+                    uint32_t jn;
+                    /* the chase: 4 scalar instructions + 1 taken branch per sequence */
+                    asm volatile(
+                        "1:\n"
+                        "s_bitset1_b64 %[ch], %[j]\n"
+                        "v_readlane_b32 %[jn], %[nx], %[j]\n"
+                        "s_cmp_lt_u32 %[jn], 64\n"
+                        "s_cselect_b32 %[j], %[jn], %[j]\n"
+                        "s_cbranch_scc1 1b\n"
+                        : [ch] "+s"(chosen), [j] "+s"(j), [jn] "=&s"(jn)
+                        : [nx] "v"(nx)
+                        : "scc");
+                    const uint32_t payload = rdlane(word[w], j) >> 15;
+                    if (jn != kNxCapped) {
+                        c = jn;
+                        e = j + payload;
+                        break;
+                    }
                     /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
-                    const uint32_t pj = w0 + j, off = rdlane(Lw, j) & 0x7FFFFFFFu;
+                    const uint32_t pj = w0 + j;
                     const uint32_t lim = umin(n, ((pj >> pf.extLog) + 2u) << pf.extLog);
-                    extLen = extend_match(lds32, pj, off, pf.capLen, lim, lane);
-                    c = e = j + extLen;
-                } else {
-                    c = jn;
-                    e = j + rdlane(Lw, j);
+                    const uint32_t xl = extend_match(lds32, pj, payload, pf.capLen, lim, lane);
+                    if (!ext0) ext0 = (j << 24) | xl; else ext1 = (j << 24) | xl;
+                    c = e = j + xl;
+                    if (c >= 64u) break;
+                    j = (rdlane(word[w], c) >> 8) & 0x7Fu;
+                    if (j >= 64u) { c = 64u; break; }
                 }
-                st.cur = w0 + umax(c, 64u);
+                st.cur = w0 + c;
                 st.anchor = w0 + e;
                 st.nseq += (uint32_t)__popcll(chosen);
             } else {
@@ -226,11 +246,13 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
         r1 = wrlane(r1, (uint32_t)(chosen >> 32), w, lane);
         r2 = wrlane(r2, anchorIn, w, lane);
         r3 = wrlane(r3, seqBase, w, lane);
-        r4 = wrlane(r4, extLen, w, lane);
+        r4 = wrlane(r4, ext0, w, lane);
+        r5 = wrlane(r5, ext1, w, lane);
     }
     if (lane < kWin) {
         *reinterpret_cast<uint4 *>(srecOut + lane * kSrecWords) = make_uint4(r0, r1, r2, r3);
         srecOut[lane * kSrecWords + 4u] = r4;
+        srecOut[lane * kSrecWords + 5u] = r5;
     }
 }
 
@@ -242,8 +264,9 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
     const uint4 rec = *reinterpret_cast<const uint4 *>(srec);
     const u64 chosen = (u64)rec.x | ((u64)rec.y << 32);
     if (!chosen) return;
-    const uint32_t anchorIn = rec.z, seqBase = rec.w, extLen = srec[4];
-    if (extLen && lane == 63u - (uint32_t)__builtin_clzll(chosen)) len = extLen; /* extended by the parse wave */
+    const uint32_t anchorIn = rec.z, seqBase = rec.w, ext0 = srec[4], ext1 = srec[5];
+    if (ext0 && (ext0 >> 24) == lane) len = ext0 & 0xFFFFFFu; /* extended by the parse wave */
+    if (ext1 && (ext1 >> 24) == lane) len = ext1 & 0xFFFFFFu;
     const bool ch = (chosen >> lane) & 1ull;
     const u64 lower = chosen & below(lane);
     const uint32_t rank = (uint32_t)__popcll(lower);
@@ -301,8 +324,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + region);
     uint32_t *nearTab = tbl + pf.tableSize;
     uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
-    uint32_t *wmask = srec + 2u * kWin * kSrecWords;   /* [2][kWin][2]  start masks                       */
-    uint32_t *lens = wmask + 2u * kWin * 2u;           /* [2][kTile]    jump length | capped bit + offset */
+    uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kTile]    per-position parse words          */
 
     /* ---- stage the block: HBM -> LDS, 16 B per lane, coalesced ---- */
     {
@@ -314,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         for (uint32_t i = (nvec << 4) + tid; i < region; i += kThreads) lds8[i] = i < n ? g[i] : (uint8_t)0;
         for (uint32_t i = tid; i < pf.tableSize; i += kThreads) tbl[i] = 0u;
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
-        for (uint32_t i = tid; i < 2u * kWin * (kSrecWords + 2u) + 2u * kTile; i += kThreads) srec[i] = 0u; /* srec, wmask, lens */
+        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kTile; i += kThreads) srec[i] = 0u; /* srec, pv */
     }
     __syncthreads();
 
@@ -341,8 +363,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #ifdef QZ_DEBUG_DUMP
                 const u64 tA = __builtin_amdgcn_s_memtime();
 #endif
-                parse_tile(pf, lds32, wmask + (k & 1u) * kWin * 2u, lens + (k & 1u) * kTile,
-                           srec + (k & 1u) * kWin * kSrecWords, k << kTileLog, n, lane, st);
+                parse_tile(pf, lds32, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog, n,
+                           lane, st);
 #ifdef QZ_DEBUG_DUMP
                 dbgCycles += __builtin_amdgcn_s_memtime() - tA;
 #endif
@@ -420,15 +442,19 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
                 if (q < p) q2 = q;
             }
-            if (!(args.dbg & 2u)) {
-                if (q1 != kNone) {
-                    const uint32_t l = match_len(lds32, p, q1, cap);
-                    if (l >= 4u) { cl = l; off = p - q1; }
-                }
-                if (q2 != kNone) {
-                    const uint32_t l = match_len(lds32, p, q2, cap);
-                    if (l >= 4u && l >= cl) { cl = l; off = p - q2; }
-                }
+            if ((q1 != kNone || q2 != kNone) && !(args.dbg & 2u)) {
+                uint32_t own[5];
+                const uint32_t pd = p >> 2;
+#pragma unroll
+                for (int i = 0; i < 5; i++) own[i] = lds32[pd + i];
+                /* 16 bytes of both candidates first: most end there; only survivors pay for more */
+                uint32_t l1 = q1 != kNone ? head_len(lds32, own, p & 3u, q1) : 0u;
+                uint32_t l2 = q2 != kNone ? head_len(lds32, own, p & 3u, q2) : 0u;
+                if (l1 == 16u) l1 = tail_len(lds32, p, q1, cap);
+                if (l2 == 16u) l2 = tail_len(lds32, p, q2, cap);
+                l1 = umin(l1, cap); l2 = umin(l2, cap);
+                if (l1 >= 4u) { cl = l1; off = p - q1; }
+                if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }
             }
         }
         if (it < nTiles && !(args.dbg & 4u)) {
@@ -438,9 +464,15 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             const bool take1 = clN != 0u && clN >= min_len(pf, offN);
             const bool start = take && !(pf.lazy && lane != 63u && take1 && clN > cl);
             const u64 startMask = __ballot(start);
-            /* what the parse wave needs: the jump length, or the offset when the length hit the cap */
-            lens[(it & 1u) * kTile + tid] = cl == pf.capLen ? (kCappedBit | off) : cl;
-            if (lane < 2u) wmask[((it & 1u) * kWin + wave) * 2u + lane] = lane ? (uint32_t)(startMask >> 32) : (uint32_t)startMask;
+            /* what the parse wave needs, one word per position (see parse_tile) */
+            const u64 here = startMask >> lane;
+            const uint32_t ns = here ? lane + (uint32_t)__builtin_ctzll(here) : 64u;
+            const bool capped = cl == pf.capLen;
+            const uint32_t endj = lane + cl;
+            const u64 rest = endj < 64u ? startMask >> endj : 0ull;
+            uint32_t nx = endj >= 64u ? endj : (rest ? endj + (uint32_t)__builtin_ctzll(rest) : 64u);
+            nx = capped ? kNxCapped : nx;
+            pv[(it & 1u) * kTile + tid] = pack_pos(nx, ns, capped ? off : cl);
         }
         offA = off;
         lenA = cl;

@@ -53,8 +53,8 @@ static size_t qz_need(int level, uint32_t len)
     /* block bytes (+16 B pad for dword over-reads) + table + near table + parse scratch + control */
     return (size_t)(((len + 15u) & ~15u) + 16u) + 4u * p.tableSize        /* hash table                                    */
            + (4u << p.tileLog)     /* tile-local near table                         */
-           + 2u * (4u << p.tileLog) /* jump length / capped offset words, 2 tiles in flight */
-           + 2u * ((1u << p.tileLog) >> 6) * (32u + 8u) /* per-window emission records + start masks, x2 */
+           + 2u * (4u << p.tileLog) /* per-position parse words, 2 tiles in flight */
+           + 2u * ((1u << p.tileLog) >> 6) * 32u /* per-window emission records, x2 */
            + QZ_LDS_CTRL;
 }
 
