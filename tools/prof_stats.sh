@@ -1,0 +1,11 @@
+#!/bin/bash
+# rocprofv3 kernel-trace + stats of the default bench workload (run on the GPU box via gpurun).
+# usage: tools/prof_stats.sh <tag>     -> gpurun_out/stats_<tag>/  (copy the summary into profiles/)
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/stats_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python $R/bench.py --steps 10 --warmup 2 --no-cpu "$@" > $OUT/run.log 2>&1
+find $OUT -name '*kernel_stats.csv' -exec cat {} \;
