@@ -34,6 +34,26 @@ import qz_shard as S  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def profiled_traffic(blocks: int, block: int):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/rNN_pmc_summary.txt,
+    produced by tools/prof_pmc.sh with separate --pmc passes on this same workload).  Corrected as
+    MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are KiB, and on gfx950 FETCH_SIZE
+    reports half of a 16 B/lane coalesced stream.  None when no summary matches the workload."""
+    import glob
+    import re
+    if (blocks, block) != (8192, 131072):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+    if not files:
+        return None, None
+    txt = open(files[-1]).read()
+    f = re.search(r"FETCH_SIZE\s+per-launch\s+([0-9.]+)", txt)
+    w = re.search(r"WRITE_SIZE\s+per-launch\s+([0-9.]+)", txt)
+    if not (f and w):
+        return None, None
+    return int((2.0 * float(f.group(1)) + float(w.group(1))) * 1024), os.path.basename(files[-1])
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +244,7 @@ def main():
         value = total_bytes / wall / 1e6
         alg_bytes = size + 16 * seq_total  # per launch: block bytes read once + 16 B per sequence written
         achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = profiled_traffic(nb, block) if level == 1 else (None, None)
         out = {
             "metric": "input MB/s via ZSTD_compress2 L1 128KiB blocks @1/2/4/8 GPU; ratio vs sw zstd",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -235,7 +256,7 @@ def main():
                        "corpus": prov[:300], "level": level, "block_bytes": block, "blocks_per_gpu": nb,
                        "parallelism": "block-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "qzstd_find_sequences_kernel", "kernel_ms_avg": round(kern_avg_ms, 3),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "input_read_frac_of_peak": round(size / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
