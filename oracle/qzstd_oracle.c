@@ -55,7 +55,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     memset(out, 0, sizeof(*out));
     out->tableSize = blockSize > (64u << 10) ? 6400u : (blockSize > (32u << 10) ? 16384u : 8192u);
     out->tileLog = 9;
-    out->capLen = 128;
+    out->capLen = 64;
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;

@@ -187,15 +187,16 @@ __device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val, uint32_t 
     return lane == l ? val : vec;
 }
 
+template <uint32_t W_BEGIN, uint32_t W_END>
 __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t *pv,
                                            uint32_t *srecOut, uint32_t base, uint32_t n, uint32_t lane, ParseState &st)
 {
     uint32_t word[kWin];
 #pragma unroll
-    for (uint32_t w = 0; w < kWin; w++) word[w] = pv[64u * w + lane];
+    for (uint32_t w = W_BEGIN; w < W_END; w++) word[w] = pv[64u * w + lane];
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0; /* lane w collects window w's record */
 #pragma unroll
-    for (uint32_t w = 0; w < kWin; w++) {
+    for (uint32_t w = W_BEGIN; w < W_END; w++) {
         const uint32_t w0 = base + 64u * w;
         const uint32_t anchorIn = st.anchor, seqBase = st.nseq;
         u64 chosen = 0;
@@ -249,7 +250,7 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
         r4 = wrlane(r4, ext0, w, lane);
         r5 = wrlane(r5, ext1, w, lane);
     }
-    if (lane < kWin) {
+    if (lane >= W_BEGIN && lane < W_END) {
         *reinterpret_cast<uint4 *>(srecOut + lane * kSrecWords) = make_uint4(r0, r1, r2, r3);
         srecOut[lane * kSrecWords + 4u] = r4;
         srecOut[lane * kSrecWords + 5u] = r5;
@@ -344,49 +345,40 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
-        __builtin_amdgcn_s_setprio(3); /* it is the serial critical path: win issue arbitration on its SIMD */
+        if (!(args.dbg & 32u)) __builtin_amdgcn_s_setprio(3); /* the serial critical path: win issue arbitration on its SIMD */
         ParseState st = { 0u, 0u, 0u };
+        constexpr uint32_t kSplit = 2; /* windows parsed in interval 1 (the short one), the rest in interval 2 */
 #ifdef QZ_DEBUG_DUMP
-        u64 dbgCycles = 0, dbgWait = 0, dbgWait1 = 0;
-        const u64 tStart = __builtin_amdgcn_s_memtime();
+        u64 pI1 = 0, pW1 = 0, pI2 = 0, pW2 = 0, tQ = __builtin_amdgcn_s_memtime();
+#define QZ_PLAP(acc) { const u64 tN = __builtin_amdgcn_s_memtime(); acc += tN - tQ; tQ = tN; }
+#else
+#define QZ_PLAP(acc)
 #endif
         for (uint32_t it = 0; it < nTiles + 2u; it++) {
-#ifdef QZ_DEBUG_DUMP
-            const u64 tC = __builtin_amdgcn_s_memtime();
-#endif
+            const bool work = it >= 1u && it - 1u < nTiles && !(args.dbg & 1u);
+            const uint32_t k = it - 1u;
+            if (work)
+                parse_tile<0, kSplit>(pf, lds32, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog,
+                                      n, lane, st);
+            QZ_PLAP(pI1)
             __syncthreads(); /* B1 */
-#ifdef QZ_DEBUG_DUMP
-            dbgWait1 += __builtin_amdgcn_s_memtime() - tC;
-#endif
-            if (it >= 1u && it - 1u < nTiles && !(args.dbg & 1u)) {
-                const uint32_t k = it - 1u;
-#ifdef QZ_DEBUG_DUMP
-                const u64 tA = __builtin_amdgcn_s_memtime();
-#endif
-                parse_tile(pf, lds32, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog, n,
-                           lane, st);
-#ifdef QZ_DEBUG_DUMP
-                dbgCycles += __builtin_amdgcn_s_memtime() - tA;
-#endif
-            }
-#ifdef QZ_DEBUG_DUMP
-            const u64 tB = __builtin_amdgcn_s_memtime();
-#endif
+            QZ_PLAP(pW1)
+            if (work)
+                parse_tile<kSplit, kWin>(pf, lds32, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords,
+                                         k << kTileLog, n, lane, st);
+            QZ_PLAP(pI2)
             __syncthreads(); /* B2 */
-#ifdef QZ_DEBUG_DUMP
-            dbgWait += __builtin_amdgcn_s_memtime() - tB;
-#endif
+            QZ_PLAP(pW2)
         }
+#ifdef QZ_DEBUG_DUMP
+        if (lane == 0) out[blk.seqCap - 2u] = make_uint4((uint32_t)pI1, (uint32_t)pW1, (uint32_t)pI2, (uint32_t)pW2);
+#endif
         if (lane == 0) {
             /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
             uint32_t count = st.nseq + 1u;
             if (st.nseq < blk.seqCap) out[st.nseq] = make_uint4(0u, n - st.anchor, 0u, 0u);
             if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
             args.nseq[blockIdx.x] = count;
-#ifdef QZ_DEBUG_DUMP
-            out[blk.seqCap - 1u] = make_uint4((uint32_t)dbgCycles, (uint32_t)dbgWait, (uint32_t)dbgWait1,
-                                              (uint32_t)(__builtin_amdgcn_s_memtime() - tStart));
-#endif
         }
         return;
     }
@@ -399,6 +391,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 
     /* (offset, jump length) of this thread's position in tiles it-1 and it-2 */
     uint32_t offA = 0, lenA = 0, offB = 0, lenB = 0;
+#ifdef QZ_DEBUG_DUMP
+    u64 dI1 = 0, dW1 = 0, dI2 = 0, dW2 = 0, tP = __builtin_amdgcn_s_memtime();
+#define QZ_LAP(acc) { const u64 tN = __builtin_amdgcn_s_memtime(); acc += tN - tP; tP = tN; }
+#else
+#define QZ_LAP(acc)
+#endif
 
     for (uint32_t it = 0; it < nTiles + 2u; it++) {
         const uint32_t t0 = it << kTileLog;
@@ -422,7 +420,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             if (pf.nearTab)
                 atomicMin(&nearTab[mix >> nearShift], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
         }
+        QZ_LAP(dI1)
         __syncthreads(); /* B1 */
+        QZ_LAP(dW1)
 
         /* ================= interval 2 ================= */
         offB = offA; lenB = lenA;
@@ -476,8 +476,13 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         }
         offA = off;
         lenA = cl;
+        QZ_LAP(dI2)
         __syncthreads(); /* B2 */
+        QZ_LAP(dW2)
     }
+#ifdef QZ_DEBUG_DUMP
+    if (lane == 0) out[blk.seqCap - 3u - wave] = make_uint4((uint32_t)dI1, (uint32_t)dW1, (uint32_t)dI2, (uint32_t)dW2);
+#endif
 }
 
 thread_local char g_err[256] = "";

@@ -28,7 +28,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     else if (blockSize > (32u << 10)) out->tableSize = 16384u;
     else out->tableSize = 8192u;
     out->tileLog = 9;
-    out->capLen = 128;
+    out->capLen = 64;
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;

@@ -48,7 +48,12 @@ def timing():
     rows = np.array([a[(i + 1) * stride - 1] for i in range(len(blocks))], dtype=np.float64)
     c = np.array(counts, dtype=np.float64)
     print("blocks %d  seq/block %.0f" % (len(blocks), c.mean()))
-    print("per block (memtime ticks @100MHz?): parse %.0f  waitB2 %.0f  waitB1 %.0f  total %.0f" % tuple(rows.mean(axis=0)))
-    print("parse ticks per sequence %.2f, per tile %.1f" % (rows[:, 0].sum() / c.sum(), rows[:, 0].mean() / 256))
+    rows2 = np.array([a[(i + 1) * stride - 2] for i in range(len(blocks))], dtype=np.float64)
+    print("parse wave per tile: I1 %.0f waitB1 %.0f I2 %.0f waitB2 %.0f" % tuple(rows2.mean(axis=0) / 256))
+    for wv in range(8):
+        rw = np.array([a[(i + 1) * stride - 3 - wv] for i in range(len(blocks))], dtype=np.float64)
+        print("matcher wave %d per tile: I1 %.0f waitB1 %.0f I2 %.0f waitB2 %.0f" % ((wv,) + tuple(rw.mean(axis=0) / 256)))
+    return
+    print("matcher wave 0, cycles per block: I1 %.0f  waitB1 %.0f  I2 %.0f  waitB2 %.0f ; per tile: %s" % (tuple(rows.mean(axis=0)) + (str((rows.mean(axis=0) / 256).round(0)),)))
 if os.environ.get("QZ_TIMING"):
     timing()
