@@ -21,7 +21,6 @@ import ctypes as C
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -102,64 +101,37 @@ def cpu_oracle_leg(data: bytes, block: int, level: int, seconds: float):
             "sample": "oracle/qzstd_oracle.c qzo_find_sequences, first %d blocks of the batch, 1 thread" % (done // block)}
 
 
-def _compress_worker(zpath, data, block, level, lo, hi, producer, res, idx, hint=None):
-    z = B.Zstd(zpath)
-    state = None
-    if producer is not None:
-        state = producer.lib.QZSTD_createSeqProdState()
-        zc = z.cctx(level, producer=producer.producer_addr, state=state, validate=False)
-    else:
-        zc = z.cctx(level)
-    cap = z.lib.ZSTD_compressBound(block)
-    dst = C.create_string_buffer(cap)
-    view = (C.c_char * (hi - lo)).from_buffer_copy(data[lo:hi])
-    base = C.addressof(view)
-    total = 0
-    t0 = time.perf_counter()
-    if producer is not None and hint:
-        producer.lib.QZSTD_hintSource(state, base, hi - lo, block, level)
-    for o in range(0, hi - lo, block):
-        n = min(block, hi - lo - o)
-        r = z.lib.ZSTD_compress2(zc, dst, cap, base + o, n)
-        if z.is_error(r):
-            res[idx] = ("error", z.err(r))
-            return
-        total += r
-    res[idx] = (time.perf_counter() - t0, total)
-    z.free(zc)
-    if state:
-        producer.lib.QZSTD_freeSeqProdState(state)
-
-
-def threaded_compress(zpath, data, block, level, threads, producer=None, hint=False):
-    """benchmark.c shape (reference test/benchmark.c:300-321): T threads, own CCtx each,
-    one ZSTD_compress2 per chunk, each chunk its own frame."""
-    nb = len(data) // block
-    per = (nb // threads) * block
-    res = [None] * threads
-    ths = []
-    t0 = time.perf_counter()
-    for t in range(threads):
-        th = threading.Thread(target=_compress_worker, args=(zpath, data, block, level, t * per, (t + 1) * per,
-                                                             producer, res, t, hint))
-        th.start()
-        ths.append(th)
-    for th in ths:
-        th.join()
-    wall = time.perf_counter() - t0
-    for r in res:
-        if r is None or r[0] == "error":
-            return {"error": str(r)}
-    csize = sum(r[1] for r in res)
-    return {"MBps": round(per * threads / wall / 1e6, 1), "threads": threads, "bytes": per * threads,
-            "csize": csize, "ratio": round(per * threads / csize, 4)}
-
-
-def find_old_libzstd():
-    for p in ("/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"):
-        if os.path.isfile(p):
-            return p
-    return None
+def c_benchmark(sample: bytes, block: int, level: int, threads: int, mode: int, hint: bool = False, ext_rep: int = 0):
+    """run qat-zstd-plugin_amd/test/benchmark (counterpart of the reference's test/benchmark.c: T threads,
+    one CCtx each, one ZSTD_compress2 per chunk, each chunk its own frame) on a sample file"""
+    import re
+    import subprocess
+    import tempfile
+    tdir = os.path.join(B.PKG_DIR, "test")
+    zpath = B.find_libzstd()
+    try:
+        subprocess.check_call(["make", "-C", tdir, "benchmark", "ZSTDLIB=" + zpath], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            f.write(sample)
+            name = f.name
+        cmd = [os.path.join(tdir, "benchmark"), "-m%d" % mode, "-t%d" % threads, "-l2", "-c%d" % block, "-L%d" % level,
+               "-E%d" % ext_rep] + (["-H1"] if hint else []) + [name]
+        t0 = time.perf_counter()
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        os.unlink(name)
+        agg = re.search(r"aggregate compression ([0-9.]+) MB/s", out.stderr)
+        first = re.search(r"Compression: (\d+) -> (\d+) ", out.stderr)
+        lat = re.search(r"P50 ([0-9.]+)\s+P75 [0-9.]+\s+P99 ([0-9.]+)", out.stderr)
+        if out.returncode != 0 or not agg or not first:
+            return {"error": (out.stderr or "benchmark failed")[-300:]}
+        return {"MBps": float(agg.group(1)), "threads": threads, "bytes_per_thread": int(first.group(1)),
+                "csize": int(first.group(2)), "ratio": round(int(first.group(1)) / max(int(first.group(2)), 1), 4),
+                "latency_us_p50": float(lat.group(1)) if lat else None, "latency_us_p99": float(lat.group(2)) if lat else None,
+                "tool": "qat-zstd-plugin_amd/test/benchmark " + " ".join(cmd[1:-1]), "wall_s": round(wall, 2)}
+    except Exception as e:  # noqa: BLE001 - the bench line must still be printed
+        return {"error": repr(e)[:300]}
 
 
 # ----------------------------------------------------------------------------- main
@@ -265,25 +237,19 @@ def main():
         if not a.no_cpu:
             ncpu = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_oracle_leg(shard, block, level, a.cpu_seconds)
-            # north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape
-            sample = shard[:min(len(shard), 256 * block)]
-            z157 = B.find_libzstd()
+            # north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape,
+            # measured by the C tool in the same run on the host cores of this box
+            sample = shard[:min(len(shard), 512 * block)]
             thr = min(ncpu, 16)  # <= QZ_DEFAULT_SLOTS_PER_DEVICE: one slot per thread
-            sw = threaded_compress(z157, sample, block, level, thr)
-            out["cpu_libzstd_sw"] = {"lib": os.path.basename(z157), "host_cores": ncpu, **(sw or {})}
-            old = find_old_libzstd()
-            if old:
-                sw_old = threaded_compress(old, sample, block, level, thr)
-                out["cpu_libzstd_sw_optimised_build"] = {"lib": os.path.basename(old), "host_cores": ncpu, **(sw_old or {})}
-            # end to end through ZSTD_compress2 with the plugin registered (look-ahead hint on)
-            L.QZSTD_startQatDevice()
-            e2e = threaded_compress(z157, sample, block, level, thr, producer=plug, hint=True)
-            L.QZSTD_stopQatDevice()
-            if e2e and sw and "csize" in e2e and "csize" in sw:
-                out["e2e_zstd_compress2_plugin"] = {**e2e, "csize_vs_sw": round(e2e["csize"] / sw["csize"], 4),
-                                                    "ratio_within_2pct": e2e["csize"] <= sw["csize"] * 1.02}
-            else:
-                out["e2e_zstd_compress2_plugin"] = e2e
+            sw = c_benchmark(sample, block, level, thr, mode=0)
+            out["cpu_libzstd_sw"] = {"lib": os.path.basename(B.find_libzstd()), "host_cores": ncpu, **sw}
+            # end to end through ZSTD_compress2 with the plugin registered (look-ahead hint on / off)
+            e2e = c_benchmark(sample, block, level, thr, mode=1, hint=True)
+            if "csize" in e2e and "csize" in sw:
+                e2e["csize_vs_sw"] = round(e2e["csize"] / sw["csize"], 4)
+                e2e["ratio_within_2pct"] = e2e["csize"] <= sw["csize"] * 1.02
+            out["e2e_zstd_compress2_plugin"] = e2e
+            out["e2e_zstd_compress2_plugin_per_block_sync"] = c_benchmark(sample[:64 * block], block, level, thr, mode=1)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

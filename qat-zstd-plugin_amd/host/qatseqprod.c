@@ -10,7 +10,9 @@
  *   QZSTD_startQatDevice   :948-964                runtime probe + slot table, under a mutex
  *   instance discovery + round-robin shuffle       slots interleaved across GPUs so that
  *     :529-663                                       consecutive slots sit on different devices
- *   QZSTD_grabInstance / releaseInstance :905-933  test-and-set sweep starting at the hint
+ *   QZSTD_grabInstance / releaseInstance :905-933  test-and-set sweep starting at the hint (hint path,
+ *                                                    QZSTD_HIP_COALESCE=0); by default callers are
+ *                                                    merged into one launch per tick per GPU (coalescer)
  *   QZSTD_allocInstMem (lazy)  :685-822            pinned + device buffers, created on first use
  *   input staging memcpy       :1222-1227          memcpy into the pinned staging buffer
  *   cpaDcCompressData2 + poll  :1243-1272          H2D, kernel launch, D2H on the slot's stream,
@@ -73,15 +75,58 @@ typedef struct {
     qzstd_hip_block_t *dBatchDesc; unsigned int *dBatchCount; size_t dBatchBlocksCap;
 } QZSTD_Slot_T;
 
+/*
+ * Cross-thread request coalescing (one per GPU).  The producer API hands over ONE block per
+ * call and waits, and a single block keeps one of 256 CUs busy for ~0.7 ms; many callers
+ * (one CCtx per thread, the reference's own scaling model: README.md:138) are therefore merged
+ * into one launch per tick: the first caller to find the device idle becomes the leader of the
+ * open batch and runs it; callers arriving while it runs pile up in the other batch, whose first
+ * member leads it when the device frees up ("group commit": no timers, no added latency for a
+ * lone caller).  Every caller copies its own block into the batch's pinned staging area and its
+ * own result out of it, so those copies run in parallel on the callers' threads.
+ */
+#define QZ_BATCH_MAX 32
+typedef struct {
+    const void *src;
+    size_t srcSize, cap, rc;
+} QZSTD_Req_T;
+
+typedef struct {
+    int state; /* 0 open (collecting), 1 running, 2 done (results being copied out) */
+    int n, copied, consumed, level;
+    QZSTD_Req_T req[QZ_BATCH_MAX];
+    unsigned char *hSrc;      /* pinned, QZ_BATCH_MAX x QZ_SRC_STRIDE */
+    ZSTD_Sequence *hSeqs;     /* pinned, QZ_BATCH_MAX x seqStride */
+    qzstd_hip_block_t *hDesc; /* pinned */
+    unsigned int *hCount;     /* pinned */
+} QZSTD_Batch_T;
+
+typedef struct {
+    int device, ready, running, open; /* open = index of the batch that accepts requests */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    QZSTD_Batch_T batch[2];
+    void *stream;
+    unsigned char *dSrc;
+    ZSTD_Sequence *dSeqs;
+    qzstd_hip_block_t *dDesc;
+    unsigned int *dCount;
+    size_t seqStride;
+    unsigned long launches, blocks;
+} QZSTD_Coalescer_T;
+#define QZ_SRC_STRIDE ((size_t)QZSTD_HIP_BLOCK_MAX + 64)
+
 typedef struct {
     int status; /* QZSTD_Status_e */
     int numDevices;
     int numSlots;
     QZSTD_Slot_T *slots;
+    QZSTD_Coalescer_T *coal; /* one per device */
+    int coalesce;            /* QZSTD_HIP_COALESCE (default 1) */
     pthread_mutex_t mutex;
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, PTHREAD_MUTEX_INITIALIZER };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, PTHREAD_MUTEX_INITIALIZER };
 
 /* Per-CCtx state (opaque to the caller). */
 typedef struct {
@@ -176,6 +221,157 @@ static void qzReleaseSlot(int i)
     __sync_lock_release(&gProc.slots[i].lock);
 }
 
+/* ---------------------------------------------------------------- coalescer ------ */
+
+static void qzFreeCoalescer(QZSTD_Coalescer_T *c)
+{
+    int b;
+    if (c->stream) (void)qzstd_hip_stream_sync(c->device, c->stream);
+    for (b = 0; b < 2; b++) {
+        qzstd_hip_host_free(c->batch[b].hSrc);
+        qzstd_hip_host_free(c->batch[b].hSeqs);
+        qzstd_hip_host_free(c->batch[b].hDesc);
+        qzstd_hip_host_free(c->batch[b].hCount);
+    }
+    qzstd_hip_free(c->device, c->dSrc);
+    qzstd_hip_free(c->device, c->dSeqs);
+    qzstd_hip_free(c->device, c->dDesc);
+    qzstd_hip_free(c->device, c->dCount);
+    if (c->stream) qzstd_hip_stream_destroy(c->device, c->stream);
+    QZ_LOG(2, "device %d: %lu block(s) in %lu coalesced launch(es)\n", c->device, c->blocks, c->launches);
+    pthread_mutex_destroy(&c->mu);
+    pthread_cond_destroy(&c->cv);
+}
+
+/* lazy, under c->mu */
+static int qzSetupCoalescer(QZSTD_Coalescer_T *c)
+{
+    int b, ok = 1;
+    if (c->ready) return QZSTD_OK;
+    c->seqStride = qzstd_hip_sequence_bound(QZSTD_HIP_BLOCK_MAX);
+    c->stream = qzstd_hip_stream_create(c->device);
+    c->dSrc = (unsigned char *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * QZ_SRC_STRIDE);
+    c->dSeqs = (ZSTD_Sequence *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * c->seqStride * sizeof(ZSTD_Sequence));
+    c->dDesc = (qzstd_hip_block_t *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * sizeof(qzstd_hip_block_t));
+    c->dCount = (unsigned int *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * sizeof(unsigned int));
+    ok = c->stream && c->dSrc && c->dSeqs && c->dDesc && c->dCount;
+    for (b = 0; b < 2 && ok; b++) {
+        QZSTD_Batch_T *bt = &c->batch[b];
+        bt->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SRC_STRIDE);
+        bt->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(QZ_BATCH_MAX * c->seqStride * sizeof(ZSTD_Sequence));
+        bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(qzstd_hip_block_t));
+        bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(unsigned int));
+        ok = bt->hSrc && bt->hSeqs && bt->hDesc && bt->hCount;
+    }
+    if (!ok) {
+        QZ_LOG(1, "coalescer setup failed on device %d: %s\n", c->device, qzstd_hip_last_error());
+        return QZSTD_FAIL;
+    }
+    c->ready = 1;
+    return QZSTD_OK;
+}
+
+/* the leader's job: one launch for the whole batch (called WITHOUT c->mu held) */
+static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
+{
+    const int n = bt->n, dev = c->device;
+    unsigned int maxLen = 0;
+    int i, failed = 0;
+    for (i = 0; i < n; i++) {
+        bt->hDesc[i].srcOff = (size_t)i * QZ_SRC_STRIDE;
+        bt->hDesc[i].seqOff = (size_t)i * c->seqStride;
+        bt->hDesc[i].srcLen = (unsigned int)bt->req[i].srcSize;
+        bt->hDesc[i].seqCap = (unsigned int)(bt->req[i].cap < c->seqStride ? bt->req[i].cap : c->seqStride);
+        if (bt->hDesc[i].srcLen > maxLen) maxLen = bt->hDesc[i].srcLen;
+    }
+    failed = qzstd_hip_memcpy_h2d(dev, c->stream, c->dSrc, bt->hSrc, (size_t)n * QZ_SRC_STRIDE) ||
+             qzstd_hip_memcpy_h2d(dev, c->stream, c->dDesc, bt->hDesc, (size_t)n * sizeof(qzstd_hip_block_t)) ||
+             qzstd_hip_find_sequences(dev, c->stream, bt->level, c->dSrc, c->dDesc, (unsigned int)n, maxLen, c->dSeqs,
+                                      c->dCount) ||
+             qzstd_hip_memcpy_d2h(dev, c->stream, bt->hCount, c->dCount, (size_t)n * sizeof(unsigned int)) ||
+             qzstd_hip_stream_sync(dev, c->stream);
+    for (i = 0; i < n && !failed; i++) { /* gather every block's used prefix */
+        const size_t cnt = bt->hCount[i];
+        if (cnt == QZSTD_HIP_NSEQ_ERROR || cnt == 0 || cnt >= bt->req[i].cap - 1) continue;
+        failed = qzstd_hip_memcpy_d2h(dev, c->stream, bt->hSeqs + (size_t)i * c->seqStride,
+                                      c->dSeqs + (size_t)i * c->seqStride, cnt * sizeof(ZSTD_Sequence));
+    }
+    if (!failed) failed = qzstd_hip_stream_sync(dev, c->stream);
+    for (i = 0; i < n; i++) {
+        const size_t cnt = failed ? QZSTD_HIP_NSEQ_ERROR : bt->hCount[i];
+        /* capacity rule, reference :1318-1322 */
+        bt->req[i].rc = (cnt == QZSTD_HIP_NSEQ_ERROR || cnt == 0 || cnt >= bt->req[i].cap - 1) ? ZSTD_SEQUENCE_PRODUCER_ERROR : cnt;
+    }
+    if (failed) QZ_LOG(1, "device request failed: %s\n", qzstd_hip_last_error());
+    c->launches++;
+    c->blocks += (unsigned long)n;
+}
+
+/* one block through the coalescer of device `dev`; returns the sequence count or the error code */
+static size_t qzCoalescedBlock(int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
+                               size_t srcSize, int level)
+{
+    QZSTD_Coalescer_T *c = &gProc.coal[dev];
+    QZSTD_Batch_T *bt;
+    size_t rc;
+    int i;
+
+    pthread_mutex_lock(&c->mu);
+    if (qzSetupCoalescer(c) != QZSTD_OK) {
+        pthread_mutex_unlock(&c->mu);
+        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+    }
+    for (;;) { /* join the open batch (same level only) */
+        bt = &c->batch[c->open];
+        if (bt->state == 0 && bt->n < QZ_BATCH_MAX && (bt->n == 0 || bt->level == level)) break;
+        pthread_cond_wait(&c->cv, &c->mu);
+    }
+    i = bt->n++;
+    bt->level = level;
+    bt->req[i].src = src;
+    bt->req[i].srcSize = srcSize;
+    bt->req[i].cap = outSeqsCapacity;
+    bt->req[i].rc = ZSTD_SEQUENCE_PRODUCER_ERROR;
+    pthread_mutex_unlock(&c->mu);
+
+    memcpy(bt->hSrc + (size_t)i * QZ_SRC_STRIDE, src, srcSize); /* staging copy (reference :1223), on the caller's thread */
+
+    pthread_mutex_lock(&c->mu);
+    bt->copied++;
+    pthread_cond_broadcast(&c->cv);
+    while (bt->state != 2) {
+        if (bt->state == 0 && !c->running && bt == &c->batch[c->open] && c->batch[c->open ^ 1].state == 0) {
+            /* device idle and nobody leads this batch yet: lead it */
+            c->running = 1;
+            bt->state = 1;
+            c->open ^= 1; /* newcomers now collect in the other batch */
+            while (bt->copied < bt->n) pthread_cond_wait(&c->cv, &c->mu); /* members still staging */
+            pthread_mutex_unlock(&c->mu);
+            qzRunBatch(c, bt);
+            pthread_mutex_lock(&c->mu);
+            bt->state = 2;
+            c->running = 0;
+            pthread_cond_broadcast(&c->cv);
+            break;
+        }
+        pthread_cond_wait(&c->cv, &c->mu);
+    }
+    pthread_mutex_unlock(&c->mu);
+
+    rc = bt->req[i].rc;
+    if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR)
+        memcpy(outSeqs, bt->hSeqs + (size_t)i * c->seqStride, rc * sizeof(ZSTD_Sequence));
+
+    pthread_mutex_lock(&c->mu);
+    if (++bt->consumed == bt->n) { /* last one out re-opens the batch */
+        bt->n = bt->copied = bt->consumed = 0;
+        bt->state = 0;
+        pthread_cond_broadcast(&c->cv);
+    }
+    pthread_mutex_unlock(&c->mu);
+    return rc;
+}
+
 /* ---------------------------------------------------------------- lifecycle ------ */
 
 static int qzEnvInt(const char *name, int dflt, int lo, int hi)
@@ -205,6 +401,14 @@ static int qzBuildSlots(void)
     gProc.numDevices = nDev;
     gProc.numSlots = nDev * perDev;
     for (i = 0; i < gProc.numSlots; i++) gProc.slots[i].device = i % nDev;
+    gProc.coalesce = qzEnvInt("QZSTD_HIP_COALESCE", 1, 0, 1);
+    gProc.coal = (QZSTD_Coalescer_T *)calloc((size_t)nDev, sizeof(QZSTD_Coalescer_T));
+    if (!gProc.coal) return QZSTD_FAIL;
+    for (i = 0; i < nDev; i++) {
+        gProc.coal[i].device = i;
+        pthread_mutex_init(&gProc.coal[i].mu, NULL);
+        pthread_cond_init(&gProc.coal[i].cv, NULL);
+    }
     return QZSTD_OK;
 }
 
@@ -238,6 +442,11 @@ void QZSTD_stopQatDevice(void)
         for (i = 0; i < gProc.numSlots; i++) qzFreeSlot(&gProc.slots[i]);
         free(gProc.slots);
     }
+    if (gProc.coal) {
+        for (i = 0; i < gProc.numDevices; i++) qzFreeCoalescer(&gProc.coal[i]);
+        free(gProc.coal);
+    }
+    gProc.coal = NULL;
     gProc.slots = NULL;
     gProc.numSlots = 0;
     gProc.numDevices = 0;
@@ -368,6 +577,16 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
         }
     }
 
+    if (gProc.coalesce) {
+        /* sticky device per state, states spread round-robin over the GPUs */
+        static volatile int nextDev = 0;
+        if (s->slotHint < 0) s->slotHint = __sync_fetch_and_add(&nextDev, 1);
+        rc = qzCoalescedBlock(s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize, compressionLevel);
+        if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
+        QZ_LOG(2, "block %zu B level %d -> %zu sequences (coalesced, device %d)\n", srcSize, compressionLevel, rc,
+               s->slotHint % gProc.numDevices);
+        return rc;
+    }
     i = qzGrabSlot(s->slotHint);
     if (i < 0) {
         QZ_LOG(1, "failed to grab a slot\n");

@@ -1,0 +1,286 @@
+/*
+ * benchmark.c — multi-threaded chunked ZSTD_compress2 benchmark for the drop-in producer.
+ *
+ * Same measurement shape and command line as the reference's tool
+ * (/root/reference/test/benchmark.c): options -t -l -c -E -L -m (:171-184, :425-479), K/M size
+ * suffixes (:192-220), one CCtx/DCtx per thread (:241-242), the input cut into chunks each
+ * compressed as its own frame and timed with CLOCK_MONOTONIC around every ZSTD_compress2
+ * (:300-321), ratio = sum(cSize)/srcSize (:323-326), whole-buffer decompress + memcmp as the
+ * PASS criterion (:329-339), a timed decompression loop (:350-369), a per-thread report line
+ * (:374-382) and latency percentiles from 200 geometric buckets x1.05 from 1 us (:100-169,
+ * :522-530).  -m0 = libzstd's own match-finder (plugin unregistered), the CPU baseline.
+ * Written from scratch; one additive option:  -H1  announce each thread's buffer to the plugin
+ * with QZSTD_hintSource() so that the GPU match-finds it in one batched launch.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "qatseqprod.h"
+
+#define MB_BYTES 1000000.0 /* MB = 10^6 bytes, as in the reference (:56) */
+#define NBUCKETS 200
+
+typedef struct {
+    unsigned threads, loops, level, mode, extRep, hint;
+    size_t chunk;
+    const unsigned char *src;
+    size_t srcSize;
+} Options;
+
+typedef struct {
+    const Options *opt;
+    unsigned id;
+    int pass;
+    double compMBps, decompMBps, ratioPct;
+} Worker;
+
+/* latency histogram shared by all threads: bucket i upper bound = 1000 ns * 1.05^i */
+static double gBound[NBUCKETS];
+static unsigned long gCount[NBUCKETS];
+static unsigned long gSamples, gSumNs, gMinNs = ~0ul, gMaxNs;
+static pthread_mutex_t gHistLock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_barrier_t gStart, gMid;
+
+static void histInit(void)
+{
+    double b = 1000.0;
+    for (int i = 0; i < NBUCKETS; i++, b *= 1.05) gBound[i] = b;
+}
+
+static void histAddBatch(const unsigned long *local, unsigned long n, unsigned long sum, unsigned long mn, unsigned long mx)
+{
+    pthread_mutex_lock(&gHistLock);
+    for (int i = 0; i < NBUCKETS; i++) gCount[i] += local[i];
+    gSamples += n;
+    gSumNs += sum;
+    if (mn < gMinNs) gMinNs = mn;
+    if (mx > gMaxNs) gMaxNs = mx;
+    pthread_mutex_unlock(&gHistLock);
+}
+
+static int bucketOf(unsigned long ns)
+{
+    int lo = 0, hi = NBUCKETS - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if ((double)ns < gBound[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+static double percentileNs(double p)
+{
+    const double want = (double)gSamples * p / 100.0;
+    double seen = 0;
+    for (int i = 0; i < NBUCKETS; i++) {
+        if (seen + (double)gCount[i] >= want && gCount[i]) {
+            const double lo = i ? gBound[i - 1] : 0.0, hi = gBound[i];
+            double v = lo + (hi - lo) * (want - seen) / (double)gCount[i];
+            if (v < (double)gMinNs) v = (double)gMinNs;
+            if (v > (double)gMaxNs) v = (double)gMaxNs;
+            return v;
+        }
+        seen += (double)gCount[i];
+    }
+    return (double)gMaxNs;
+}
+
+static unsigned long nowNs(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (unsigned long)t.tv_sec * 1000000000ul + (unsigned long)t.tv_nsec;
+}
+
+/* "128K" -> 131072, "4M" -> 4194304, "65536" -> 65536 */
+static size_t parseSize(const char *s)
+{
+    char *end;
+    unsigned long v = strtoul(s, &end, 10);
+    if (*end == 'K' || *end == 'k') v <<= 10;
+    else if (*end == 'M' || *end == 'm') v <<= 20;
+    return (size_t)v;
+}
+
+static void usage(const char *exe)
+{
+    fprintf(stderr,
+            "Usage: %s [options] file\n"
+            "  -t#   threads [1-128] (default 1)\n"
+            "  -l#   loops [1-1000000] (default 1)\n"
+            "  -c#   chunk size, K/M suffix allowed (default 32K)\n"
+            "  -E#   searchForExternalRepcodes 0 auto, 1 enable, 2 disable (default auto)\n"
+            "  -L#   compression level [1-12] (default 1)\n"
+            "  -m#   0 software zstd, 1 GPU sequence producer (default 1)\n"
+            "  -H#   1 = announce each thread's buffer with QZSTD_hintSource (default 0)\n", exe);
+}
+
+static void *worker(void *arg)
+{
+    Worker *w = (Worker *)arg;
+    const Options *o = w->opt;
+    const size_t nChunks = (o->srcSize + o->chunk - 1) / o->chunk;
+    const size_t dstCap = ZSTD_compressBound(o->chunk) * nChunks;
+    unsigned char *dst = (unsigned char *)malloc(dstCap ? dstCap : 1);
+    unsigned char *back = (unsigned char *)malloc(o->srcSize ? o->srcSize : 1);
+    size_t *cSizes = (size_t *)calloc(nChunks ? nChunks : 1, sizeof(size_t));
+    ZSTD_CCtx *zc = ZSTD_createCCtx();
+    ZSTD_DCtx *zd = ZSTD_createDCtx();
+    void *state = NULL;
+    unsigned long local[NBUCKETS] = { 0 }, nS = 0, sumNs = 0, mn = ~0ul, mx = 0, compNs = 0, decNs = 0;
+    size_t total = 0;
+    int ok = dst && back && cSizes && zc && zd;
+
+    if (ok && o->mode == 1) {
+        QZSTD_startQatDevice(); /* once per thread, return value ignored: as reference :262 */
+        state = QZSTD_createSeqProdState();
+        ZSTD_registerSequenceProducer(zc, state, qatSequenceProducer);
+    } else if (ok) {
+        ZSTD_registerSequenceProducer(zc, NULL, NULL);
+    }
+    if (ok) {
+        const int e = o->extRep == 1 ? ZSTD_ps_enable : (o->extRep == 2 ? ZSTD_ps_disable : ZSTD_ps_auto);
+        if (ZSTD_isError(ZSTD_CCtx_setParameter(zc, ZSTD_c_searchForExternalRepcodes, e)) ||
+            ZSTD_isError(ZSTD_CCtx_setParameter(zc, ZSTD_c_compressionLevel, (int)o->level))) {
+            fprintf(stderr, "thread %u: cannot set parameters\n", w->id);
+            ok = 0;
+        }
+    }
+    pthread_barrier_wait(&gStart);
+    for (unsigned l = 0; ok && l < o->loops; l++) {
+        size_t off = 0, dpos = 0;
+        if (o->mode == 1 && o->hint) {
+            const unsigned long t0 = nowNs();
+            QZSTD_hintSource(state, o->src, o->srcSize, o->chunk, (int)o->level);
+            compNs += nowNs() - t0; /* the batched match-finding is part of the compression time */
+        }
+        for (size_t c = 0; c < nChunks; c++) {
+            const size_t n = o->srcSize - off < o->chunk ? o->srcSize - off : o->chunk;
+            const unsigned long t0 = nowNs();
+            const size_t r = ZSTD_compress2(zc, dst + dpos, dstCap - dpos, o->src + off, n);
+            const unsigned long dt = nowNs() - t0;
+            if (ZSTD_isError(r)) {
+                fprintf(stderr, "thread %u: Compress failed: %s\n", w->id, ZSTD_getErrorName(r));
+                ok = 0;
+                break;
+            }
+            compNs += dt;
+            sumNs += dt; nS++;
+            if (dt < mn) mn = dt;
+            if (dt > mx) mx = dt;
+            local[bucketOf(dt)]++;
+            cSizes[c] = r;
+            dpos += r;
+            off += n;
+        }
+        total = dpos;
+    }
+    if (ok) { /* verify: decompress every frame back to back, compare with the source */
+        size_t off = 0, dpos = 0;
+        for (size_t c = 0; c < nChunks && ok; c++) {
+            const size_t n = o->srcSize - off < o->chunk ? o->srcSize - off : o->chunk;
+            const size_t r = ZSTD_decompressDCtx(zd, back + off, n, dst + dpos, cSizes[c]);
+            if (ZSTD_isError(r) || r != n) ok = 0;
+            dpos += cSizes[c];
+            off += n;
+        }
+        if (ok && memcmp(back, o->src, o->srcSize) != 0) ok = 0;
+    }
+    pthread_barrier_wait(&gMid);
+    for (unsigned l = 0; ok && l < o->loops; l++) { /* timed decompression */
+        size_t off = 0, dpos = 0;
+        for (size_t c = 0; c < nChunks; c++) {
+            const size_t n = o->srcSize - off < o->chunk ? o->srcSize - off : o->chunk;
+            const unsigned long t0 = nowNs();
+            (void)ZSTD_decompressDCtx(zd, back + off, n, dst + dpos, cSizes[c]);
+            decNs += nowNs() - t0;
+            dpos += cSizes[c];
+            off += n;
+        }
+    }
+    w->pass = ok;
+    w->ratioPct = o->srcSize ? 100.0 * (double)total / (double)o->srcSize : 0.0;
+    w->compMBps = compNs ? (double)o->srcSize * o->loops / MB_BYTES / ((double)compNs / 1e9) : 0.0;
+    w->decompMBps = decNs ? (double)o->srcSize * o->loops / MB_BYTES / ((double)decNs / 1e9) : 0.0;
+    histAddBatch(local, nS, sumNs, mn, mx);
+    ZSTD_freeCCtx(zc);
+    ZSTD_freeDCtx(zd);
+    QZSTD_freeSeqProdState(state);
+    free(dst); free(back); free(cSizes);
+    return NULL;
+}
+
+int main(int argc, char **argv)
+{
+    Options o = { 1, 1, 1, 1, 0, 0, 32 * 1024, NULL, 0 };
+    const char *file = NULL;
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (a[0] != '-') { file = a; continue; }
+        switch (a[1]) {
+        case 't': o.threads = (unsigned)atoi(a + 2); break;
+        case 'l': o.loops = (unsigned)atoi(a + 2); break;
+        case 'c': o.chunk = parseSize(a + 2); break;
+        case 'E': o.extRep = (unsigned)atoi(a + 2); break;
+        case 'L': o.level = (unsigned)atoi(a + 2); break;
+        case 'm': o.mode = (unsigned)atoi(a + 2); break;
+        case 'H': o.hint = (unsigned)atoi(a + 2); break;
+        default: usage(argv[0]); return a[1] == 'h' || a[1] == 'H' ? 0 : 1;
+        }
+    }
+    if (!file || o.threads < 1 || o.threads > 128 || o.loops < 1 || o.loops > 1000000 || o.chunk < 1 ||
+        o.level < 1 || o.level > 12 || o.mode > 1 || o.extRep > 2) {
+        usage(argv[0]);
+        return 1;
+    }
+    FILE *f = fopen(file, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", file); return 1; }
+    fseek(f, 0, SEEK_END);
+    o.srcSize = (size_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    unsigned char *src = (unsigned char *)malloc(o.srcSize ? o.srcSize : 1);
+    if (!src || fread(src, 1, o.srcSize, f) != o.srcSize) { fprintf(stderr, "cannot read %s\n", file); return 1; }
+    fclose(f);
+    o.src = src;
+
+    histInit();
+    pthread_barrier_init(&gStart, NULL, o.threads);
+    pthread_barrier_init(&gMid, NULL, o.threads);
+    pthread_t *th = (pthread_t *)calloc(o.threads, sizeof(pthread_t));
+    Worker *ws = (Worker *)calloc(o.threads, sizeof(Worker));
+    const unsigned long w0 = nowNs();
+    for (unsigned t = 0; t < o.threads; t++) {
+        ws[t].opt = &o;
+        ws[t].id = t;
+        pthread_create(&th[t], NULL, worker, &ws[t]);
+    }
+    int allPass = 1;
+    double sumComp = 0, sumDec = 0;
+    for (unsigned t = 0; t < o.threads; t++) {
+        pthread_join(th[t], NULL);
+        fprintf(stderr, "Thread %u: Compression: %zu -> %.0f (%.2f%%), %.1f MB/s, Decompression: %.1f MB/s, %s\n", t,
+                o.srcSize, ws[t].ratioPct * (double)o.srcSize / 100.0, ws[t].ratioPct, ws[t].compMBps, ws[t].decompMBps,
+                ws[t].pass ? "PASS" : "FAIL");
+        allPass &= ws[t].pass;
+        sumComp += ws[t].compMBps;
+        sumDec += ws[t].decompMBps;
+    }
+    const double wall = (double)(nowNs() - w0) / 1e9;
+    fprintf(stderr, "%s level %u chunk %zu threads %u: aggregate compression %.1f MB/s (sum of per-thread rates), "
+                    "decompression %.1f MB/s, wall %.3f s\n", o.mode ? "GPU sequence producer" : "software zstd", o.level,
+            o.chunk, o.threads, sumComp, sumDec, wall);
+    if (gSamples)
+        fprintf(stderr, "Latency (us): P25 %.1f  P50 %.1f  P75 %.1f  P99 %.1f  avg %.1f  min %.1f  max %.1f  (%lu calls)\n",
+                percentileNs(25) / 1e3, percentileNs(50) / 1e3, percentileNs(75) / 1e3, percentileNs(99) / 1e3,
+                (double)gSumNs / (double)gSamples / 1e3, (double)gMinNs / 1e3, (double)gMaxNs / 1e3, gSamples);
+#ifdef DISPLAY_HISTOGRAM
+    for (int i = 0; i < NBUCKETS; i++)
+        if (gCount[i]) fprintf(stderr, "  < %.1f us: %lu\n", gBound[i] / 1e3, gCount[i]);
+#endif
+    if (o.mode == 1) QZSTD_stopQatDevice();
+    free(src); free(th); free(ws);
+    return allPass ? 0 : 1;
+}

@@ -118,3 +118,59 @@ def test_threads_each_with_own_cctx(started, zstd, oracle):
     [t.join() for t in ths]
     for t in range(len(data)):
         assert res[t] == compress_with(zstd, oracle.producer_addr, None, data[t], 131072, 1)
+
+
+def test_compress_stream2_chunked_frames(started, zstd):
+    """BASELINE config #5 shape at test scale: ZSTD_compressStream2, 4 MiB frames (ZSTD_e_end per
+    frame), level 3: src then points into libzstd's own buffer, blocks are still independent."""
+    import ctypes as C
+    L = zstd.lib
+
+    class InB(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    class OutB(C.Structure):
+        _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(OutB), C.POINTER(InB), C.c_int]
+    L.ZSTD_compressStream2.restype = C.c_size_t
+    data = K.mixed_entropy(5, 2 * (4 << 20) + 70000)
+    st = started.lib.QZSTD_createSeqProdState()
+    zc = zstd.cctx(3, producer=started.producer_addr, state=st, fallback=False, validate=True)
+    frames = []
+    for o in range(0, len(data), 4 << 20):
+        part = data[o:o + (4 << 20)]
+        src = C.create_string_buffer(part, len(part))
+        cap = L.ZSTD_compressBound(len(part))
+        dst = C.create_string_buffer(cap)
+        out = OutB(C.cast(dst, C.c_void_p), cap, 0)
+        pos = 0
+        while True:  # feed in 256 KiB pieces
+            n = min(256 << 10, len(part) - pos)
+            inp = InB(C.cast(C.byref(src, pos), C.c_void_p), n, 0)
+            last = pos + n >= len(part)
+            r = L.ZSTD_compressStream2(zc, C.byref(out), C.byref(inp), B.e_end if last else B.e_continue)
+            assert not zstd.is_error(r), zstd.err(r)
+            pos += inp.pos
+            if last and r == 0:
+                break
+        frames.append((dst.raw[:out.pos], len(part)))
+    zstd.free(zc)
+    started.lib.QZSTD_freeSeqProdState(st)
+    assert b"".join(zstd.decompress(f, n) for f, n in frames) == data
+
+
+def test_benchmark_tool_gpu_modes(started, tmp_path):
+    """the C benchmark (counterpart of reference test/benchmark.c) with the producer registered"""
+    import os
+    import subprocess
+    zpath = B.find_libzstd()
+    tdir = os.path.join(B.PKG_DIR, "test")
+    subprocess.check_call(["make", "-C", tdir, "benchmark", "ZSTDLIB=" + zpath], stdout=subprocess.DEVNULL)
+    f = tmp_path / "corpus.bin"
+    f.write_bytes(K.by_name("system", 24 * 131072))
+    exe = os.path.join(tdir, "benchmark")
+    for extra in ([], ["-H1"]):
+        out = subprocess.run([exe, "-m1", "-t3", "-l2", "-c128K", "-L1"] + extra + [str(f)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert out.stderr.count("PASS") == 3, out.stderr

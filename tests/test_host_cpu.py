@@ -244,3 +244,34 @@ def test_c_roundtrip_program_config1(plugin, tmp_path):
     assert "PASS" in out.stdout and "Source size: 131072" in out.stdout
     bad = subprocess.run([os.path.join(tdir, "test"), str(tmp_path / "missing")], capture_output=True, text=True)
     assert bad.returncode != 0
+
+
+def test_benchmark_tool_software_mode_and_no_device(plugin, tmp_path):
+    """counterpart of the reference's test/benchmark.c: -m0 (software zstd) works anywhere; -m1 without a
+    device fails because the tool, like the reference's (:261-267, :309-311), does not enable the fallback"""
+    zpath = B.find_libzstd()
+    tdir = os.path.join(B.PKG_DIR, "test")
+    subprocess.check_call(["make", "-C", tdir, "benchmark", "ZSTDLIB=" + zpath], stdout=subprocess.DEVNULL)
+    f = tmp_path / "corpus.bin"
+    f.write_bytes(K.mix(3, 5 * 65536 + 123))
+    exe = os.path.join(tdir, "benchmark")
+    out = subprocess.run([exe, "-m0", "-t2", "-l2", "-c64K", "-L3", "-E2", str(f)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stderr.count("PASS") == 2 and "Latency (us): P25" in out.stderr
+    assert "software zstd level 3 chunk 65536 threads 2" in out.stderr
+    if not has_gpu(plugin):
+        bad = subprocess.run([exe, "-m1", "-c64K", str(f)], capture_output=True, text=True)
+        assert bad.returncode != 0 and "Compress failed" in bad.stderr
+    assert subprocess.run([exe, "-t0", str(f)], capture_output=True).returncode != 0      # option validation
+    assert subprocess.run([exe, "-L13", str(f)], capture_output=True).returncode != 0
+
+
+def test_fuzz_adapter_exports_the_five_hooks():
+    """reference test/fuzzing/qatseqprodfuzzer.c:41-74: the symbols upstream zstd's fuzzers look for"""
+    fdir = os.path.join(B.PKG_DIR, "test", "fuzzing")
+    subprocess.check_call(["make", "-C", fdir], stdout=subprocess.DEVNULL)
+    syms = subprocess.check_output(["nm", os.path.join(fdir, "qatseqprodfuzzer.o")], text=True)
+    for s in ("FUZZ_seqProdSetup", "FUZZ_seqProdTearDown", "FUZZ_createSeqProdState", "FUZZ_freeSeqProdState",
+              "FUZZ_thirdPartySeqProd"):
+        assert re.search(r" T %s$" % s, syms, re.M), s
+    assert " U qatSequenceProducer" in syms and " U QZSTD_stopQatDevice" not in syms
