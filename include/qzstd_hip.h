@@ -45,7 +45,7 @@ typedef struct {
     uint32_t minMatch;  /* minimum match length for near offsets                           */
     uint32_t farLog1;   /* offset >= 1<<farLog1 needs minMatch+1                           */
     uint32_t farLog2;   /* offset >= 1<<farLog2 needs minMatch+2                           */
-    uint32_t lazy;      /* 0 greedy, 1 one-step lazy                                       */
+    uint32_t lazy;      /* 0 greedy; 1..3 = lazy, looks that many positions ahead            */
     uint32_t backExt;   /* max backward extension of a chosen match                        */
     uint32_t nearTab;   /* 1 = tile-local "earliest occurrence" probe                      */
     uint32_t window;    /* max offset, 0 = whole block                                     */

@@ -59,7 +59,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;
-    out->lazy = 1;
+    out->lazy = 3;
     out->backExt = 4;
     out->nearTab = 1;
     out->window = 0;
@@ -206,6 +206,18 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
         if (pf->lazy && p + 1 < nh && ((p + 1) & 63u) != 0 /* never across a 64-position window edge */ &&
             qzo_take(pf, &cand[p + 1]) && cand[p + 1].len > cand[p].len) {
             p++; /* one-step lazy: the next position has a strictly longer match */
+            continue;
+        }
+        /* deeper lazy steps: a match two positions on that is longer, or three on and longer by more
+         * than two bytes, is preferred (thresholds tuned on the bench corpus against software zstd) */
+        if (pf->lazy >= 2 && p + 2 < nh && (p & 63u) < 62u && qzo_take(pf, &cand[p + 2]) &&
+            cand[p + 2].len > cand[p].len) {
+            p++;
+            continue;
+        }
+        if (pf->lazy >= 3 && p + 3 < nh && (p & 63u) < 61u && qzo_take(pf, &cand[p + 3]) &&
+            cand[p + 3].len > cand[p].len + 2u) {
+            p++;
             continue;
         }
         L = cand[p].len;

@@ -106,18 +106,6 @@ __device__ __forceinline__ uint32_t head_len(const uint32_t *lds32, const uint32
     return L;
 }
 
-/* the rest of a candidate whose first 16 bytes matched: 32 bytes per LDS round trip up to cap */
-__device__ __forceinline__ uint32_t tail_len(const uint32_t *lds32, uint32_t p, uint32_t q, uint32_t cap)
-{
-    uint32_t L = 16u;
-    while (L < cap) {
-        const uint32_t l = chunk_len(lds32, p + L, q + L);
-        L += l;
-        if (l < 32u) break;
-    }
-    return umin(L, cap);
-}
-
 __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint32_t off)
 {
     return pf.minMatch + ((off >> pf.farLog1) ? 1u : 0u) + ((off >> pf.farLog2) ? 1u : 0u);
@@ -406,19 +394,28 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         const bool valid = it < nTiles && p < nh;
 
         /* ================= interval 1 ================= */
+        /* the position's own first 20 bytes (5 aligned dwords): issued first so that their LDS latency
+         * hides behind the emission below; used by the hash now and by the candidate compare later */
+        uint32_t own[5];
+        {
+            const uint32_t pd = (valid ? p : 0u) >> 2;
+#pragma unroll
+            for (int i = 0; i < 5; i++) own[i] = lds32[pd + i];
+        }
         if (it >= 2u && !(args.dbg & 8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
             emit_window(pf, lds32, srec + ((it & 1u) * kWin + wave) * kSrecWords, offB, lenB, t0 - 2u * kTile + 64u * wave,
                         lane, out, blk.seqCap);
+        uint32_t slot = 0, nslot = 0;
         if (valid) { /* phase A(it) */
-            const uint32_t d = p >> 2, s = p & 3u;
-            const uint32_t w0 = lds32[d], w1 = lds32[d + 1];
-            const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, s);
+            const uint32_t s = p & 3u;
+            const uint32_t v = __builtin_amdgcn_alignbyte(own[1], own[0], s);
             uint32_t hi = 0;
-            if (pf.hashBytes > 4) hi = __builtin_amdgcn_alignbyte(lds32[d + 2], w1, s) & hiMask;
+            if (pf.hashBytes > 4) hi = __builtin_amdgcn_alignbyte(own[2], own[1], s) & hiMask;
             mix = (v * kPrime1) ^ (hi * kPrime2);
-            old = tbl[__umulhi(mix, pf.tableSize)];
-            if (pf.nearTab)
-                atomicMin(&nearTab[mix >> nearShift], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
+            slot = __umulhi(mix, pf.tableSize);
+            nslot = mix >> nearShift;
+            old = tbl[slot];
+            if (pf.nearTab) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
         }
         QZ_LAP(dI1)
         __syncthreads(); /* B1 */
@@ -429,40 +426,46 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         uint32_t cl = 0, off = 0; /* capped candidate length, offset */
         if (valid) {
             const uint32_t tag = (mix >> 3) & kTagMask;
-            const uint32_t en = pf.nearTab ? nearTab[mix >> nearShift] : 0xFFFFFFFFu;
-            atomicMax(&tbl[__umulhi(mix, pf.tableSize)], ((p + 1u) << kTagBits) | tag);
+            const uint32_t en = pf.nearTab ? nearTab[nslot] : 0xFFFFFFFFu;
+            atomicMax(&tbl[slot], ((p + 1u) << kTagBits) | tag);
             const uint32_t cap = umin(pf.capLen, n - p);
-            /* candidate 1: newest position of earlier tiles; candidate 2: earliest of this tile */
+            /* candidate 1: newest position of earlier tiles (known since interval 1: its bytes are fetched
+             * while the near-table read is still in flight); candidate 2: earliest of this tile */
             uint32_t q1 = kNone, q2 = kNone;
             if (old != 0u && (old & kTagMask) == tag) {
                 const uint32_t q = (old >> kTagBits) - 1u;
                 if (pf.window == 0u || p - q <= pf.window) q1 = q;
             }
+            if (args.dbg & 2u) q1 = kNone;
+            uint32_t l1 = 0, l2 = 0;
+            if (q1 != kNone) l1 = head_len(lds32, own, p & 3u, q1);
             if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
-                if (q < p) q2 = q;
+                if (q < p && !(args.dbg & 2u)) q2 = q;
             }
-            if ((q1 != kNone || q2 != kNone) && !(args.dbg & 2u)) {
-                uint32_t own[5];
-                const uint32_t pd = p >> 2;
-#pragma unroll
-                for (int i = 0; i < 5; i++) own[i] = lds32[pd + i];
-                /* 16 bytes of both candidates first: most end there; only survivors pay for more */
-                uint32_t l1 = q1 != kNone ? head_len(lds32, own, p & 3u, q1) : 0u;
-                uint32_t l2 = q2 != kNone ? head_len(lds32, own, p & 3u, q2) : 0u;
-                if (l1 == 16u) l1 = tail_len(lds32, p, q1, cap);
-                if (l2 == 16u) l2 = tail_len(lds32, p, q2, cap);
-                l1 = umin(l1, cap); l2 = umin(l2, cap);
-                if (l1 >= 4u) { cl = l1; off = p - q1; }
-                if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }
+            if (q2 != kNone) l2 = head_len(lds32, own, p & 3u, q2);
+            /* survivors of the 16-byte head: 32 more bytes per step, both candidates in one loop */
+            bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u;
+            while (need1 || need2) {
+                const bool first = need1;
+                const uint32_t q = first ? q1 : q2, L = first ? l1 : l2;
+                const uint32_t l = chunk_len(lds32, p + L, q + L);
+                const bool more = l == 32u && L + 32u < cap;
+                if (first) { l1 = L + l; need1 = more; } else { l2 = L + l; need2 = more; }
             }
+            l1 = umin(l1, cap); l2 = umin(l2, cap);
+            if (l1 >= 4u) { cl = l1; off = p - q1; }
+            if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }
         }
         if (it < nTiles && !(args.dbg & 4u)) {
-            /* start flags: the lazy rule compares capped lengths and never looks across the window edge */
-            const uint32_t clN = __shfl_down(cl, 1), offN = __shfl_down(off, 1);
+            /* start flags: the lazy rules compare capped lengths and never look across the window edge */
             const bool take = cl != 0u && cl >= min_len(pf, off);
-            const bool take1 = clN != 0u && clN >= min_len(pf, offN);
-            const bool start = take && !(pf.lazy && lane != 63u && take1 && clN > cl);
+            const uint32_t tl = take ? cl : 0u; /* length if this position could start a match, else 0 */
+            const uint32_t tl1 = __shfl_down(tl, 1), tl2 = __shfl_down(tl, 2), tl3 = __shfl_down(tl, 3);
+            const bool defer1 = pf.lazy >= 1u && lane < 63u && tl1 > cl;      /* next position: strictly longer */
+            const bool defer2 = pf.lazy >= 2u && lane < 62u && tl2 > cl;      /* two on: strictly longer */
+            const bool defer3 = pf.lazy >= 3u && lane < 61u && tl3 > cl + 2u; /* three on: longer by more than two */
+            const bool start = take && !defer1 && !defer2 && !defer3;
             const u64 startMask = __ballot(start);
             /* what the parse wave needs, one word per position (see parse_tile) */
             const u64 here = startMask >> lane;

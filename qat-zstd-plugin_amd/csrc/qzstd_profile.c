@@ -32,7 +32,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;
-    out->lazy = 1;
+    out->lazy = 3;
     out->backExt = 4;
     out->nearTab = 1;
     out->window = 0;
