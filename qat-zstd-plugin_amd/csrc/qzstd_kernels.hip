@@ -55,10 +55,19 @@ struct LaunchArgs {
     uint4 *seqs; /* ZSTD_Sequence = 4 x u32 */
     uint32_t *nseq;
     qzstd_hip_profile_t prof[3]; /* by block size class: >64 KiB, >32 KiB, <=32 KiB */
-    uint32_t dbg; /* profiling ablation switches (QZSTD_HIP_ABLATE); 0 in production */
+#ifdef QZ_DEBUG_DUMP
+    uint32_t dbg; /* profiling build only: ablation switches (QZSTD_HIP_ABLATE) */
+#endif
 };
 
 typedef unsigned long long u64;
+
+/* profiling build (-DQZ_DEBUG_DUMP): phases can be switched off and per-wave cycle counts are dumped */
+#ifdef QZ_DEBUG_DUMP
+#define QZ_ABLATED(bit) (args.dbg & (bit))
+#else
+#define QZ_ABLATED(bit) false
+#endif
 
 /* v_readlane_b32 with an unsigned result (the builtin returns int: a set bit 31 would sign-extend) */
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
-        if (!(args.dbg & 32u)) __builtin_amdgcn_s_setprio(3); /* the serial critical path: win issue arbitration on its SIMD */
+        if (!QZ_ABLATED(32u)) __builtin_amdgcn_s_setprio(3); /* the serial critical path: win issue arbitration on its SIMD */
         ParseState st = { 0u, 0u, 0u };
         constexpr uint32_t kSplit = 2; /* windows parsed in interval 1 (the short one), the rest in interval 2 */
 #ifdef QZ_DEBUG_DUMP
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #define QZ_PLAP(acc)
 #endif
         for (uint32_t it = 0; it < nTiles + 2u; it++) {
-            const bool work = it >= 1u && it - 1u < nTiles && !(args.dbg & 1u);
+            const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
             const uint32_t k = it - 1u;
             if (work)
                 parse_tile<0, kSplit>(pf, lds32, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog,
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #pragma unroll
             for (int i = 0; i < 5; i++) own[i] = lds32[pd + i];
         }
-        if (it >= 2u && !(args.dbg & 8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
+        if (it >= 2u && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
             emit_window(pf, lds32, srec + ((it & 1u) * kWin + wave) * kSrecWords, offB, lenB, t0 - 2u * kTile + 64u * wave,
                         lane, out, blk.seqCap);
         uint32_t slot = 0, nslot = 0;
@@ -436,12 +445,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 const uint32_t q = (old >> kTagBits) - 1u;
                 if (pf.window == 0u || p - q <= pf.window) q1 = q;
             }
-            if (args.dbg & 2u) q1 = kNone;
+            if (QZ_ABLATED(2u)) q1 = kNone;
             uint32_t l1 = 0, l2 = 0;
             if (q1 != kNone) l1 = head_len(lds32, own, p & 3u, q1);
             if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
-                if (q < p && !(args.dbg & 2u)) q2 = q;
+                if (q < p && !QZ_ABLATED(2u)) q2 = q;
             }
             if (q2 != kNone) l2 = head_len(lds32, own, p & 3u, q2);
             /* survivors of the 16-byte head: 32 more bytes per step, both candidates in one loop */
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             if (l1 >= 4u) { cl = l1; off = p - q1; }
             if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }
         }
-        if (it < nTiles && !(args.dbg & 4u)) {
+        if (it < nTiles && !QZ_ABLATED(4u)) {
             /* start flags: the lazy rules compare capped lengths and never look across the window edge */
             const bool take = cl != 0u && cl >= min_len(pf, off);
             const uint32_t tl = take ? cl : 0u; /* length if this position could start a match, else 0 */
@@ -641,7 +650,9 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     a.blocks = d_blocks;
     a.seqs = static_cast<uint4 *>(d_seqs);
     a.nseq = d_nseq;
+#ifdef QZ_DEBUG_DUMP
     { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
+#endif
     hipLaunchKernelGGL(qzstd_find_sequences_kernel, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;
