@@ -53,7 +53,8 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    out->tableSize = blockSize > (64u << 10) ? 6400u : (blockSize > (32u << 10) ? 16384u : 8192u);
+    (void)blockSize; /* one profile for every block size (the kernel's LDS footprint is fixed) */
+    out->tableSize = 6400u;
     out->tileLog = 9;
     out->capLen = 64;
     out->minMatch = 4;

@@ -48,6 +48,15 @@ constexpr uint32_t kTagMask = (1u << kTagBits) - 1u;
 constexpr uint32_t kPrime1 = 2654435761u;
 constexpr uint32_t kPrime2 = 0x85EBCA77u;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+/* Only a RING of the most recent block bytes lives in LDS (so that two workgroups fit on a CU):
+ * position x sits at ring offset x mod kRing; the first kMirror bytes are mirrored behind the ring
+ * so that a 36-byte read never has to wrap.  At iteration `it` the ring holds
+ * [it*512 + 512 + kLook - kRing, it*512 + 512 + kLook); sources farther back than kNear bytes
+ * ("far" candidates, a few %) are compared straight from HBM/L2 instead. */
+constexpr uint32_t kRing = 49152u;
+constexpr uint32_t kMirror = 128u;
+constexpr uint32_t kLook = 4608u;  /* bytes staged ahead of the current tile (covers the bounded extension) */
+constexpr uint32_t kNear = 40960u; /* kRing - kLook - 3 tiles of pipeline lag - slack */
 
 struct LaunchArgs {
     const uint8_t *src;
@@ -75,21 +84,50 @@ __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__bui
 __device__ __forceinline__ u64 below(uint32_t c) { return c >= 64u ? ~0ull : ((1ull << c) - 1ull); }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-/* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte_b32 */
-__device__ __forceinline__ uint32_t lds_rd32u(const uint32_t *lds32, uint32_t a)
+/* where the block's bytes can be read from: the LDS ring (recent bytes) or HBM (anything) */
+struct Src {
+    const uint32_t *ring; /* LDS, kRing + kMirror bytes */
+    const uint32_t *g;    /* the block in HBM; 16-byte aligned, so aligned dword loads work */
+};
+
+/* dword index inside the ring of byte position a (a < 3 * kRing) */
+__device__ __forceinline__ uint32_t ring_dw(uint32_t a)
 {
-    const uint32_t d = a >> 2;
-    return __builtin_amdgcn_alignbyte(lds32[d + 1], lds32[d], a & 3u);
+    const uint32_t m = umin(a, a - kRing);
+    return umin(m, m - kRing) >> 2;
 }
 
-/* first mismatching byte (0..32) of the 32 bytes at p and at q: 9 aligned dwords per side are
- * fetched with independent ds_reads (ONE LDS round trip), then compared in registers */
-__device__ __forceinline__ uint32_t chunk_len(const uint32_t *lds32, uint32_t p, uint32_t q)
+/* N consecutive aligned dwords covering byte position a: from the ring, or from HBM when `far` */
+template <int N>
+__device__ __forceinline__ void load_dw(const Src &s, uint32_t a, bool far, uint32_t (&D)[N])
 {
-    const uint32_t pd = p >> 2, qd = q >> 2, ps = p & 3u, qs = q & 3u;
-    uint32_t P[9], Q[9];
+    if (far) {
+        const uint32_t d = a >> 2;
 #pragma unroll
-    for (int i = 0; i < 9; i++) { P[i] = lds32[pd + i]; Q[i] = lds32[qd + i]; }
+        for (int i = 0; i < N; i++) D[i] = s.g[d + i];
+    } else {
+        const uint32_t d = ring_dw(a);
+#pragma unroll
+        for (int i = 0; i < N; i++) D[i] = s.ring[d + i];
+    }
+}
+
+/* 4 bytes at an arbitrary position: two aligned dwords + v_alignbyte_b32 */
+__device__ __forceinline__ uint32_t rd32u(const Src &s, uint32_t a, bool far)
+{
+    uint32_t D[2];
+    load_dw<2>(s, a, far, D);
+    return __builtin_amdgcn_alignbyte(D[1], D[0], a & 3u);
+}
+
+/* first mismatching byte (0..32) of the 32 bytes at p (ring) and at q (ring or HBM): 9 aligned
+ * dwords per side are fetched with independent loads (ONE round trip), then compared in registers */
+__device__ __forceinline__ uint32_t chunk_len(const Src &s, uint32_t p, uint32_t q, bool far)
+{
+    const uint32_t ps = p & 3u, qs = q & 3u;
+    uint32_t P[9], Q[9];
+    load_dw<9>(s, p, false, P);
+    load_dw<9>(s, q, far, Q);
     uint32_t L = 32u;
 #pragma unroll
     for (int i = 7; i >= 0; i--) {
@@ -100,12 +138,11 @@ __device__ __forceinline__ uint32_t chunk_len(const uint32_t *lds32, uint32_t p,
 }
 
 /* first mismatching byte (0..16) of the 16 bytes at p (5 aligned dwords already in `own`) and at q */
-__device__ __forceinline__ uint32_t head_len(const uint32_t *lds32, const uint32_t (&own)[5], uint32_t ps, uint32_t q)
+__device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&own)[5], uint32_t ps, uint32_t q, bool far)
 {
-    const uint32_t qd = q >> 2, qs = q & 3u;
+    const uint32_t qs = q & 3u;
     uint32_t Q[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) Q[i] = lds32[qd + i];
+    load_dw<5>(s, q, far, Q);
     uint32_t L = 16u;
 #pragma unroll
     for (int i = 3; i >= 0; i--) {
@@ -122,17 +159,18 @@ __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint3
 
 /* cooperative forward extension of a match that hit the candidate cap: 64 lanes x 16 bytes
  * (1 KiB) per step, never past `lim` */
-__device__ __forceinline__ uint32_t extend_match(const uint32_t *lds32, uint32_t p, uint32_t off, uint32_t L,
-                                                 uint32_t lim, uint32_t lane)
+__device__ __forceinline__ uint32_t extend_match(const Src &s, uint32_t p, uint32_t off, uint32_t L, uint32_t lim,
+                                                 uint32_t lane)
 {
+    const bool far = off > kNear; /* uniform: the whole match has one offset */
     for (;;) {
         const uint32_t a = p + L + 16u * lane;
         uint32_t ok = 0; /* bytes of this lane's 16 that match and lie below lim */
         if (a < lim) {
-            const uint32_t b = a - off, ad = a >> 2, bd = b >> 2, as = a & 3u, bs = b & 3u;
+            const uint32_t b = a - off, as = a & 3u, bs = b & 3u;
             uint32_t A[5], B[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) { A[i] = lds32[ad + i]; B[i] = lds32[bd + i]; }
+            load_dw<5>(s, a, false, A);
+            load_dw<5>(s, b, far, B);
             ok = 16u;
 #pragma unroll
             for (int i = 3; i >= 0; i--) {
@@ -185,7 +223,7 @@ __device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val, uint32_t 
 }
 
 template <uint32_t W_BEGIN, uint32_t W_END>
-__device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t *pv,
+__device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *pv,
                                            uint32_t *srecOut, uint32_t base, uint32_t n, uint32_t lane, ParseState &st)
 {
     uint32_t word[kWin];
@@ -226,7 +264,7 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
                     /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
                     const uint32_t pj = w0 + j;
                     const uint32_t lim = umin(n, ((pj >> pf.extLog) + 2u) << pf.extLog);
-                    const uint32_t xl = extend_match(lds32, pj, payload, pf.capLen, lim, lane);
+                    const uint32_t xl = extend_match(src, pj, payload, pf.capLen, lim, lane);
                     if (!ext0) ext0 = (j << 24) | xl; else ext1 = (j << 24) | xl;
                     c = e = j + xl;
                     if (c >= 64u) break;
@@ -255,7 +293,7 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
 }
 
 /* emission of one window's chosen matches by the wave that owns the window */
-__device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const uint32_t *lds32, const uint32_t *srec,
+__device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *srec,
                                             uint32_t off, uint32_t len, uint32_t w0, uint32_t lane, uint4 *out,
                                             uint32_t seqCap)
 {
@@ -279,8 +317,9 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
         uint32_t b = 0;
         if (maxb) {
             /* the 4 bytes before p and before q, top byte = nearest; count equal bytes from the top */
-            const uint32_t pb = p >= 4u ? lds_rd32u(lds32, p - 4u) : lds32[0] << (8u * (4u - p));
-            const uint32_t qb = q >= 4u ? lds_rd32u(lds32, q - 4u) : lds32[0] << (8u * (4u - q));
+            const bool far = off > kNear;
+            const uint32_t pb = p >= 4u ? rd32u(src, p - 4u, false) : rd32u(src, 0u, false) << (8u * (4u - p));
+            const uint32_t qb = q >= 4u ? rd32u(src, q - 4u, far) : rd32u(src, 0u, far) << (8u * (4u - q));
             const uint32_t x = pb ^ qb;
             b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
         }
@@ -315,23 +354,28 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     const uint32_t nh = n >= pf.hashBytes ? n - pf.hashBytes + 1u : 0u; /* hashable positions */
     const uint32_t nTiles = (nh + kTile - 1u) >> kTileLog;
 
-    /* ---- LDS layout for THIS block ---- */
-    const uint32_t region = ((n + 15u) & ~15u) + 16u;
-    uint8_t *lds8 = smem;
-    uint32_t *lds32 = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + region);
+    /* ---- LDS layout (81 600 B: two workgroups per CU) ---- */
+    uint32_t *ring32 = reinterpret_cast<uint32_t *>(smem);
+    uint4 *ring128 = reinterpret_cast<uint4 *>(smem);
+    uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + kRing + kMirror);
     uint32_t *nearTab = tbl + pf.tableSize;
     uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
     uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kTile]    per-position parse words          */
+    const uint8_t *gsrc = args.src + blk.srcOff;
+    const uint4 *g128 = reinterpret_cast<const uint4 *>(gsrc);
+    Src src;
+    src.ring = ring32;
+    src.g = reinterpret_cast<const uint32_t *>(gsrc);
+    const uint32_t nPad = (n + 15u) & ~15u; /* the caller keeps the buffer readable up to here */
 
-    /* ---- stage the block: HBM -> LDS, 16 B per lane, coalesced ---- */
+    /* ---- prefill the ring with the first kTile + kLook bytes (16 B per lane, coalesced), clear the tables ---- */
     {
-        const uint8_t *g = args.src + blk.srcOff;
-        const uint32_t nvec = n >> 4;
-        const uint4 *g4 = reinterpret_cast<const uint4 *>(g);
-        uint4 *l4 = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = tid; i < nvec; i += kThreads) l4[i] = g4[i];
-        for (uint32_t i = (nvec << 4) + tid; i < region; i += kThreads) lds8[i] = i < n ? g[i] : (uint8_t)0;
+        const uint32_t first = umin(nPad, kTile + kLook);
+        for (uint32_t o = tid * 16u; o < kTile + kLook; o += kThreads * 16u) {
+            const uint4 v = o < first ? g128[o >> 4] : make_uint4(0u, 0u, 0u, 0u);
+            ring128[o >> 4] = v;
+            if (o < kMirror) ring128[(kRing + o) >> 4] = v;
+        }
         for (uint32_t i = tid; i < pf.tableSize; i += kThreads) tbl[i] = 0u;
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
         for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kTile; i += kThreads) srec[i] = 0u; /* srec, pv */
@@ -355,13 +399,13 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
             const uint32_t k = it - 1u;
             if (work)
-                parse_tile<0, kSplit>(pf, lds32, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog,
+                parse_tile<0, kSplit>(pf, src, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog,
                                       n, lane, st);
             QZ_PLAP(pI1)
             __syncthreads(); /* B1 */
             QZ_PLAP(pW1)
             if (work)
-                parse_tile<kSplit, kWin>(pf, lds32, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords,
+                parse_tile<kSplit, kWin>(pf, src, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords,
                                          k << kTileLog, n, lane, st);
             QZ_PLAP(pI2)
             __syncthreads(); /* B2 */
@@ -406,13 +450,16 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         /* the position's own first 20 bytes (5 aligned dwords): issued first so that their LDS latency
          * hides behind the emission below; used by the hash now and by the candidate compare later */
         uint32_t own[5];
-        {
-            const uint32_t pd = (valid ? p : 0u) >> 2;
-#pragma unroll
-            for (int i = 0; i < 5; i++) own[i] = lds32[pd + i];
-        }
+        load_dw<5>(src, valid ? p : 0u, false, own);
+        /* refill: the 512 bytes that enter the look-ahead window this iteration (HBM -> registers now,
+         * registers -> ring after the barrier; the ring slots they replace left everyone's reach
+         * three tiles ago) */
+        uint4 fresh = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t fpos = t0 + kLook + tid * 16u; /* iteration it stages [t0 + kLook, t0 + kLook + kTile) */
+        const bool refill = it >= 1u && tid < kTile / 16u && fpos < nPad;
+        if (refill) fresh = g128[fpos >> 4];
         if (it >= 2u && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
-            emit_window(pf, lds32, srec + ((it & 1u) * kWin + wave) * kSrecWords, offB, lenB, t0 - 2u * kTile + 64u * wave,
+            emit_window(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, offB, lenB, t0 - 2u * kTile + 64u * wave,
                         lane, out, blk.seqCap);
         uint32_t slot = 0, nslot = 0;
         if (valid) { /* phase A(it) */
@@ -431,6 +478,11 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         QZ_LAP(dW1)
 
         /* ================= interval 2 ================= */
+        if (refill) {
+            const uint32_t o = ring_dw(fpos) << 2;
+            ring128[o >> 4] = fresh;
+            if (o < kMirror) ring128[(kRing + o) >> 4] = fresh;
+        }
         offB = offA; lenB = lenA;
         uint32_t cl = 0, off = 0; /* capped candidate length, offset */
         if (valid) {
@@ -447,18 +499,19 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             }
             if (QZ_ABLATED(2u)) q1 = kNone;
             uint32_t l1 = 0, l2 = 0;
-            if (q1 != kNone) l1 = head_len(lds32, own, p & 3u, q1);
+            const bool far1 = q1 != kNone && p - q1 > kNear;
+            if (q1 != kNone) l1 = head_len(src, own, p & 3u, q1, far1);
             if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
                 if (q < p && !QZ_ABLATED(2u)) q2 = q;
             }
-            if (q2 != kNone) l2 = head_len(lds32, own, p & 3u, q2);
+            if (q2 != kNone) l2 = head_len(src, own, p & 3u, q2, false); /* same tile: always near */
             /* survivors of the 16-byte head: 32 more bytes per step, both candidates in one loop */
             bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u;
             while (need1 || need2) {
                 const bool first = need1;
                 const uint32_t q = first ? q1 : q2, L = first ? l1 : l2;
-                const uint32_t l = chunk_len(lds32, p + L, q + L);
+                const uint32_t l = chunk_len(src, p + L, q + L, first && far1);
                 const bool more = l == 32u && L + 32u < cap;
                 if (first) { l1 = L + l; need1 = more; } else { l2 = L + l; need2 = more; }
             }
