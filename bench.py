@@ -234,7 +234,7 @@ def main():
                          "input_read_frac_of_peak": round(size / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "sequences_per_block": round(seq_total / max(nb - n_err, 1), 1), "error_blocks": n_err,
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:  # CPU legs on rank 0 at N=1 only (bench contract)
             ncpu = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_oracle_leg(shard, block, level, a.cpu_seconds)
             # north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape,
