@@ -51,6 +51,8 @@ typedef struct {
     uint32_t window;    /* max offset, 0 = whole block                                     */
     uint32_t hashBytes; /* bytes hashed per position (4..8)                                */
     uint32_t extLog;    /* a match never extends past the end of the next 1<<extLog cell       */
+    uint32_t longSize;  /* entries of the second table keyed by 8 bytes (0 = none)               */
+    uint32_t reserved;
 } qzstd_hip_profile_t;
 
 /* One work item = one <=128 KiB block, parsed with no history

@@ -53,8 +53,11 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    (void)blockSize; /* one profile for every block size (the kernel's LDS footprint is fixed) */
-    out->tableSize = 6400u;
+    (void)blockSize; /* the profile does not depend on the block size (the kernel's LDS footprint is fixed) */
+    /* levels 1-2: 6400 + no long table = 81.6 KB of LDS, two blocks per CU; levels >= 3: a bigger
+     * table plus a second table keyed by 8 bytes (the double-fast idea of zstd's levels 3-4), one block per CU */
+    out->tableSize = level >= 3 ? 16000u : 6400u;
+    out->longSize = level >= 3 ? 8192u : 0u;
     out->tileLog = 9;
     out->capLen = 64;
     out->minMatch = 4;
@@ -107,14 +110,22 @@ typedef struct {
     uint32_t off;
 } qzo_cand_t;
 
-static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t n,
-                           qzo_cand_t *cand, uint32_t *tbl, uint32_t *near)
+/* 32-bit mix of the 8 bytes at a position (the key of the optional "long" table) */
+static inline uint32_t qzo_mix8(const uint8_t *p)
 {
+    return (qzo_rd32(p) * QZO_HASH_PRIME) ^ (qzo_rd32(p + 4) * QZO_HASH_PRIME2);
+}
+
+static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t n,
+                           qzo_cand_t *cand, uint32_t *tbl, uint32_t *near, uint32_t *tblL)
+{
+    const uint32_t nl = pf->longSize && n >= 8u ? n - 7u : 0u; /* positions that have 8 bytes for the long table */
     const uint32_t nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0; /* hashable positions */
     const uint32_t T = 1u << pf->tileLog;
     uint32_t t0, p;
 
     memset(tbl, 0, sizeof(uint32_t) * pf->tableSize);
+    if (pf->longSize) memset(tblL, 0, sizeof(uint32_t) * pf->longSize);
     for (p = 0; p < n; p++) cand[p].len = 0, cand[p].off = 0;
 
     for (t0 = 0; t0 < nh; t0 += T) {
@@ -144,6 +155,18 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
                     bestOff = off;
                 }
             }
+            /* probe 3 (levels >= 3): newest position of EARLIER tiles whose first 8 bytes hash alike */
+            if (p < nl) {
+                const uint32_t m8 = qzo_mix8(src + p);
+                const uint32_t eL = tblL[qzo_slot(m8, pf->longSize)];
+                if (eL != 0 && (eL & QZO_TAG_MASK) == qzo_tag(m8)) {
+                    const uint32_t q = (eL >> QZO_TAG_BITS) - 1u;
+                    if (qzo_rd32(src + q) == v) {
+                        const uint32_t l = qzo_prefix_len(src, q, p, cap);
+                        if (l > bestLen) { bestLen = l; bestOff = p - q; } /* must be strictly longer */
+                    }
+                }
+            }
             /* probe 2: earliest position of THIS tile in the near slot, if it lies before p */
             if (pf->nearTab) {
                 const uint32_t en = near[qzo_near_slot(m, pf->tileLog)];
@@ -163,6 +186,10 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
         for (p = t0; p < t1; p++) {
             const uint32_t m = qzo_mix(src + p, pf->hashBytes);
             tbl[qzo_slot(m, pf->tableSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m);
+            if (p < nl) {
+                const uint32_t m8 = qzo_mix8(src + p);
+                tblL[qzo_slot(m8, pf->longSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m8);
+            }
         }
     }
 }
@@ -184,22 +211,23 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
     const uint32_t n = (uint32_t)srcSize;
     uint32_t nh;
     qzo_cand_t *cand;
-    uint32_t *tbl, *near;
+    uint32_t *tbl, *near, *tblL;
     uint32_t p = 0, anchor = 0;
     size_t ns = 0;
 
     if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
-        pf->capLen < pf->minMatch + 2 || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17)
+        pf->capLen < pf->minMatch + 2 || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
         return QZO_ERROR;
     nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
 
     cand = (qzo_cand_t *)malloc(sizeof(qzo_cand_t) * (n + 1));
     tbl = (uint32_t *)malloc(sizeof(uint32_t) * pf->tableSize);
     near = (uint32_t *)malloc(sizeof(uint32_t) << pf->tileLog);
-    if (!cand || !tbl || !near) { free(cand); free(tbl); free(near); return QZO_ERROR; }
+    tblL = (uint32_t *)malloc(sizeof(uint32_t) * (pf->longSize ? pf->longSize : 1u));
+    if (!cand || !tbl || !near || !tblL) { free(cand); free(tbl); free(near); free(tblL); return QZO_ERROR; }
 
-    qzo_candidates(pf, src, n, cand, tbl, near);
+    qzo_candidates(pf, src, n, cand, tbl, near, tblL);
 
     while (p < nh) {
         uint32_t L, off, q, b = 0;
@@ -249,7 +277,7 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
     ns++;
     if (ns >= cap - 1) ns = QZO_ERROR; /* src/qatseqprod.c:1318 */
 done:
-    free(cand); free(tbl); free(near);
+    free(cand); free(tbl); free(near); free(tblL);
     return ns;
 }
 

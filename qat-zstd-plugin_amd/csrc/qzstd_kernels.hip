@@ -339,6 +339,7 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
  *                                parse wave: greedy chain over tile it-1
  *   barrier
  */
+template <bool HAS_LONG>
 __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -358,7 +359,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     uint32_t *ring32 = reinterpret_cast<uint32_t *>(smem);
     uint4 *ring128 = reinterpret_cast<uint4 *>(smem);
     uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + kRing + kMirror);
-    uint32_t *nearTab = tbl + pf.tableSize;
+    uint32_t *tblL = tbl + pf.tableSize;               /* [longSize]    8-byte-key table (levels >= 3)    */
+    uint32_t *nearTab = tblL + pf.longSize;
     uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
     uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kTile]    per-position parse words          */
     const uint8_t *gsrc = args.src + blk.srcOff;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             ring128[o >> 4] = v;
             if (o < kMirror) ring128[(kRing + o) >> 4] = v;
         }
-        for (uint32_t i = tid; i < pf.tableSize; i += kThreads) tbl[i] = 0u;
+        for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
         for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kTile; i += kThreads) srec[i] = 0u; /* srec, pv */
     }
@@ -461,7 +463,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         if (it >= 2u && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
             emit_window(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, offB, lenB, t0 - 2u * kTile + 64u * wave,
                         lane, out, blk.seqCap);
-        uint32_t slot = 0, nslot = 0;
+        uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
+        const bool validL = HAS_LONG && valid && p + 8u <= n;
         if (valid) { /* phase A(it) */
             const uint32_t s = p & 3u;
             const uint32_t v = __builtin_amdgcn_alignbyte(own[1], own[0], s);
@@ -472,6 +475,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             nslot = mix >> nearShift;
             old = tbl[slot];
             if (pf.nearTab) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
+            if (validL) { /* second table, keyed by the first 8 bytes */
+                const uint32_t m8 = (v * kPrime1) ^ (__builtin_amdgcn_alignbyte(own[2], own[1], s) * kPrime2);
+                slotL = __umulhi(m8, pf.longSize);
+                tagL = (m8 >> 3) & kTagMask;
+                oldL = tblL[slotL];
+            }
         }
         QZ_LAP(dI1)
         __syncthreads(); /* B1 */
@@ -489,6 +498,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             const uint32_t tag = (mix >> 3) & kTagMask;
             const uint32_t en = pf.nearTab ? nearTab[nslot] : 0xFFFFFFFFu;
             atomicMax(&tbl[slot], ((p + 1u) << kTagBits) | tag);
+            if (validL) atomicMax(&tblL[slotL], ((p + 1u) << kTagBits) | tagL);
             const uint32_t cap = umin(pf.capLen, n - p);
             /* candidate 1: newest position of earlier tiles (known since interval 1: its bytes are fetched
              * while the near-table read is still in flight); candidate 2: earliest of this tile */
@@ -498,26 +508,35 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 if (pf.window == 0u || p - q <= pf.window) q1 = q;
             }
             if (QZ_ABLATED(2u)) q1 = kNone;
-            uint32_t l1 = 0, l2 = 0;
+            uint32_t l1 = 0, l2 = 0, l3 = 0;
             const bool far1 = q1 != kNone && p - q1 > kNear;
             if (q1 != kNone) l1 = head_len(src, own, p & 3u, q1, far1);
+            /* candidate 3 (levels >= 3): newest earlier-tile position whose first 8 bytes hash alike */
+            uint32_t q3 = kNone;
+            if (HAS_LONG && validL && oldL != 0u && (oldL & kTagMask) == tagL && !QZ_ABLATED(2u)) q3 = (oldL >> kTagBits) - 1u;
+            const bool far3 = q3 != kNone && p - q3 > kNear;
+            if (q3 != kNone) l3 = head_len(src, own, p & 3u, q3, far3);
             if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
                 if (q < p && !QZ_ABLATED(2u)) q2 = q;
             }
             if (q2 != kNone) l2 = head_len(src, own, p & 3u, q2, false); /* same tile: always near */
-            /* survivors of the 16-byte head: 32 more bytes per step, both candidates in one loop */
-            bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u;
-            while (need1 || need2) {
-                const bool first = need1;
-                const uint32_t q = first ? q1 : q2, L = first ? l1 : l2;
-                const uint32_t l = chunk_len(src, p + L, q + L, first && far1);
+            /* survivors of the 16-byte head: 32 more bytes per step, all candidates in one loop */
+            bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u, need3 = HAS_LONG && l3 == 16u && cap > 16u;
+            while (need1 || need2 || need3) {
+                const int which = need1 ? 1 : (need3 ? 3 : 2);
+                const uint32_t q = which == 1 ? q1 : (which == 3 ? q3 : q2);
+                const uint32_t L = which == 1 ? l1 : (which == 3 ? l3 : l2);
+                const uint32_t l = chunk_len(src, p + L, q + L, which == 1 ? far1 : (which == 3 ? far3 : false));
                 const bool more = l == 32u && L + 32u < cap;
-                if (first) { l1 = L + l; need1 = more; } else { l2 = L + l; need2 = more; }
+                if (which == 1) { l1 = L + l; need1 = more; }
+                else if (which == 3) { l3 = L + l; need3 = more; }
+                else { l2 = L + l; need2 = more; }
             }
-            l1 = umin(l1, cap); l2 = umin(l2, cap);
+            l1 = umin(l1, cap); l2 = umin(l2, cap); l3 = umin(l3, cap);
             if (l1 >= 4u) { cl = l1; off = p - q1; }
-            if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }
+            if (l3 >= 4u && l3 > cl) { cl = l3; off = p - q3; }   /* 8-byte table: only if strictly longer */
+            if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }  /* same tile: ties go to the nearer source */
         }
         if (it < nTiles && !QZ_ABLATED(4u)) {
             /* start flags: the lazy rules compare capped lengths and never look across the window edge */
@@ -693,7 +712,10 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");
     QZ_CHECK(hipSetDevice(device), "hipSetDevice");
     if (attrDevice != device || attrBytes < lds) {
-        QZ_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qzstd_find_sequences_kernel),
+        QZ_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        QZ_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                  "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         attrDevice = device;
@@ -706,7 +728,10 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
 #ifdef QZ_DEBUG_DUMP
     { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
 #endif
-    hipLaunchKernelGGL(qzstd_find_sequences_kernel, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
+    if (a.prof[0].longSize)
+        hipLaunchKernelGGL(qzstd_find_sequences_kernel<true>, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(qzstd_find_sequences_kernel<false>, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;
 }

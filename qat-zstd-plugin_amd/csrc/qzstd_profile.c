@@ -23,8 +23,12 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
 {
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
-    (void)blockSize; /* one profile for every block size: the LDS footprint is fixed (ring + table) */
-    out->tableSize = 6400u;
+    (void)blockSize; /* the profile does not depend on the block size: the LDS footprint is fixed (ring + tables) */
+    /* levels 1-2: 6400 entries, no long table = 81.6 KB of LDS -> two blocks per CU;
+     * levels >= 3: 16000 entries + a second table keyed by 8 bytes (the double-fast idea of zstd's
+     * levels 3-4) = 152.8 KB -> one block per CU */
+    out->tableSize = level >= 3 ? 16000u : 6400u;
+    out->longSize = level >= 3 ? 8192u : 0u;
     out->tileLog = 9;
     out->capLen = 64;
     out->minMatch = 4;
@@ -46,7 +50,7 @@ size_t qzstd_hip_sequence_bound(size_t srcSize)
 
 #define QZ_RING_BYTES (49152u + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip) */
 
-/* LDS per workgroup: independent of the block size — 81 600 B, i.e. two workgroups per CU */
+/* LDS per workgroup: independent of the block size — 81 600 B at levels 1-2 (two workgroups per CU) */
 size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
 {
     qzstd_hip_profile_t p;
@@ -54,6 +58,7 @@ size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX || qzstd_hip_profile_for_level(level, maxBlockLen, &p)) return 0;
     need = (size_t)QZ_RING_BYTES
            + 4u * p.tableSize        /* hash table                                    */
+           + 4u * p.longSize         /* 8-byte-key table (levels >= 3)                */
            + (4u << p.tileLog)     /* tile-local near table                         */
            + 2u * (4u << p.tileLog) /* per-position parse words, 2 tiles in flight */
            + 2u * ((1u << p.tileLog) >> 6) * 32u /* per-window emission records, x2 */

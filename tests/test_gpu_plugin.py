@@ -73,12 +73,13 @@ def test_one_shot_multiblock_frame(started, zstd):
     assert zstd.decompress(frame, len(data)) == data
 
 
-def test_ratio_within_2pct_of_software_l1(started, zstd):
+@pytest.mark.parametrize("level", [1, 3])
+def test_ratio_within_2pct_of_software(started, zstd, level):
     data = K.by_name("system", 64 * 131072)
     st = started.lib.QZSTD_createSeqProdState()
-    got = compress_with(zstd, started.producer_addr, st, data, 131072, 1, hint_lib=started.lib)
+    got = compress_with(zstd, started.producer_addr, st, data, 131072, level, hint_lib=started.lib)
     started.lib.QZSTD_freeSeqProdState(st)
-    zc = zstd.cctx(1)
+    zc = zstd.cctx(level)
     sw, _ = zstd.compress_chunks(zc, data, 131072)
     zstd.free(zc)
     ours = sum(len(f) for f in got)
