@@ -175,3 +175,33 @@ def test_benchmark_tool_gpu_modes(started, tmp_path):
         out = subprocess.run([exe, "-m1", "-t3", "-l2", "-c128K", "-L1"] + extra + [str(f)], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
         assert out.stderr.count("PASS") == 3, out.stderr
+
+
+def test_coalescer_stress_mixed_levels_and_sizes(started, zstd, oracle):
+    """many callers, two levels, ragged chunk sizes: the group-commit coalescer must hand every
+    caller exactly its own block's sequences (frames identical to the oracle's)"""
+    import random
+    nthreads = 24
+    jobs = []
+    rng = random.Random(7)
+    for t in range(nthreads):
+        level = 1 if t % 3 else 3
+        chunk = rng.choice([131072, 65536, 100000, 32768, 4096])
+        data = K.by_name(rng.choice(["text", "binary", "weblog", "mix"]), chunk * 5 + rng.randrange(1, 3000), seed=200 + t)
+        jobs.append((level, chunk, data))
+    res = [None] * nthreads
+
+    def work(t):
+        level, chunk, data = jobs[t]
+        z = B.Zstd(zstd.path)
+        st = started.lib.QZSTD_createSeqProdState()
+        res[t] = compress_with(z, started.producer_addr, st, data, chunk, level)
+        started.lib.QZSTD_freeSeqProdState(st)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for t in range(nthreads):
+        level, chunk, data = jobs[t]
+        assert res[t] is not None
+        assert res[t] == compress_with(zstd, oracle.producer_addr, None, data, chunk, level), "thread %d" % t

@@ -26,19 +26,6 @@ def main():
                 print("   %5d gpu %-22s oracle %-22s" % (k, g[k].tolist(), w[k].tolist()))
 main()
 
-def dump(n=3000, first=14, count=12):
-    plug, orc = B.Plugin(os.path.join(B.PKG_DIR, "lib", "libqatseqprod_dbg.so")), B.Oracle()
-    blk = K.text(1, 140000)[:n]
-    counts, seqs, stride = plug.find_batch([blk], 1)
-    a = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)
-    for wi in range(first, first + count):
-        s = a[stride - 1 - 2 * wi]; c = a[stride - 2 - 2 * wi]
-        print("win %3d (pos %5d): chosen %08x%08x curIn %d (rel %d) anchorIn %d | vis %08x%08x chainLo %08x exit %d" % (
-            wi, wi * 64, s[1], s[0], s[2], int(s[2]) - wi * 64, s[3], c[1], c[0], c[2], c[3]))
-if os.environ.get("QZ_DUMP"):
-    dump()
-
-
 def timing():
     plug = B.Plugin(os.path.join(B.PKG_DIR, "lib", "libqatseqprod_dbg.so"))
     data = K.system_corpus(256 * 131072)[0]
@@ -53,7 +40,7 @@ def timing():
     for wv in range(8):
         rw = np.array([a[(i + 1) * stride - 3 - wv] for i in range(len(blocks))], dtype=np.float64)
         print("matcher wave %d per tile: I1 %.0f waitB1 %.0f I2 %.0f waitB2 %.0f" % ((wv,) + tuple(rw.mean(axis=0) / 256)))
-    return
-    print("matcher wave 0, cycles per block: I1 %.0f  waitB1 %.0f  I2 %.0f  waitB2 %.0f ; per tile: %s" % (tuple(rows.mean(axis=0)) + (str((rows.mean(axis=0) / 256).round(0)),)))
+
+
 if os.environ.get("QZ_TIMING"):
     timing()
