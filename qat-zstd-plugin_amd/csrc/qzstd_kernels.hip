@@ -8,20 +8,26 @@
  * Here one workgroup does both jobs for one block and writes ZSTD_Sequence entries
  * straight to HBM:
  *
- *   - the block's bytes are staged once from HBM into LDS with 16-byte coalesced loads;
- *   - a 4-byte-entry hash table ((position+1)<<14 | 14-bit tag) lives in LDS next to it;
- *   - positions are processed in tiles of 1<<tileLog: every position of a tile reads its
- *     slot (newest position of EARLIER tiles), then all insert with ds_max_u32, so the
- *     result does not depend on wave scheduling; a tile-local ds_min_u32 table finds
- *     sources inside the current tile;
- *   - candidate lengths are measured from LDS (capped), packed per position, and a
- *     dedicated wave runs the (lazy) greedy parse over 64-position windows with
- *     ballot / readlane, extends long matches cooperatively, and the chosen lanes emit
- *     their {offset, litLength, matchLength} entries with a popcount prefix rank.
+ *   - the block streams from HBM into a 48 KiB LDS RING of its most recent bytes (16-byte
+ *     coalesced loads, 4.5 KiB ahead of the tile being matched); sources more than 40 KiB
+ *     back (a few % of the candidates) are compared from HBM/L2 instead, which halves the LDS
+ *     footprint: two blocks are resident per CU at levels 1-2;
+ *   - a 4-byte-entry hash table ((position+1)<<14 | 14-bit tag) lives in LDS next to it
+ *     (levels >= 3 add a second table keyed by 8 bytes);
+ *   - positions are processed in tiles of 512: every position of a tile reads its slot
+ *     (newest position of EARLIER tiles), then all insert with ds_max_u32, so the result does
+ *     not depend on wave scheduling; a tile-local ds_min_u32 table finds sources inside the
+ *     current tile;
+ *   - the 8 matcher waves measure the candidate lengths (16 bytes, then 32 per step), apply the
+ *     lazy start rules with three shuffles, and reduce every position to one packed word;
+ *   - a dedicated 9th wave runs the serial greedy chain as a 4-instruction scalar pointer chase
+ *     (bitset / readlane / compare / select), extends capped matches cooperatively when it
+ *     takes them, and publishes per-window records; the matcher waves then emit their chosen
+ *     {offset, litLength, matchLength} entries ranked by a popcount prefix.
  *
  * Integer byte matching: no MFMA.  The roofline that bounds it is HBM (block read once,
- * 16 B per sequence written); in practice it is LDS-latency / occupancy bound
- * (one 128 KiB block + table = the CU's whole 160 KiB LDS).
+ * 16 B per sequence written); in practice it is bound by LDS latency and instruction issue at
+ * 18 waves per CU (profiles/).
  *
  * The sequential definition of exactly this computation is oracle/qzstd_oracle.c
  * (test infrastructure); tests compare the two sequence-for-sequence.
@@ -63,7 +69,7 @@ struct LaunchArgs {
     const qzstd_hip_block_t *blocks;
     uint4 *seqs; /* ZSTD_Sequence = 4 x u32 */
     uint32_t *nseq;
-    qzstd_hip_profile_t prof[3]; /* by block size class: >64 KiB, >32 KiB, <=32 KiB */
+    qzstd_hip_profile_t prof; /* the level's search profile (block-size independent) */
 #ifdef QZ_DEBUG_DUMP
     uint32_t dbg; /* profiling build only: ablation switches (QZSTD_HIP_ABLATE) */
 #endif
@@ -330,14 +336,18 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
 
 /*
  * One workgroup = one block.  8 matcher waves (one position per thread per 512-position tile)
- * + 1 parse wave, software-pipelined over tiles with two barriers per iteration:
+ * + 1 parse wave, each role with its own loop and the same cadence of two barriers per iteration:
  *
- *   interval 1 of iteration it   matchers: emit(it-2), phase A(it) (hash, table look-up, near-table min)
+ *   interval 1 of iteration it   matchers: own bytes + ring refill loads, emit(it-2),
+ *                                          phase A(it): hash, table look-up(s), near-table ds_min
+ *                                parse wave: windows 0-1 of tile it-1
  *   barrier
- *   interval 2                   matchers: phase B(it) (insert), candidate lengths, run-tail
- *                                          extension, start flags of tile it
- *                                parse wave: greedy chain over tile it-1
+ *   interval 2                   matchers: ring refill store, phase B(it): ds_max insert(s), near read,
+ *                                          candidate lengths, lazy start flags, packed parse words
+ *                                parse wave: windows 2-7 of tile it-1
  *   barrier
+ *
+ * HAS_LONG selects the level >= 3 variant with the second (8-byte-key) table.
  */
 template <bool HAS_LONG>
 __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     const bool matcher = wave < (uint32_t)kMatchWaves;
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     const uint32_t n = blk.srcLen;
-    const qzstd_hip_profile_t pf = args.prof[n > (64u << 10) ? 0 : (n > (32u << 10) ? 1 : 2)];
+    const qzstd_hip_profile_t pf = args.prof;
     const uint32_t nh = n >= pf.hashBytes ? n - pf.hashBytes + 1u : 0u; /* hashable positions */
     const uint32_t nTiles = (nh + kTile - 1u) >> kTileLog;
 
@@ -700,14 +710,11 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (nBlocks == 0) return 0;
     if (!d_src || !d_blocks || !d_seqs || !d_nseq) return fail_msg("qzstd_hip_find_sequences: null pointer");
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX) return fail_msg("qzstd_hip_find_sequences: block larger than 128 KiB");
-    if (qzstd_hip_profile_for_level(level, 128u << 10, &a.prof[0]) ||
-        qzstd_hip_profile_for_level(level, 64u << 10, &a.prof[1]) ||
-        qzstd_hip_profile_for_level(level, 32u << 10, &a.prof[2]))
+    if (qzstd_hip_profile_for_level(level, maxBlockLen, &a.prof))
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12");
-    for (int c = 0; c < 3; c++)
-        if (a.prof[c].tileLog != kTileLog || a.prof[c].extLog < 8 || a.prof[c].extLog > 15 || a.prof[c].capLen > 128 || a.prof[c].capLen < 32 || a.prof[c].minMatch < 4 || a.prof[c].hashBytes < 4 ||
-            a.prof[c].hashBytes > 8)
-            return fail_msg("qzstd_hip_find_sequences: unsupported profile");
+    if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
+        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8)
+        return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");
     QZ_CHECK(hipSetDevice(device), "hipSetDevice");
@@ -728,7 +735,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
 #ifdef QZ_DEBUG_DUMP
     { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
 #endif
-    if (a.prof[0].longSize)
+    if (a.prof.longSize)
         hipLaunchKernelGGL(qzstd_find_sequences_kernel<true>, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(qzstd_find_sequences_kernel<false>, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
