@@ -82,3 +82,28 @@ def test_capacity_rule(gpu_plugin, oracle):
         assert counts[0] == (want_n if want_n != B.SEQ_ERROR else B.NSEQ_ERROR), cap
     assert oracle.find(prof, blk, cap=n_full + 2)[0] == n_full
     assert oracle.find(prof, blk, cap=n_full + 1)[0] == B.SEQ_ERROR
+
+
+@pytest.mark.parametrize("level,seed", [(1, 1), (1, 2), (3, 3)])
+def test_randomised_blocks(gpu_plugin, oracle, level, seed):
+    """ragged random batch: random sizes (incl. tiny and ring-wrapping ones), random content kinds,
+    repeated / shifted copies that create far (> 40 KiB) and very long matches"""
+    import random
+    rng = random.Random(seed)
+    pool = {k: K.by_name(k, 300000, seed=seed + i) for i, k in enumerate(["text", "binary", "weblog", "mixed_entropy", "random"])}
+    blocks = []
+    for _ in range(96):
+        n = rng.choice([rng.randrange(0, 600), rng.randrange(600, 50000), rng.randrange(50000, 131073), 131072])
+        kind = rng.choice(list(pool))
+        o = rng.randrange(0, 300000 - 131072)
+        b = bytearray(pool[kind][o:o + n])
+        if n > 60000 and rng.random() < 0.5:  # plant a far, long repeat
+            src = rng.randrange(0, n // 4)
+            ln = rng.randrange(100, 20000)
+            dst = rng.randrange(n // 2, max(n // 2 + 1, n - ln))
+            b[dst:dst + ln] = b[src:src + ln][:max(0, n - dst)]
+        if rng.random() < 0.1 and n > 1000:  # a run
+            s0 = rng.randrange(0, n - 1000)
+            b[s0:s0 + 900] = bytes([rng.randrange(256)]) * 900
+        blocks.append(bytes(b[:n]))
+    check_blocks(gpu_plugin, oracle, blocks, level)
