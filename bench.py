@@ -101,7 +101,8 @@ def cpu_oracle_leg(data: bytes, block: int, level: int, seconds: float):
             "sample": "oracle/qzstd_oracle.c qzo_find_sequences, first %d blocks of the batch, 1 thread" % (done // block)}
 
 
-def c_benchmark(sample: bytes, block: int, level: int, threads: int, mode: int, hint: bool = False, ext_rep: int = 0):
+def c_benchmark(sample: bytes, block: int, level: int, threads: int, mode: int, hint: bool = False, ext_rep: int = 0,
+                loops: int = 2):
     """run qat-zstd-plugin_amd/test/benchmark (counterpart of the reference's test/benchmark.c: T threads,
     one CCtx each, one ZSTD_compress2 per chunk, each chunk its own frame) on a sample file"""
     import re
@@ -115,7 +116,7 @@ def c_benchmark(sample: bytes, block: int, level: int, threads: int, mode: int, 
         with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
             f.write(sample)
             name = f.name
-        cmd = [os.path.join(tdir, "benchmark"), "-m%d" % mode, "-t%d" % threads, "-l2", "-c%d" % block, "-L%d" % level,
+        cmd = [os.path.join(tdir, "benchmark"), "-m%d" % mode, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level,
                "-E%d" % ext_rep] + (["-H1"] if hint else []) + [name]
         t0 = time.perf_counter()
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
@@ -241,10 +242,11 @@ def main():
             # measured by the C tool in the same run on the host cores of this box
             sample = shard[:min(len(shard), 512 * block)]
             thr = min(ncpu, 16)  # <= QZ_DEFAULT_SLOTS_PER_DEVICE: one slot per thread
-            sw = c_benchmark(sample, block, level, thr, mode=0)
+            sw = c_benchmark(sample, block, level, thr, mode=0, loops=6)
             out["cpu_libzstd_sw"] = {"lib": os.path.basename(B.find_libzstd()), "host_cores": ncpu, **sw}
-            # end to end through ZSTD_compress2 with the plugin registered (look-ahead hint on / off)
-            e2e = c_benchmark(sample, block, level, thr, mode=1, hint=True)
+            # end to end through ZSTD_compress2 with the plugin registered: 4 MiB look-ahead hints (the GPU match-finds
+            # segment k+1 while the thread entropy-codes segment k), then without hints (per-block, coalesced)
+            e2e = c_benchmark(sample, block, level, thr, mode=1, hint=True, loops=6)
             if "csize" in e2e and "csize" in sw:
                 e2e["csize_vs_sw"] = round(e2e["csize"] / sw["csize"], 4)
                 e2e["ratio_within_2pct"] = e2e["csize"] <= sw["csize"] * 1.02

@@ -87,6 +87,9 @@ int qzstd_hip_stream_query(int device, void *stream); /* 0 done, 1 still running
 int qzstd_hip_memcpy_h2d(int device, void *stream, void *dst, const void *src, size_t bytes);
 int qzstd_hip_memcpy_d2h(int device, void *stream, void *dst, const void *src, size_t bytes);
 int qzstd_hip_memset(int device, void *stream, void *dst, int value, size_t bytes);
+/* strided device->host copy: `height` rows of `width` bytes, row r at src + r*spitch -> dst + r*dpitch */
+int qzstd_hip_memcpy2d_d2h(int device, void *stream, void *dst, size_t dpitch, const void *src, size_t spitch,
+                           size_t width, size_t height);
 
 /*
  * The hot path.  Asynchronously launches the match-finder on `stream` (NULL = the

@@ -700,6 +700,15 @@ int qzstd_hip_memset(int device, void *stream, void *dst, int value, size_t byte
     return 0;
 }
 
+int qzstd_hip_memcpy2d_d2h(int device, void *stream, void *dst, size_t dpitch, const void *src, size_t spitch,
+                           size_t width, size_t height)
+{
+    QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    QZ_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, (hipStream_t)stream),
+             "hipMemcpy2DAsync D2H");
+    return 0;
+}
+
 int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_src,
                              const qzstd_hip_block_t *d_blocks, uint32_t nBlocks, uint32_t maxBlockLen,
                              void *d_seqs, uint32_t *d_nseq)

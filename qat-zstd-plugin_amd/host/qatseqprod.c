@@ -32,6 +32,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #ifndef DEBUGLEVEL
 #define DEBUGLEVEL 0
@@ -43,7 +44,7 @@
 #define QZ_GRAB_SWEEPS 10000
 #define QZ_MAX_DEVICES 64
 #define QZ_MAX_SLOTS 1024
-#define QZ_DEFAULT_SLOTS_PER_DEVICE 16
+#define QZ_DEFAULT_SLOTS_PER_DEVICE 64
 #define QZ_FIRST_COPY_SEQS 16384u /* sequences fetched together with the count */
 
 static int qzLogLevel = DEBUGLEVEL; /* 0 silent, 1 errors, 2 events, 3 every sequence */
@@ -128,20 +129,33 @@ typedef struct {
 
 static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, PTHREAD_MUTEX_INITIALIZER };
 
+/* One announced buffer: staged in pinned memory, match-found asynchronously on a slot's stream,
+ * results (count + the first QZ_HINT_PITCH sequences of every block) copied back asynchronously. */
+#define QZ_HINT_MAX_BYTES ((size_t)16 << 20)
+#define QZ_HINT_PITCH ((size_t)12288) /* blocks with more sequences take the per-block path */
+typedef struct {
+    int st;   /* 0 empty, 1 in flight on the GPU (slot held), 2 ready */
+    int slot; /* index of the slot held while in flight */
+    const unsigned char *base;
+    size_t size, block, nb;
+    int level;
+    unsigned char *hSrc;      /* pinned staging copy of the buffer */
+    ZSTD_Sequence *hSeqs;     /* pinned, nb x QZ_HINT_PITCH */
+    unsigned int *hCount;     /* pinned */
+    qzstd_hip_block_t *hDesc; /* pinned */
+    size_t hSrcCap, hSeqsCap, hCountCap, hDescCap; /* bytes */
+} QZSTD_Hint_T;
+
 /* Per-CCtx state (opaque to the caller). */
 typedef struct {
     int slotHint;
     unsigned int failOffloadCnt;
-    /* look-ahead batch served to later callbacks (QZSTD_hintSource) */
-    const unsigned char *hintBase;
-    size_t hintSize, hintBlock;
-    int hintLevel;
-    size_t batchBlocks, batchPitch; /* pitch in sequences */
-    ZSTD_Sequence *batchSeqs;       /* pinned host, batchBlocks * batchPitch */
-    unsigned int *batchCount;       /* pinned host */
-    qzstd_hip_block_t *batchDesc;   /* pinned host */
-    size_t batchSeqsCap, batchDescCap, batchCountCap; /* bytes */
+    /* look-ahead batches served to later callbacks (QZSTD_hintSource): two, so that the GPU can
+     * work on the next buffer while libzstd entropy-codes the current one on this thread */
+    QZSTD_Hint_T hint[2];
+    int hintNext;
     unsigned long servedFromBatch, servedSync;
+    unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs; /* event log only */
 } QZSTD_Session_T;
 
 const char *QZSTD_version(void)
@@ -462,22 +476,45 @@ void *QZSTD_createSeqProdState(void)
     return s;
 }
 
-static void qzDropBatch(QZSTD_Session_T *s)
+static void qzReleaseSlot(int i);
+
+static unsigned long qzNowNs(void)
 {
-    s->hintBase = NULL;
-    s->hintSize = 0;
-    s->batchBlocks = 0;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (unsigned long)ts.tv_sec * 1000000000ul + (unsigned long)ts.tv_nsec;
+}
+
+/* wait for an in-flight hint and give its slot back; the hint becomes ready (or empty on failure) */
+static void qzHintFinish(QZSTD_Hint_T *h)
+{
+    if (h->st != 1) return;
+    if (gProc.slots && h->slot >= 0 && h->slot < gProc.numSlots) {
+        QZSTD_Slot_T *sl = &gProc.slots[h->slot];
+        const int bad = qzstd_hip_stream_sync(sl->device, sl->stream);
+        qzReleaseSlot(h->slot);
+        h->st = bad ? 0 : 2;
+        if (bad) QZ_LOG(1, "look-ahead batch failed: %s\n", qzstd_hip_last_error());
+    } else {
+        h->st = 0;
+    }
 }
 
 void QZSTD_freeSeqProdState(void *sequenceProducerState)
 {
     QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
+    int k;
     if (!s) return;
-    QZ_LOG(2, "state %p: %lu block(s) served from a look-ahead batch, %lu synchronously\n", (void *)s,
-           s->servedFromBatch, s->servedSync);
-    qzstd_hip_host_free(s->batchSeqs);
-    qzstd_hip_host_free(s->batchCount);
-    qzstd_hip_host_free(s->batchDesc);
+    QZ_LOG(2, "state %p: %lu block(s) served from a look-ahead batch, %lu per block; %lu hint(s): staging %.2f ms, "
+              "queueing %.2f ms, waited %.2f ms for the GPU\n", (void *)s, s->servedFromBatch, s->servedSync,
+           s->hintCalls, s->hintStageNs / 1e6, s->hintQueueNs / 1e6, s->hintWaitNs / 1e6);
+    for (k = 0; k < 2; k++) {
+        qzHintFinish(&s->hint[k]);
+        qzstd_hip_host_free(s->hint[k].hSrc);
+        qzstd_hip_host_free(s->hint[k].hSeqs);
+        qzstd_hip_host_free(s->hint[k].hCount);
+        qzstd_hip_host_free(s->hint[k].hDesc);
+    }
     free(s);
 }
 
@@ -558,22 +595,34 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     if (!s || !outSeqs || !src || srcSize > QZSTD_HIP_BLOCK_MAX || outSeqsCapacity < 3) return ZSTD_SEQUENCE_PRODUCER_ERROR;
     if (!qzDeviceUsable(s)) return ZSTD_SEQUENCE_PRODUCER_ERROR;
 
-    /* look-ahead batch hit?  (src, srcSize) must sit exactly on the hinted block grid */
-    if (s->batchBlocks && s->hintLevel == compressionLevel) {
-        const unsigned char *p = (const unsigned char *)src;
-        if (p >= s->hintBase && p + srcSize <= s->hintBase + s->hintSize) {
-            const size_t rel = (size_t)(p - s->hintBase);
-            const size_t b = rel / s->hintBlock;
-            if (rel % s->hintBlock == 0 && b < s->batchBlocks && s->batchDesc[b].srcLen == srcSize) {
-                const size_t count = s->batchCount[b];
-                if (count != QZSTD_HIP_NSEQ_ERROR && count != 0 && count < outSeqsCapacity - 1 &&
-                    count <= s->batchPitch) {
-                    memcpy(outSeqs, s->batchSeqs + b * s->batchPitch, count * sizeof(ZSTD_Sequence));
+    /* look-ahead batch hit?  (src, srcSize) must sit exactly on an announced block grid */
+    {
+        int k;
+        for (k = 0; k < 2; k++) {
+            QZSTD_Hint_T *h = &s->hint[k];
+            const unsigned char *p = (const unsigned char *)src;
+            size_t rel, b;
+            if (h->st == 0 || h->level != compressionLevel || p < h->base || p + srcSize > h->base + h->size) continue;
+            rel = (size_t)(p - h->base);
+            b = rel / h->block;
+            if (rel % h->block != 0 || b >= h->nb || h->hDesc[b].srcLen != srcSize) continue;
+            if (h->st == 1) { /* first use: wait for the GPU (usually long done) */
+                const unsigned long w0 = qzNowNs();
+                qzHintFinish(h);
+                s->hintWaitNs += qzNowNs() - w0;
+            }
+            if (h->st == 2) {
+                const size_t count = h->hCount[b];
+                const int last = rel + srcSize >= h->size;
+                if (count != QZSTD_HIP_NSEQ_ERROR && count != 0 && count < outSeqsCapacity - 1 && count <= QZ_HINT_PITCH) {
+                    memcpy(outSeqs, h->hSeqs + b * QZ_HINT_PITCH, count * sizeof(ZSTD_Sequence));
                     s->servedFromBatch++;
-                    if (rel + srcSize >= s->hintSize) qzDropBatch(s); /* last block consumed */
+                    if (last) h->st = 0; /* last block consumed */
                     return count;
                 }
+                if (last) h->st = 0;
             }
+            break; /* announced but unusable (too many sequences, failed launch): per-block path */
         }
     }
 
@@ -626,79 +675,108 @@ static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need)
     return p;
 }
 
+/* one quick sweep over the slots (no waiting) */
+static int qzTryGrabSlot(int hint)
+{
+    int k;
+    const int n = gProc.numSlots;
+    if (n <= 0) return -1;
+    if (hint < 0 || hint >= n) hint = 0;
+    for (k = 0; k < n; k++) {
+        const int i = (hint + k) % n;
+        if (__sync_lock_test_and_set(&gProc.slots[i].lock, 1) == 0) return i;
+    }
+    return -1;
+}
+
 int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
                      int compressionLevel)
 {
     QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
+    QZSTD_Hint_T *h;
     QZSTD_Slot_T *sl;
-    size_t nb, b, stride, pitch = 0, blocksBytes, srcBytes;
+    size_t nb, b, stride, blocksBytes, srcBytes;
+    unsigned long tq;
     int i, rc = -1;
 
-    if (!s || !src || srcSize == 0 || blockSize == 0 || blockSize > QZSTD_HIP_BLOCK_MAX || (blockSize & 15)) return -1;
+    if (!s || !src || srcSize == 0 || srcSize > QZ_HINT_MAX_BYTES || blockSize == 0 || blockSize > QZSTD_HIP_BLOCK_MAX ||
+        (blockSize & 15))
+        return -1;
     if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) return -1;
-    qzDropBatch(s);
     if (!qzDeviceUsable(s)) return -1;
+
+    h = &s->hint[s->hintNext];
+    s->hintNext ^= 1;
+    qzHintFinish(h); /* an old announcement that was never consumed */
+    h->st = 0;
     nb = (srcSize + blockSize - 1) / blockSize;
     stride = qzstd_hip_sequence_bound(blockSize);
-    i = qzGrabSlot(s->slotHint);
-    if (i < 0) return -1;
-    s->slotHint = i;
-    sl = &gProc.slots[i];
-    if (qzSetupSlot(sl) != QZSTD_OK) goto out;
-
     blocksBytes = nb * sizeof(qzstd_hip_block_t);
     srcBytes = (srcSize + 63) & ~(size_t)63;
-    s->batchDesc = (qzstd_hip_block_t *)qzGrowHost(s->batchDesc, &s->batchDescCap, blocksBytes);
-    s->batchCount = (unsigned int *)qzGrowHost(s->batchCount, &s->batchCountCap, nb * sizeof(unsigned int));
-    if (!s->batchDesc || !s->batchCount) goto out;
+
+    h->hSrc = (unsigned char *)qzGrowHost(h->hSrc, &h->hSrcCap, srcBytes);
+    h->hDesc = (qzstd_hip_block_t *)qzGrowHost(h->hDesc, &h->hDescCap, blocksBytes);
+    h->hCount = (unsigned int *)qzGrowHost(h->hCount, &h->hCountCap, nb * sizeof(unsigned int));
+    h->hSeqs = (ZSTD_Sequence *)qzGrowHost(h->hSeqs, &h->hSeqsCap, nb * QZ_HINT_PITCH * sizeof(ZSTD_Sequence));
+    if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs) return -1;
+
+    i = qzTryGrabSlot(s->slotHint);
+    if (i < 0) {
+        /* every slot is busy: give back what this state still holds, then wait for one */
+        qzHintFinish(&s->hint[s->hintNext]);
+        i = qzGrabSlot(s->slotHint);
+        if (i < 0) return -1;
+    }
+    s->slotHint = i;
+    sl = &gProc.slots[i];
+    if (qzSetupSlot(sl) != QZSTD_OK) goto fail;
     sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, srcBytes);
     sl->dBatchSeqs = (ZSTD_Sequence *)qzGrowDev(sl->device, sl->dBatchSeqs, &sl->dBatchSeqsCap,
                                                 nb * stride * sizeof(ZSTD_Sequence));
-    if (!sl->dBatchSrc || !sl->dBatchSeqs) goto out;
+    if (!sl->dBatchSrc || !sl->dBatchSeqs) goto fail;
     if (sl->dBatchBlocksCap < nb) {
         qzstd_hip_free(sl->device, sl->dBatchDesc);
         qzstd_hip_free(sl->device, sl->dBatchCount);
         sl->dBatchDesc = (qzstd_hip_block_t *)qzstd_hip_malloc(sl->device, blocksBytes);
         sl->dBatchCount = (unsigned int *)qzstd_hip_malloc(sl->device, nb * sizeof(unsigned int));
         sl->dBatchBlocksCap = sl->dBatchDesc && sl->dBatchCount ? nb : 0;
-        if (!sl->dBatchBlocksCap) goto out;
+        if (!sl->dBatchBlocksCap) goto fail;
     }
+    tq = qzNowNs();
+    memcpy(h->hSrc, src, srcSize); /* pinned staging: the H2D below is then truly asynchronous */
     for (b = 0; b < nb; b++) {
         const size_t o = b * blockSize;
-        s->batchDesc[b].srcOff = o;
-        s->batchDesc[b].seqOff = b * stride;
-        s->batchDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
-        s->batchDesc[b].seqCap = (unsigned int)stride;
+        h->hDesc[b].srcOff = o;
+        h->hDesc[b].seqOff = b * stride;
+        h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
+        h->hDesc[b].seqCap = (unsigned int)stride;
     }
-    if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, src, srcSize) ||
-        qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchDesc, s->batchDesc, blocksBytes) ||
+    s->hintStageNs += qzNowNs() - tq;
+    tq = qzNowNs();
+    /* everything below is queued on the slot's stream and returns immediately */
+    if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc, srcBytes) ||
+        qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchDesc, h->hDesc, blocksBytes) ||
         qzstd_hip_find_sequences(sl->device, sl->stream, compressionLevel, sl->dBatchSrc, sl->dBatchDesc,
                                  (unsigned int)nb, (unsigned int)blockSize, sl->dBatchSeqs, sl->dBatchCount) ||
-        qzstd_hip_memcpy_d2h(sl->device, sl->stream, s->batchCount, sl->dBatchCount, nb * sizeof(unsigned int)) ||
-        qzstd_hip_stream_sync(sl->device, sl->stream))
-        goto out;
-    for (b = 0; b < nb; b++)
-        if (s->batchCount[b] != QZSTD_HIP_NSEQ_ERROR && s->batchCount[b] > pitch) pitch = s->batchCount[b];
-    if (pitch == 0) goto out;
-    s->batchSeqs = (ZSTD_Sequence *)qzGrowHost(s->batchSeqs, &s->batchSeqsCap, nb * pitch * sizeof(ZSTD_Sequence));
-    if (!s->batchSeqs) goto out;
-    /* gather: every block's used prefix, one D2H per block on the same stream */
-    for (b = 0; b < nb; b++) {
-        const size_t cnt = s->batchCount[b] == QZSTD_HIP_NSEQ_ERROR ? 0 : s->batchCount[b];
-        if (cnt && qzstd_hip_memcpy_d2h(sl->device, sl->stream, s->batchSeqs + b * pitch,
-                                        sl->dBatchSeqs + b * stride, cnt * sizeof(ZSTD_Sequence)))
-            goto out;
+        qzstd_hip_memcpy_d2h(sl->device, sl->stream, h->hCount, sl->dBatchCount, nb * sizeof(unsigned int)) ||
+        qzstd_hip_memcpy2d_d2h(sl->device, sl->stream, h->hSeqs, QZ_HINT_PITCH * sizeof(ZSTD_Sequence), sl->dBatchSeqs,
+                               stride * sizeof(ZSTD_Sequence),
+                               (stride < QZ_HINT_PITCH ? stride : QZ_HINT_PITCH) * sizeof(ZSTD_Sequence), nb)) {
+        (void)qzstd_hip_stream_sync(sl->device, sl->stream);
+        goto fail;
     }
-    if (qzstd_hip_stream_sync(sl->device, sl->stream)) goto out;
-    s->hintBase = (const unsigned char *)src;
-    s->hintSize = srcSize;
-    s->hintBlock = blockSize;
-    s->hintLevel = compressionLevel;
-    s->batchBlocks = nb;
-    s->batchPitch = pitch;
-    rc = 0;
-out:
-    if (rc) QZ_LOG(1, "look-ahead hint not taken: %s\n", qzstd_hip_last_error());
+    h->base = (const unsigned char *)src;
+    h->size = srcSize;
+    h->block = blockSize;
+    h->level = compressionLevel;
+    h->nb = nb;
+    h->slot = i;
+    h->st = 1; /* in flight; the slot stays ours until qzHintFinish() */
+    s->hintQueueNs += qzNowNs() - tq;
+    s->hintCalls++;
+    return 0;
+fail:
+    QZ_LOG(1, "look-ahead hint not taken: %s\n", qzstd_hip_last_error());
     qzReleaseSlot(i);
     return rc;
 }

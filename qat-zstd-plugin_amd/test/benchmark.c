@@ -9,8 +9,9 @@
  * PASS criterion (:329-339), a timed decompression loop (:350-369), a per-thread report line
  * (:374-382) and latency percentiles from 200 geometric buckets x1.05 from 1 us (:100-169,
  * :522-530).  -m0 = libzstd's own match-finder (plugin unregistered), the CPU baseline.
- * Written from scratch; one additive option:  -H1  announce each thread's buffer to the plugin
- * with QZSTD_hintSource() so that the GPU match-finds it in one batched launch.
+ * Written from scratch; one additive option:  -H<n>  announce each thread's buffer to the plugin
+ * one segment ahead with QZSTD_hintSource(), so that the GPU match-finds segment k+1 in one batched
+ * launch while this thread's libzstd entropy-codes segment k.
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -115,7 +116,7 @@ static void usage(const char *exe)
             "  -E#   searchForExternalRepcodes 0 auto, 1 enable, 2 disable (default auto)\n"
             "  -L#   compression level [1-12] (default 1)\n"
             "  -m#   0 software zstd, 1 GPU sequence producer (default 1)\n"
-            "  -H#   1 = announce each thread's buffer with QZSTD_hintSource (default 0)\n", exe);
+            "  -H#   look-ahead with QZSTD_hintSource: 1 = 4 MiB segments, n>1 = n MiB segments (default 0 = off)\n", exe);
 }
 
 static void *worker(void *arg)
@@ -149,16 +150,30 @@ static void *worker(void *arg)
             ok = 0;
         }
     }
+    /* look-ahead: segments of -H MiB (1 -> 4 MiB), a whole number of chunks, on libzstd's block grid */
+    const size_t grid = o->chunk <= 131072 ? o->chunk : 131072;
+    const size_t segWant = (size_t)(o->hint > 1 ? o->hint : 4) << 20;
+    const size_t segChunks = segWant / o->chunk ? segWant / o->chunk : 1;
+    const size_t segBytes = segChunks * o->chunk;
+    const int useHint = o->mode == 1 && o->hint && o->chunk % grid == 0 && (grid & 15) == 0 && segBytes <= ((size_t)16 << 20);
     pthread_barrier_wait(&gStart);
     for (unsigned l = 0; ok && l < o->loops; l++) {
         size_t off = 0, dpos = 0;
-        if (o->mode == 1 && o->hint) {
+        if (useHint) { /* announce the first segment; later ones are announced one segment ahead */
             const unsigned long t0 = nowNs();
-            QZSTD_hintSource(state, o->src, o->srcSize, o->chunk, (int)o->level);
-            compNs += nowNs() - t0; /* the batched match-finding is part of the compression time */
+            QZSTD_hintSource(state, o->src, o->srcSize < segBytes ? o->srcSize : segBytes, grid, (int)o->level);
+            compNs += nowNs() - t0; /* staging + queueing is part of the compression time */
         }
         for (size_t c = 0; c < nChunks; c++) {
             const size_t n = o->srcSize - off < o->chunk ? o->srcSize - off : o->chunk;
+            if (useHint && c % segChunks == 0 && off + segBytes < o->srcSize) {
+                /* the GPU match-finds the next segment while this thread entropy-codes the current one */
+                const size_t nextOff = off + segBytes;
+                const size_t nextLen = o->srcSize - nextOff < segBytes ? o->srcSize - nextOff : segBytes;
+                const unsigned long h0 = nowNs();
+                QZSTD_hintSource(state, o->src + nextOff, nextLen, grid, (int)o->level);
+                compNs += nowNs() - h0;
+            }
             const unsigned long t0 = nowNs();
             const size_t r = ZSTD_compress2(zc, dst + dpos, dstCap - dpos, o->src + off, n);
             const unsigned long dt = nowNs() - t0;

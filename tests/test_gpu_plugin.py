@@ -61,6 +61,59 @@ def test_hint_batch_path_identical(started, zstd, oracle):
     assert b"".join(zstd.decompress(f, 131072) for f in got) == data
 
 
+@pytest.mark.parametrize("level,chunk,seg", [(1, 131072, 8), (3, 65536, 5), (1, 32768, 16)])
+def test_hint_double_buffered_lookahead(started, zstd, oracle, level, chunk, seg):
+    """segment k+1 is announced (asynchronous launch) before segment k is compressed: frames must
+    still be exactly the oracle's, including the ragged last segment"""
+    data = K.by_name("system", 5 * seg * chunk + 3 * chunk + 999)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    segb = seg * chunk
+    st = started.lib.QZSTD_createSeqProdState()
+    zc = zstd.cctx(level, producer=started.producer_addr, state=st, fallback=False, validate=True)
+    cap = zstd.lib.ZSTD_compressBound(chunk)
+    dst = C.create_string_buffer(cap)
+    assert started.lib.QZSTD_hintSource(st, buf, min(segb, len(data)), chunk, level) == 0
+    got = []
+    for o in range(0, len(data), chunk):
+        if o % segb == 0 and o + segb < len(data):
+            n2 = min(segb, len(data) - o - segb)
+            assert started.lib.QZSTD_hintSource(st, C.byref(buf, o + segb), n2, chunk, level) == 0
+        n = min(chunk, len(data) - o)
+        r = zstd.lib.ZSTD_compress2(zc, dst, cap, C.byref(buf, o), n)
+        assert not zstd.is_error(r), zstd.err(r)
+        got.append(dst.raw[:r])
+    zstd.free(zc)
+    started.lib.QZSTD_freeSeqProdState(st)
+    want = compress_with(zstd, oracle.producer_addr, None, data, chunk, level)
+    assert got == want
+    assert b"".join(zstd.decompress(f, chunk) for f in got) == data
+
+
+def test_hint_limits_and_abandoned_hints(started, zstd):
+    """oversized announcements are refused; announcements that are never consumed must give their
+    slot back when the state is freed (more states than slots, then a normal compression)"""
+    L = started.lib
+    st = L.QZSTD_createSeqProdState()
+    big = C.create_string_buffer((16 << 20) + 131072)
+    assert L.QZSTD_hintSource(st, big, len(big), 131072, 1) == -1
+    assert L.QZSTD_hintSource(st, big, 1 << 20, 131072 + 16, 1) == -1   # block grid > 128 KiB
+    assert L.QZSTD_hintSource(st, big, 1 << 20, 1000, 1) == -1           # grid not 16-aligned
+    assert L.QZSTD_hintSource(st, big, 1 << 20, 131072, 0) == -1         # level guard
+    L.QZSTD_freeSeqProdState(st)
+    data = K.text(3, 4 * 131072)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    for _ in range(80):
+        s2 = L.QZSTD_createSeqProdState()
+        assert L.QZSTD_hintSource(s2, buf, len(data), 131072, 1) == 0
+        assert L.QZSTD_hintSource(s2, buf, len(data), 65536, 1) == 0
+        assert L.QZSTD_hintSource(s2, buf, len(data), 131072, 2) == 0    # re-uses (and drains) buffer 0
+        L.QZSTD_freeSeqProdState(s2)
+    st = L.QZSTD_createSeqProdState()
+    frames = compress_with(zstd, started.producer_addr, st, data, 131072, 1)
+    L.QZSTD_freeSeqProdState(st)
+    assert b"".join(zstd.decompress(f, 131072) for f in frames) == data
+
+
 def test_one_shot_multiblock_frame(started, zstd):
     """plain ZSTD_compress2 over 1 MiB+: libzstd calls the producer once per 128 KiB block
     (and 1.5.7 may pre-split); every call is an independent block."""
