@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--level", type=lambda v: int(v, 0), default=1, help="1..12, optionally | 0x100 (repeat-offset aware)")
     ap.add_argument("--block", type=int, default=131072)
     ap.add_argument("--blocks", type=int, default=8192, help="blocks per GPU per step (8192 x 128 KiB = 1 GiB)")
     ap.add_argument("--corpus", default="system", help="system | text | mix | weblog | mixed_entropy | /path/to/file")

@@ -52,7 +52,9 @@ typedef struct {
     uint32_t hashBytes; /* bytes hashed per position (4..8)                                */
     uint32_t extLog;    /* a match never extends past the end of the next 1<<extLog cell       */
     uint32_t longSize;  /* entries of the second table keyed by 8 bytes (0 = none)               */
-    uint32_t reserved;
+    uint32_t repWin;    /* 0 = plain parse; n = repeat-offset aware parse: after every match the next n positions
+                         * are also tried with the last two offsets (for callers with
+                         * ZSTD_c_searchForExternalRepcodes on, which is libzstd's default from level 10) */
 } qzstd_hip_profile_t;
 
 /* One work item = one <=128 KiB block, parsed with no history
@@ -65,6 +67,10 @@ typedef struct {
 } qzstd_hip_block_t;
 
 const char *qzstd_hip_last_error(void);
+
+/* OR-ed into a `level` argument: the caller compresses with ZSTD_c_searchForExternalRepcodes enabled (libzstd
+ * only does that by itself from level 10), so repeat-offset aware sequences pay off at every level */
+#define QZSTD_HIP_LEVEL_REPCODES 0x100
 
 /* ---- level -> profile (pure host function, no GPU needed) ---- */
 int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t *out);

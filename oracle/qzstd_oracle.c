@@ -51,6 +51,8 @@ static inline uint32_t qzo_rd32(const uint8_t *p)
  */
 int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
 {
+    const int repcodes = (level & QZO_LEVEL_REPCODES) != 0;
+    level &= ~QZO_LEVEL_REPCODES;
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
     (void)blockSize; /* the profile does not depend on the block size (the kernel's LDS footprint is fixed) */
@@ -69,6 +71,9 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->window = 0;
     out->hashBytes = 5;
     out->extLog = 11;
+    /* libzstd turns repeat offsets of external sequences into repcodes only from level 10 (or when the
+     * caller sets ZSTD_c_searchForExternalRepcodes); without that, short repeat matches cost a full offset */
+    out->repWin = (repcodes || level >= 10) ? 8u : 0u;
     return 0;
 }
 
@@ -205,6 +210,130 @@ static inline int qzo_take(const qzo_profile_t *pf, const qzo_cand_t *c)
     return c->len != 0 && c->len >= qzo_min_len(pf, c->off);
 }
 
+/* start flag of the plain parse: a usable candidate that none of the lazy rules defers */
+static inline int qzo_is_start(const qzo_profile_t *pf, const qzo_cand_t *cand, uint32_t nh, uint32_t p)
+{
+    if (!qzo_take(pf, &cand[p])) return 0;
+    if (pf->lazy && p + 1 < nh && (p & 63u) < 63u && qzo_take(pf, &cand[p + 1]) && cand[p + 1].len > cand[p].len) return 0;
+    if (pf->lazy >= 2 && p + 2 < nh && (p & 63u) < 62u && qzo_take(pf, &cand[p + 2]) && cand[p + 2].len > cand[p].len) return 0;
+    if (pf->lazy >= 3 && p + 3 < nh && (p & 63u) < 61u && qzo_take(pf, &cand[p + 3]) && cand[p + 3].len > cand[p].len + 2u)
+        return 0;
+    return 1;
+}
+
+/* a match found with its length capped at `from` bytes is extended to its true end, but never past the
+ * end of the NEXT 1<<extLog cell: bounds the parallel extension work (a longer repeat simply continues
+ * as another sequence) */
+static inline uint32_t qzo_extend(const qzo_profile_t *pf, const uint8_t *src, uint32_t n, uint32_t p, uint32_t off,
+                                  uint32_t from)
+{
+    const uint32_t l0 = ((p >> pf->extLog) + 2u) << pf->extLog;
+    const uint32_t lim = l0 < n ? l0 : n;
+    const uint32_t q = p - off;
+    uint32_t L = from;
+    while (p + L < lim && src[q + L] == src[p + L]) L++;
+    return L;
+}
+
+/* "price" of taking a match, in quarter bytes saved: 4 per matched byte minus the bits of the offset;
+ * a repeated offset is nearly free.  0 = no match.  Always > 0 for a usable candidate. */
+#define QZO_REP_CAP 16u   /* repeat-offset probes compare this many bytes; a full hit always wins */
+#define QZO_REP_MIN 3u
+static inline uint32_t qzo_hash_gain(const qzo_profile_t *pf, const qzo_cand_t *c)
+{
+    if (!qzo_take(pf, c)) return 0;
+    return 4u * c->len + 32u - (31u - (uint32_t)__builtin_clz(c->off + 1u));
+}
+static inline uint32_t qzo_rep_gain(uint32_t l, uint32_t r)
+{
+    if (l < QZO_REP_MIN) return 0;
+    return l >= QZO_REP_CAP ? 1000u - r : 4u * l + 36u - r;
+}
+
+/*
+ * Parse, repeat-offset aware variant (profile.repWin != 0).  Same candidates and the same start flags as
+ * the plain parse; in addition, on arrival at the end of a match, the next repWin positions (inside the
+ * current tile) are also tried with the last two distinct offsets; if any of those probes hits, the choice
+ * among {candidate, repeat 1, repeat 2} at those positions, and the one/two-position deferral, go by
+ * qzo_*_gain (otherwise the plain start flags decide, as if there were no repeats).
+ * Shaped for the kernel's parse wave: one 16-byte vector probe per arrival, no other new state than the
+ * two offsets.  libzstd encodes such offsets as repcodes when ZSTD_c_searchForExternalRepcodes is on.
+ */
+static size_t qzo_parse_rep(const qzo_profile_t *pf, const uint8_t *src, uint32_t n, uint32_t nh,
+                            const qzo_cand_t *cand, qzo_seq_t *out, size_t cap)
+{
+    uint32_t cur = 0, anchor = 0, rep[2] = { 0u, 0u };
+    int arrival = 0;
+    size_t ns = 0;
+    while (cur < nh) {
+        uint32_t q = 0, off = 0, L = 0, b = 0;
+        int found = 0;
+        if (arrival && rep[0] != 0u) {
+            const uint32_t tileEnd = ((cur >> pf->tileLog) + 1u) << pf->tileLog;
+            const uint32_t lim = tileEnd < nh ? tileEnd : nh;
+            const uint32_t W = pf->repWin < lim - cur ? pf->repWin : lim - cur;       /* positions probed with the repeats */
+            const uint32_t V = W + 2u < lim - cur ? W + 2u : lim - cur;               /* ... + look-ahead for the deferral */
+            uint32_t G[34], opt[34], k, r, hits = 0;
+            for (k = 0; k < V; k++) {
+                const uint32_t p = cur + k;
+                G[k] = qzo_hash_gain(pf, &cand[p]);
+                opt[k] = 0;
+                for (r = 0; r < 2u && k < W; r++) {
+                    if (rep[r] != 0u) {
+                        const uint32_t mx = n - p < QZO_REP_CAP ? n - p : QZO_REP_CAP;
+                        const uint32_t g = qzo_rep_gain(qzo_prefix_len(src, p - rep[r], p, mx), r);
+                        hits += g != 0u;
+                        if (g > G[k]) { G[k] = g; opt[k] = 1u + r; }
+                    }
+                }
+            }
+            if (!hits) { arrival = 0; continue; } /* no repeat in reach: the plain start flags decide from here */
+            for (k = 0; k < W && !found; k++) {
+                if (G[k] == 0u) continue;
+                if (k + 1u < V && G[k + 1u] > G[k] + 4u) continue;
+                if (k + 2u < V && G[k + 2u] > G[k] + 11u) continue;
+                found = 1;
+                q = cur + k;
+                if (opt[k]) {
+                    const uint32_t mx = n - q < QZO_REP_CAP ? n - q : QZO_REP_CAP;
+                    off = rep[opt[k] - 1u];
+                    L = qzo_prefix_len(src, q - off, q, mx);
+                    if (L == QZO_REP_CAP) L = qzo_extend(pf, src, n, q, off, L);
+                } else {
+                    off = cand[q].off;
+                    L = cand[q].len;
+                    if (L == pf->capLen) L = qzo_extend(pf, src, n, q, off, L);
+                }
+            }
+            if (!found) { cur += W; arrival = 0; continue; }
+        } else {
+            while (cur < nh && !qzo_is_start(pf, cand, nh, cur)) cur++;
+            if (cur >= nh) break;
+            q = cur;
+            off = cand[q].off;
+            L = cand[q].len;
+            if (L == pf->capLen) L = qzo_extend(pf, src, n, q, off, L);
+        }
+        while (b < pf->backExt && q - b > anchor && q - off - b > 0 && src[q - b - 1] == src[q - off - b - 1]) b++;
+        if (ns + 1 >= cap - 1) return QZO_ERROR; /* src/qatseqprod.c:1073-1076 */
+        out[ns].offset = off;
+        out[ns].litLength = q - b - anchor;
+        out[ns].matchLength = L + b;
+        out[ns].rep = 0;
+        ns++;
+        if (off != rep[0]) { rep[1] = rep[0]; rep[0] = off; }
+        cur = anchor = q + L;
+        arrival = 1;
+    }
+    out[ns].offset = 0; /* trailing literals delimiter, src/qatseqprod.c:1037-1045 */
+    out[ns].litLength = n - anchor;
+    out[ns].matchLength = 0;
+    out[ns].rep = 0;
+    ns++;
+    if (ns >= cap - 1) ns = QZO_ERROR; /* src/qatseqprod.c:1318 */
+    return ns;
+}
+
 size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t srcSize,
                           qzo_seq_t *out, size_t cap)
 {
@@ -217,7 +346,7 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
 
     if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
-        pf->capLen < pf->minMatch + 2 || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
+        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
         return QZO_ERROR;
     nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
 
@@ -229,6 +358,10 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
 
     qzo_candidates(pf, src, n, cand, tbl, near, tblL);
 
+    if (pf->repWin) {
+        ns = qzo_parse_rep(pf, src, n, nh, cand, out, cap);
+        goto done;
+    }
     while (p < nh) {
         uint32_t L, off, q, b = 0;
         if (!qzo_take(pf, &cand[p])) { p++; continue; }

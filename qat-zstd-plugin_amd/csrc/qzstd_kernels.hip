@@ -80,8 +80,10 @@ typedef unsigned long long u64;
 /* profiling build (-DQZ_DEBUG_DUMP): phases can be switched off and per-wave cycle counts are dumped */
 #ifdef QZ_DEBUG_DUMP
 #define QZ_ABLATED(bit) (args.dbg & (bit))
+#define QZ_DBG args.dbg
 #else
 #define QZ_ABLATED(bit) false
+#define QZ_DBG 0u
 #endif
 
 /* v_readlane_b32 with an unsigned result (the builtin returns int: a set bit 31 would sign-extend) */
@@ -89,6 +91,7 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 below(uint32_t c) { return c >= 64u ? ~0ull : ((1ull << c) - 1ull); }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 /* where the block's bytes can be read from: the LDS ring (recent bytes) or HBM (anything) */
 struct Src {
@@ -158,6 +161,18 @@ __device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&own)
     return L;
 }
 
+/* first mismatching byte (0..16) of two 16-byte strings held as 5 aligned dwords each */
+__device__ __forceinline__ uint32_t cmp16(const uint32_t (&A)[5], uint32_t as, const uint32_t (&Bv)[5], uint32_t bs)
+{
+    uint32_t L = 16u;
+#pragma unroll
+    for (int i = 3; i >= 0; i--) {
+        const uint32_t x = __builtin_amdgcn_alignbyte(A[i + 1], A[i], as) ^ __builtin_amdgcn_alignbyte(Bv[i + 1], Bv[i], bs);
+        if (x) L = 4u * (uint32_t)i + ((uint32_t)__builtin_ctz(x) >> 3);
+    }
+    return L;
+}
+
 __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint32_t off)
 {
     return pf.minMatch + ((off >> pf.farLog1) ? 1u : 0u) + ((off >> pf.farLog2) ? 1u : 0u);
@@ -215,6 +230,7 @@ struct ParseState {
  * literal anchor at entry, index of the first sequence, up to two (lane, extended length)}.
  */
 constexpr uint32_t kSrecWords = 8;
+constexpr uint32_t kPvStride = kTile + 8u; /* parse words of one tile (+ room for the override of its last position) */
 constexpr uint32_t kNxCapped = 255u;
 
 __device__ __forceinline__ uint32_t pack_pos(uint32_t nx, uint32_t ns, uint32_t payload)
@@ -298,17 +314,172 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
     }
 }
 
+/*
+ * Repeat-offset aware parse (profile.repWin != 0; oracle: qzo_parse_rep).  Same candidates and the same
+ * start flags; in addition, on arrival at the end of a match the next repWin positions (inside the tile)
+ * are probed with the last two offsets: lane k holds {candidate, repeat 1, repeat 2} of position cur+k,
+ * 16 bytes compared per probe, everything in one LDS round trip; if any probe hits, the choice and
+ * the one/two position deferral go by gain (4 per byte, minus the offset bits for a candidate, a full probe hit always
+ * wins).  Per position the matchers leave   ns (7 bits) | capped length (7) | offset (17).
+ * A chosen match that is not simply "the candidate as found" (a repeat, or an extended one) is written
+ * back over the parse words of its first two positions (behind the cursor: dead) for the emitting wave.
+ */
+struct RepState {
+    uint32_t cur, anchor, nseq;
+    uint32_t rep1, rep2; /* the last two distinct offsets */
+    uint32_t arrival;    /* standing at the end of a match */
+    /* the emission record being collected: its 64-position window (kNone = none) and contents */
+    uint32_t win, anchorIn, seqBase;
+    u64 chosen, ov;
+};
+constexpr uint32_t kRepCap = 16u, kRepMin = 3u;
+
+/* publish the record of the window being collected (srecT = the tile's records, base = the tile's first position) */
+__device__ __forceinline__ void rep_flush(RepState &st, uint32_t *srecT, uint32_t base, uint32_t lane)
+{
+    if (st.win != kNone && lane == 0u) {
+        uint32_t *r = srecT + ((st.win - base) >> 6) * kSrecWords;
+        *reinterpret_cast<uint4 *>(r) = make_uint4((uint32_t)st.chosen, (uint32_t)(st.chosen >> 32), st.anchorIn, st.seqBase);
+        *reinterpret_cast<uint2 *>(r + 4) = make_uint2((uint32_t)st.ov, (uint32_t)(st.ov >> 32));
+    }
+    st.win = kNone;
+}
+
+/* parse from the cursor up to `limit` (a window boundary inside the tile that starts at `base`).  A plain
+ * loop over cursor positions, not unrolled over windows: the parse words are read from LDS (a window at a
+ * time for the start-flag chase, the probe window directly), which keeps the code small and the state in
+ * SGPRs. */
+__device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, const Src &src, uint32_t *pvT, uint32_t *srecT,
+                                               uint32_t base, uint32_t limit, uint32_t n, uint32_t nh, uint32_t lane,
+                                               RepState &st, uint32_t dbg = 0u)
+{
+    const uint32_t tileLim = umin(base + kTile, nh);
+    uint32_t wv = 0, cw0 = kNone; /* parse words of the window the chase is in */
+    while (st.cur < limit && st.cur < nh) {
+        const uint32_t w0 = st.cur & ~63u, c = st.cur & 63u;
+        uint32_t q, off, L;
+        bool needOv = false;
+        if (st.arrival && st.rep1 != 0u && !(dbg & 64u)) {
+            const uint32_t W = umin(pf.repWin, tileLim - st.cur), V = umin(W + 2u, tileLim - st.cur);
+            const uint32_t p = st.cur + lane; /* lanes 0..V-1 stand on the positions of the probe window */
+            /* one LDS round trip: the position's parse word (never overwritten at or after the cursor), its
+             * own 16 bytes, and the 16 bytes one repeat offset back, for both offsets */
+            uint32_t wd = 0, rl1 = 0, rl2 = 0;
+            if (lane < V) wd = pvT[p - base];
+            if (lane < W) {
+                const uint32_t q1 = p - st.rep1, q2 = p - (st.rep2 != 0u ? st.rep2 : st.rep1);
+                uint32_t own[5], Q1[5], Q2[5];
+                load_dw<5>(src, p, false, own);
+                if (umax(st.rep1, st.rep2) <= kNear) { /* uniform: both sources in the ring (the usual case) */
+                    load_dw<5>(src, q1, false, Q1);
+                    load_dw<5>(src, q2, false, Q2);
+                } else {
+                    load_dw<5>(src, q1, st.rep1 > kNear, Q1);
+                    load_dw<5>(src, q2, st.rep2 > kNear, Q2);
+                }
+                rl1 = umin(cmp16(own, p & 3u, Q1, q1 & 3u), n - p);
+                rl2 = st.rep2 != 0u ? umin(cmp16(own, p & 3u, Q2, q2 & 3u), n - p) : 0u;
+            }
+            const uint32_t rg1 = rl1 < kRepMin ? 0u : (rl1 >= kRepCap ? 1000u : 4u * rl1 + 36u);
+            const uint32_t rg2 = rl2 < kRepMin ? 0u : (rl2 >= kRepCap ? 999u : 4u * rl2 + 35u);
+            if (!__ballot((rg1 | rg2) != 0u) || (dbg & 128u)) { /* no repeat in reach: the plain start flags decide from here */
+                st.arrival = 0u;
+                continue;
+            }
+            const uint32_t cl = (wd >> 7) & 0x7Fu, co = wd >> 14;
+            uint32_t G = 0, opt = 0;
+            if (cl != 0u && cl >= min_len(pf, co)) G = 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(co + 1u));
+            if (rg1 > G) { G = rg1; opt = 1u; }
+            if (rg2 > G) { G = rg2; opt = 2u; }
+            /* the gains one and two positions on: DPP row shifts (the window lives in lanes 0-15 = one row) */
+            const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x101, 0xF, 0xF, true);
+            const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x102, 0xF, 0xF, true);
+            const bool ok = lane < W && G != 0u && !(G1 > G + 4u) && !(G2 > G + 11u);
+            const u64 m = __ballot(ok);
+            if (!m) {
+                st.cur += W;
+                st.arrival = 0u;
+                continue;
+            }
+            const uint32_t ks = (uint32_t)__builtin_ctzll(m);
+            const uint32_t o = rdlane(opt, ks);
+            q = st.cur + ks;
+            uint32_t from;
+            if (o == 0u) {
+                off = rdlane(co, ks);
+                L = rdlane(cl, ks);
+                from = pf.capLen;
+            } else {
+                off = o == 1u ? st.rep1 : st.rep2;
+                L = rdlane(o == 1u ? rl1 : rl2, ks);
+                from = kRepCap;
+                needOv = true;
+            }
+            if (L == from) {
+                L = extend_match(src, q, off, from, umin(n, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
+                needOv = true;
+            }
+        } else {
+            if (w0 != cw0) {
+                wv = pvT[w0 - base + lane];
+                cw0 = w0;
+            }
+            const uint32_t j = rdlane(wv, c) & 0x7Fu; /* next start flag at/after the cursor */
+            if (j >= 64u) {
+                st.cur = w0 + 64u;
+                continue;
+            }
+            const uint32_t wd = rdlane(wv, j);
+            q = w0 + j;
+            L = (wd >> 7) & 0x7Fu;
+            off = wd >> 14;
+            if (L == pf.capLen) {
+                L = extend_match(src, q, off, L, umin(n, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
+                needOv = true;
+            }
+        }
+        if (needOv && lane == 0u) {
+            pvT[q - base] = off;
+            pvT[q - base + 1u] = L;
+        }
+        if ((q & ~63u) != st.win) {
+            rep_flush(st, srecT, base, lane);
+            st.win = q & ~63u;
+            st.chosen = st.ov = 0ull;
+            st.anchorIn = st.anchor;
+            st.seqBase = st.nseq;
+        }
+        st.chosen |= 1ull << (q & 63u);
+        if (needOv) st.ov |= 1ull << (q & 63u);
+        st.nseq++;
+        if (off != st.rep1) {
+            st.rep2 = st.rep1;
+            st.rep1 = off;
+        }
+        st.cur = st.anchor = q + L;
+        st.arrival = 1u;
+    }
+}
+
 /* emission of one window's chosen matches by the wave that owns the window */
+template <bool REP>
 __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *srec,
-                                            uint32_t off, uint32_t len, uint32_t w0, uint32_t lane, uint4 *out,
-                                            uint32_t seqCap)
+                                            const uint32_t *pvW, uint32_t off, uint32_t len, uint32_t w0, uint32_t lane,
+                                            uint4 *out, uint32_t seqCap)
 {
     const uint4 rec = *reinterpret_cast<const uint4 *>(srec);
     const u64 chosen = (u64)rec.x | ((u64)rec.y << 32);
     if (!chosen) return;
     const uint32_t anchorIn = rec.z, seqBase = rec.w, ext0 = srec[4], ext1 = srec[5];
-    if (ext0 && (ext0 >> 24) == lane) len = ext0 & 0xFFFFFFu; /* extended by the parse wave */
-    if (ext1 && (ext1 >> 24) == lane) len = ext1 & 0xFFFFFFu;
+    if (REP) { /* words 4-5 = mask of the chosen matches the parse wave rewrote (repeat offset / extended) */
+        if ((((u64)ext0 | ((u64)ext1 << 32)) >> lane) & 1ull) {
+            off = pvW[lane];
+            len = pvW[lane + 1u];
+        }
+    } else {
+        if (ext0 && (ext0 >> 24) == lane) len = ext0 & 0xFFFFFFu; /* extended by the parse wave */
+        if (ext1 && (ext1 >> 24) == lane) len = ext1 & 0xFFFFFFu;
+    }
     const bool ch = (chosen >> lane) & 1ull;
     const u64 lower = chosen & below(lane);
     const uint32_t rank = (uint32_t)__popcll(lower);
@@ -349,7 +520,7 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
  *
  * HAS_LONG selects the level >= 3 variant with the second (8-byte-key) table.
  */
-template <bool HAS_LONG>
+template <bool HAS_LONG, bool REP>
 __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -372,7 +543,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     uint32_t *tblL = tbl + pf.tableSize;               /* [longSize]    8-byte-key table (levels >= 3)    */
     uint32_t *nearTab = tblL + pf.longSize;
     uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
-    uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kTile]    per-position parse words          */
+    uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kPvStride] per-position parse words         */
     const uint8_t *gsrc = args.src + blk.srcOff;
     const uint4 *g128 = reinterpret_cast<const uint4 *>(gsrc);
     Src src;
@@ -390,7 +561,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         }
         for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
-        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kTile; i += kThreads) srec[i] = 0u; /* srec, pv */
+        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride; i += kThreads) srec[i] = 0u; /* srec, pv */
     }
     __syncthreads();
 
@@ -399,7 +570,6 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
         if (!QZ_ABLATED(32u)) __builtin_amdgcn_s_setprio(3); /* the serial critical path: win issue arbitration on its SIMD */
-        ParseState st = { 0u, 0u, 0u };
         constexpr uint32_t kSplit = 2; /* windows parsed in interval 1 (the short one), the rest in interval 2 */
 #ifdef QZ_DEBUG_DUMP
         u64 pI1 = 0, pW1 = 0, pI2 = 0, pW2 = 0, tQ = __builtin_amdgcn_s_memtime();
@@ -407,29 +577,58 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #else
 #define QZ_PLAP(acc)
 #endif
-        for (uint32_t it = 0; it < nTiles + 2u; it++) {
-            const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
-            const uint32_t k = it - 1u;
-            if (work)
-                parse_tile<0, kSplit>(pf, src, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog,
-                                      n, lane, st);
-            QZ_PLAP(pI1)
-            __syncthreads(); /* B1 */
-            QZ_PLAP(pW1)
-            if (work)
-                parse_tile<kSplit, kWin>(pf, src, pv + (k & 1u) * kTile, srec + (k & 1u) * kWin * kSrecWords,
-                                         k << kTileLog, n, lane, st);
-            QZ_PLAP(pI2)
-            __syncthreads(); /* B2 */
-            QZ_PLAP(pW2)
+        uint32_t nseqEnd, anchorEnd;
+        if (REP) {
+            RepState st = { 0u, 0u, 0u, 0u, 0u, 0u, kNone, 0u, 0u, 0ull, 0ull };
+            for (uint32_t it = 0; it < nTiles + 2u; it++) {
+                const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
+                const uint32_t k = it - 1u, base = k << kTileLog;
+                uint32_t *pvT = pv + (k & 1u) * kPvStride, *srecT = srec + (k & 1u) * kWin * kSrecWords;
+                if (work) {
+                    if (lane < kWin) *reinterpret_cast<uint2 *>(srecT + lane * kSrecWords) = make_uint2(0u, 0u); /* nothing chosen yet */
+                    parse_rep_span(pf, src, pvT, srecT, base, base + 64u * kSplit, n, nh, lane, st, QZ_DBG);
+                }
+                QZ_PLAP(pI1)
+                __syncthreads(); /* B1 */
+                QZ_PLAP(pW1)
+                if (work) {
+                    parse_rep_span(pf, src, pvT, srecT, base, base + kTile, n, nh, lane, st, QZ_DBG);
+                    rep_flush(st, srecT, base, lane);
+                }
+                QZ_PLAP(pI2)
+                __syncthreads(); /* B2 */
+                QZ_PLAP(pW2)
+            }
+            nseqEnd = st.nseq;
+            anchorEnd = st.anchor;
+        } else {
+            ParseState st = { 0u, 0u, 0u };
+            for (uint32_t it = 0; it < nTiles + 2u; it++) {
+                const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
+                const uint32_t k = it - 1u;
+                if (work)
+                    parse_tile<0, kSplit>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
+                                          k << kTileLog, n, lane, st);
+                QZ_PLAP(pI1)
+                __syncthreads(); /* B1 */
+                QZ_PLAP(pW1)
+                if (work)
+                    parse_tile<kSplit, kWin>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
+                                             k << kTileLog, n, lane, st);
+                QZ_PLAP(pI2)
+                __syncthreads(); /* B2 */
+                QZ_PLAP(pW2)
+            }
+            nseqEnd = st.nseq;
+            anchorEnd = st.anchor;
         }
 #ifdef QZ_DEBUG_DUMP
         if (lane == 0) out[blk.seqCap - 2u] = make_uint4((uint32_t)pI1, (uint32_t)pW1, (uint32_t)pI2, (uint32_t)pW2);
 #endif
         if (lane == 0) {
             /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
-            uint32_t count = st.nseq + 1u;
-            if (st.nseq < blk.seqCap) out[st.nseq] = make_uint4(0u, n - st.anchor, 0u, 0u);
+            uint32_t count = nseqEnd + 1u;
+            if (nseqEnd < blk.seqCap) out[nseqEnd] = make_uint4(0u, n - anchorEnd, 0u, 0u);
             if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
             args.nseq[blockIdx.x] = count;
         }
@@ -471,8 +670,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         const bool refill = it >= 1u && tid < kTile / 16u && fpos < nPad;
         if (refill) fresh = g128[fpos >> 4];
         if (it >= 2u && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
-            emit_window(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, offB, lenB, t0 - 2u * kTile + 64u * wave,
-                        lane, out, blk.seqCap);
+            emit_window<REP>(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, pv + (it & 1u) * kPvStride + 64u * wave,
+                             offB, lenB, t0 - 2u * kTile + 64u * wave, lane, out, blk.seqCap);
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
         const bool validL = HAS_LONG && valid && p + 8u <= n;
         if (valid) { /* phase A(it) */
@@ -566,7 +765,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             const u64 rest = endj < 64u ? startMask >> endj : 0ull;
             uint32_t nx = endj >= 64u ? endj : (rest ? endj + (uint32_t)__builtin_ctzll(rest) : 64u);
             nx = capped ? kNxCapped : nx;
-            pv[(it & 1u) * kTile + tid] = pack_pos(nx, ns, capped ? off : cl);
+            pv[(it & 1u) * kPvStride + tid] = REP ? (ns | (cl << 7) | (off << 14)) : pack_pos(nx, ns, capped ? off : cl);
         }
         offA = off;
         lenA = cl;
@@ -720,20 +919,21 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (!d_src || !d_blocks || !d_seqs || !d_nseq) return fail_msg("qzstd_hip_find_sequences: null pointer");
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX) return fail_msg("qzstd_hip_find_sequences: block larger than 128 KiB");
     if (qzstd_hip_profile_for_level(level, maxBlockLen, &a.prof))
-        return fail_msg("qzstd_hip_find_sequences: level outside 1..12");
+        return fail_msg("qzstd_hip_find_sequences: level outside 1..12 (optionally | QZSTD_HIP_LEVEL_REPCODES)");
     if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
-        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8)
+        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 8)
         return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");
     QZ_CHECK(hipSetDevice(device), "hipSetDevice");
     if (attrDevice != device || attrBytes < lds) {
-        QZ_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        QZ_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        const void *variants[4] = { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false>),
+                                    reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false>),
+                                    reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true>),
+                                    reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true>) };
+        for (int v = 0; v < 4; v++)
+            QZ_CHECK(hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                     "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         attrDevice = device;
         attrBytes = lds;
     }
@@ -744,10 +944,15 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
 #ifdef QZ_DEBUG_DUMP
     { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
 #endif
-    if (a.prof.longSize)
-        hipLaunchKernelGGL(qzstd_find_sequences_kernel<true>, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
+    const dim3 grid(nBlocks), wg(kThreads);
+    if (a.prof.longSize && a.prof.repWin)
+        hipLaunchKernelGGL((qzstd_find_sequences_kernel<true, true>), grid, wg, lds, (hipStream_t)stream, a);
+    else if (a.prof.longSize)
+        hipLaunchKernelGGL((qzstd_find_sequences_kernel<true, false>), grid, wg, lds, (hipStream_t)stream, a);
+    else if (a.prof.repWin)
+        hipLaunchKernelGGL((qzstd_find_sequences_kernel<false, true>), grid, wg, lds, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(qzstd_find_sequences_kernel<false>, dim3(nBlocks), dim3(kThreads), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((qzstd_find_sequences_kernel<false, false>), grid, wg, lds, (hipStream_t)stream, a);
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;
 }

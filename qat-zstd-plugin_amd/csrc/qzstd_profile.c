@@ -9,7 +9,7 @@
  * LDS budget per workgroup (gfx950: 160 KiB = 163840 B per CU, target: TWO workgroups per CU):
  *     48 KiB ring of recent block bytes (+128 B wrap mirror) + 4*tableSize + near table 4<<tileLog
  *     + 2 tiles of per-position parse words + per-window emission records + 64 B control
- *     = 81 600 B with 6400 table entries at tileLog 9.
+ *     = 81 664 B with 6400 table entries at tileLog 9.
  */
 #include "qzstd_hip.h"
 
@@ -21,6 +21,8 @@
 
 int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t *out)
 {
+    const int repcodes = (level & QZSTD_HIP_LEVEL_REPCODES) != 0;
+    level &= ~QZSTD_HIP_LEVEL_REPCODES;
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
     (void)blockSize; /* the profile does not depend on the block size: the LDS footprint is fixed (ring + tables) */
@@ -40,6 +42,9 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     out->window = 0;
     out->hashBytes = 5;
     out->extLog = 11;
+    /* libzstd turns repeat offsets of external sequences into repcodes only from level 10 (or when the
+     * caller sets ZSTD_c_searchForExternalRepcodes); without that, short repeat matches cost a full offset */
+    out->repWin = (repcodes || level >= 10) ? 8u : 0u;
     return 0;
 }
 
@@ -50,7 +55,7 @@ size_t qzstd_hip_sequence_bound(size_t srcSize)
 
 #define QZ_RING_BYTES (49152u + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip) */
 
-/* LDS per workgroup: independent of the block size — 81 600 B at levels 1-2 (two workgroups per CU) */
+/* LDS per workgroup: independent of the block size — 81 664 B at levels 1-2 (two workgroups per CU) */
 size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
 {
     qzstd_hip_profile_t p;
@@ -60,7 +65,7 @@ size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
            + 4u * p.tableSize        /* hash table                                    */
            + 4u * p.longSize         /* 8-byte-key table (levels >= 3)                */
            + (4u << p.tileLog)     /* tile-local near table                         */
-           + 2u * (4u << p.tileLog) /* per-position parse words, 2 tiles in flight */
+           + 2u * ((4u << p.tileLog) + 32u) /* per-position parse words (+ override spill), 2 tiles in flight */
            + 2u * ((1u << p.tileLog) >> 6) * 32u /* per-window emission records, x2 */
            + QZ_LDS_CTRL;
     return need <= QZ_LDS_MAX ? need : 0;

@@ -124,10 +124,11 @@ typedef struct {
     QZSTD_Slot_T *slots;
     QZSTD_Coalescer_T *coal; /* one per device */
     int coalesce;            /* QZSTD_HIP_COALESCE (default 1) */
+    int levelFlags;          /* QZSTD_HIP_LEVEL_REPCODES when QZSTD_HIP_EXT_REPCODES=1 */
     pthread_mutex_t mutex;
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, PTHREAD_MUTEX_INITIALIZER };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, PTHREAD_MUTEX_INITIALIZER };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously on a slot's stream,
  * results (count + the first QZ_HINT_PITCH sequences of every block) copied back asynchronously. */
@@ -432,7 +433,11 @@ int QZSTD_startQatDevice(void)
     pthread_mutex_lock(&gProc.mutex);
     {
         const char *dbg = getenv("QZSTD_HIP_DEBUG");
+        const char *rep = getenv("QZSTD_HIP_EXT_REPCODES");
         if (dbg && *dbg) qzLogLevel = atoi(dbg);
+        /* the caller promises ZSTD_c_searchForExternalRepcodes = enable on its CCtx (libzstd's default only
+         * from level 10): repeat-offset aware sequences at every level */
+        gProc.levelFlags = (rep && atoi(rep) > 0) ? QZSTD_HIP_LEVEL_REPCODES : 0;
     }
     if (gProc.status == QZSTD_FAIL) {
         /* runtime up? (reference: QZSTD_salUserStart, :498-527) */
@@ -630,7 +635,8 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
         /* sticky device per state, states spread round-robin over the GPUs */
         static volatile int nextDev = 0;
         if (s->slotHint < 0) s->slotHint = __sync_fetch_and_add(&nextDev, 1);
-        rc = qzCoalescedBlock(s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize, compressionLevel);
+        rc = qzCoalescedBlock(s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize,
+                              compressionLevel | gProc.levelFlags);
         if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
         QZ_LOG(2, "block %zu B level %d -> %zu sequences (coalesced, device %d)\n", srcSize, compressionLevel, rc,
                s->slotHint % gProc.numDevices);
@@ -643,7 +649,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     }
     s->slotHint = i;
     if (qzSetupSlot(&gProc.slots[i]) == QZSTD_OK) {
-        rc = qzRunBlock(&gProc.slots[i], outSeqs, outSeqsCapacity, src, srcSize, compressionLevel);
+        rc = qzRunBlock(&gProc.slots[i], outSeqs, outSeqsCapacity, src, srcSize, compressionLevel | gProc.levelFlags);
         if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
     }
     QZ_LOG(2, "block %zu B level %d -> %zu sequences (slot %d, device %d)\n", srcSize, compressionLevel, rc, i,
@@ -756,7 +762,7 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     /* everything below is queued on the slot's stream and returns immediately */
     if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc, srcBytes) ||
         qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchDesc, h->hDesc, blocksBytes) ||
-        qzstd_hip_find_sequences(sl->device, sl->stream, compressionLevel, sl->dBatchSrc, sl->dBatchDesc,
+        qzstd_hip_find_sequences(sl->device, sl->stream, compressionLevel | gProc.levelFlags, sl->dBatchSrc, sl->dBatchDesc,
                                  (unsigned int)nb, (unsigned int)blockSize, sl->dBatchSeqs, sl->dBatchCount) ||
         qzstd_hip_memcpy_d2h(sl->device, sl->stream, h->hCount, sl->dBatchCount, nb * sizeof(unsigned int)) ||
         qzstd_hip_memcpy2d_d2h(sl->device, sl->stream, h->hSeqs, QZ_HINT_PITCH * sizeof(ZSTD_Sequence), sl->dBatchSeqs,

@@ -71,14 +71,22 @@ def test_version_matches_reference_macros(plugin):
 
 
 # ------------------------------------------------------------------ level tables / LDS budget
-@pytest.mark.parametrize("level", range(1, 13))
+@pytest.mark.parametrize("level", list(range(1, 13)) + [0x100 | l for l in range(1, 13)])
 @pytest.mark.parametrize("block", [1, 1000, 32768, 32769, 65536, 65537, 100000, 131072])
 def test_profile_tables_agree(plugin, oracle, level, block):
     assert plugin.profile(level, block).as_dict() == oracle.profile(level, block).as_dict()
 
 
+def test_repcode_aware_parse_follows_libzstd_default(plugin):
+    """libzstd resolves ZSTD_c_searchForExternalRepcodes = auto to "on" from level 10; below that the
+    caller has to ask for it (level | QZSTD_HIP_LEVEL_REPCODES, env QZSTD_HIP_EXT_REPCODES=1)"""
+    for level in range(1, 13):
+        assert (plugin.profile(level, 131072).repWin != 0) == (level >= 10)
+        assert plugin.profile(level | 0x100, 131072).repWin == 8
+
+
 def test_profile_rejects_bad_levels(plugin, oracle):
-    for lvl in (0, -1, 13, 22):
+    for lvl in (0, -1, 13, 22, 0x100, 0x10D, 0x201):
         assert plugin.lib.qzstd_hip_profile_for_level(lvl, 131072, C.byref(B.HipProfile())) != 0
         assert oracle.lib.qzo_profile_for_level(lvl, 131072, C.byref(B.OracleProfile())) != 0
 

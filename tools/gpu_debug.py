@@ -7,12 +7,13 @@ import qz_bind as B, qz_corpus as K
 
 def main():
     plug, orc = B.Plugin(), B.Oracle()
+    level = int(os.environ.get("QZ_LEVEL", "1"), 0)  # e.g. 0x106 = level 6 | QZSTD_HIP_LEVEL_REPCODES
     sizes = [int(a) for a in sys.argv[1:]] or [600, 1500, 3000, 9000, 131072]
-    base = K.text(1, 140000)
+    base = K.by_name(os.environ.get("QZ_CORPUS", "text"), 140000)
     for n in sizes:
         blk = base[:n]
-        counts, seqs, stride = plug.find_batch([blk], 1)
-        want_n, want = orc.find(orc.profile(1, n), blk, cap=stride)
+        counts, seqs, stride = plug.find_batch([blk], level)
+        want_n, want = orc.find(orc.profile(level, n), blk, cap=stride)
         g = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)[:max(counts[0], 1) if counts[0] != B.NSEQ_ERROR else 1, :3]
         w = np.frombuffer(want, dtype=np.uint32).reshape(-1, 4)[:want_n, :3]
         m = min(len(g), len(w))
@@ -24,13 +25,11 @@ def main():
             print("  at seq %d (block pos %d, window %d lane %d):" % (i, pos_g, pos_g // 64, pos_g % 64))
             for k in range(max(0, i - 2), min(m, i + 4)):
                 print("   %5d gpu %-22s oracle %-22s" % (k, g[k].tolist(), w[k].tolist()))
-main()
-
 def timing():
     plug = B.Plugin(os.path.join(B.PKG_DIR, "lib", "libqatseqprod_dbg.so"))
     data = K.system_corpus(256 * 131072)[0]
     blocks = [data[o:o + 131072] for o in range(0, len(data), 131072)]
-    counts, seqs, stride = plug.find_batch(blocks, 1)
+    counts, seqs, stride = plug.find_batch(blocks, int(os.environ.get("QZ_LEVEL", "1"), 0))
     a = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)
     rows = np.array([a[(i + 1) * stride - 1] for i in range(len(blocks))], dtype=np.float64)
     c = np.array(counts, dtype=np.float64)
@@ -44,3 +43,5 @@ def timing():
 
 if os.environ.get("QZ_TIMING"):
     timing()
+else:
+    main()

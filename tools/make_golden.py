@@ -29,7 +29,19 @@ CASES = [  # (generator, seed, blockSize, nBlocks, level)
     ("text", 1, 131072, 4, 1), ("text", 3, 131072, 2, 6), ("binary", 2, 131072, 4, 1),
     ("weblog", 4, 32768, 8, 12), ("weblog", 4, 131072, 2, 1), ("mixed_entropy", 5, 131072, 5, 3),
     ("mix", 2, 131072, 6, 1), ("mix", 2, 65536, 6, 1), ("random", 9, 131072, 1, 1), ("text", 7, 100001, 1, 1),
+    # level | 0x100 = the caller compresses with ZSTD_c_searchForExternalRepcodes on: repeat-offset aware parse
+    ("text", 1, 131072, 2, 0x101), ("binary", 2, 131072, 3, 0x106), ("mix", 2, 131072, 4, 0x103), ("weblog", 4, 32768, 4, 0x102),
 ]
+REP = 0x100
+
+
+def oracle_cctx(z, orc, level, block):
+    """CCtx with the oracle registered; a flagged level passes its profile explicitly and turns the
+    external repcode search on (what a caller of the plugin does together with QZSTD_HIP_EXT_REPCODES=1)"""
+    if level & REP:
+        prof = orc.profile(level, block)
+        return z.cctx(level & ~REP, producer=orc.producer_addr, state=B.C.addressof(prof), validate=True, ext_repcodes=1), prof
+    return z.cctx(level, producer=orc.producer_addr, state=None, validate=True), None
 
 
 def main():
@@ -37,10 +49,10 @@ def main():
     rows = []
     for gen, seed, block, nb, level in CASES:
         data = K.by_name(gen, block * nb, seed)
-        zc = z.cctx(level)
+        zc = z.cctx(level & ~REP)
         sw, _ = z.compress_chunks(zc, data, block)
         z.free(zc)
-        zc = z.cctx(level, producer=orc.producer_addr, state=None, validate=True)
+        zc, keep = oracle_cctx(z, orc, level, block)
         got, frames = z.compress_chunks(zc, data, block)
         z.free(zc)
         assert b"".join(z.decompress(f, block) for f in frames) == data
