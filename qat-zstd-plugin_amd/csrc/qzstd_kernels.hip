@@ -94,9 +94,12 @@ __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b 
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 /* where the block's bytes can be read from: the LDS ring (recent bytes) or HBM (anything) */
+/* explicit address spaces: through generic pointers the compiler falls back to FLAT loads for the ring */
+typedef const __attribute__((address_space(3))) uint32_t *LdsWords;
+typedef const __attribute__((address_space(1))) uint32_t *HbmWords;
 struct Src {
-    const uint32_t *ring; /* LDS, kRing + kMirror bytes */
-    const uint32_t *g;    /* the block in HBM; 16-byte aligned, so aligned dword loads work */
+    LdsWords ring; /* LDS, kRing + kMirror bytes */
+    HbmWords g;    /* the block in HBM; 16-byte aligned, so aligned dword loads work */
 };
 
 /* dword index inside the ring of byte position a (a < 3 * kRing) */
@@ -547,8 +550,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     const uint8_t *gsrc = args.src + blk.srcOff;
     const uint4 *g128 = reinterpret_cast<const uint4 *>(gsrc);
     Src src;
-    src.ring = ring32;
-    src.g = reinterpret_cast<const uint32_t *>(gsrc);
+    src.ring = (LdsWords)ring32;
+    src.g = (HbmWords)reinterpret_cast<const uint32_t *>(gsrc);
     const uint32_t nPad = (n + 15u) & ~15u; /* the caller keeps the buffer readable up to here */
 
     /* ---- prefill the ring with the first kTile + kLook bytes (16 B per lane, coalesced), clear the tables ---- */
