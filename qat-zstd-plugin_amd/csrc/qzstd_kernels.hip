@@ -164,18 +164,6 @@ __device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&own)
     return L;
 }
 
-/* first mismatching byte (0..16) of two 16-byte strings held as 5 aligned dwords each */
-__device__ __forceinline__ uint32_t cmp16(const uint32_t (&A)[5], uint32_t as, const uint32_t (&Bv)[5], uint32_t bs)
-{
-    uint32_t L = 16u;
-#pragma unroll
-    for (int i = 3; i >= 0; i--) {
-        const uint32_t x = __builtin_amdgcn_alignbyte(A[i + 1], A[i], as) ^ __builtin_amdgcn_alignbyte(Bv[i + 1], Bv[i], bs);
-        if (x) L = 4u * (uint32_t)i + ((uint32_t)__builtin_ctz(x) >> 3);
-    }
-    return L;
-}
-
 __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint32_t off)
 {
     return pf.minMatch + ((off >> pf.farLog1) ? 1u : 0u) + ((off >> pf.farLog2) ? 1u : 0u);
@@ -324,136 +312,125 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
  * 16 bytes compared per probe, everything in one LDS round trip; if any probe hits, the choice and
  * the one/two position deferral go by gain (4 per byte, minus the offset bits for a candidate, a full probe hit always
  * wins).  Per position the matchers leave   ns (7 bits) | capped length (7) | offset (17).
- * A chosen match that is not simply "the candidate as found" (a repeat, or an extended one) is written
- * back over the parse words of its first two positions (behind the cursor: dead) for the emitting wave.
+ * Every chosen match is written back over the parse words of its first three positions (behind the
+ * cursor: dead) as {offset, length, index, literal anchor} for the emitting wave: no masks, no ranks.
  */
 struct RepState {
     uint32_t cur, anchor, nseq;
     uint32_t rep1, rep2; /* the last two distinct offsets */
     uint32_t arrival;    /* standing at the end of a match */
-    /* the emission record being collected: its 64-position window (kNone = none) and contents */
-    uint32_t win, anchorIn, seqBase;
-    u64 chosen, ov;
+    uint32_t tileSeq;    /* nseq when the parse entered the tile being parsed */
 };
 constexpr uint32_t kRepCap = 16u, kRepMin = 3u;
+constexpr uint32_t kChosenBit = 0x80000000u; /* marks a parse-word slot rewritten into a chosen-match record */
 
-/* publish the record of the window being collected (srecT = the tile's records, base = the tile's first position) */
-__device__ __forceinline__ void rep_flush(RepState &st, uint32_t *srecT, uint32_t base, uint32_t lane)
+/* one byte of the block at position x: from the ring, or from HBM when `far` */
+__device__ __forceinline__ uint32_t ring_byte(const Src &s, uint32_t x, bool far)
 {
-    if (st.win != kNone && lane == 0u) {
-        uint32_t *r = srecT + ((st.win - base) >> 6) * kSrecWords;
-        *reinterpret_cast<uint4 *>(r) = make_uint4((uint32_t)st.chosen, (uint32_t)(st.chosen >> 32), st.anchorIn, st.seqBase);
-        *reinterpret_cast<uint2 *>(r + 4) = make_uint2((uint32_t)st.ov, (uint32_t)(st.ov >> 32));
-    }
-    st.win = kNone;
+    if (far) return reinterpret_cast<const __attribute__((address_space(1))) uint8_t *>(s.g)[x];
+    const uint32_t m = umin(x, x - kRing);
+    return reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(s.ring)[umin(m, m - kRing)];
 }
 
 /* parse from the cursor up to `limit` (a window boundary inside the tile that starts at `base`).  A plain
- * loop over cursor positions, not unrolled over windows: the parse words are read from LDS (a window at a
- * time for the start-flag chase, the probe window directly), which keeps the code small and the state in
- * SGPRs. */
+ * loop, one sequence per iteration: [probe the repeats on arrival] -> [else chase the start flags] ->
+ * record.  The parse words are read from LDS (a window at a time for the chase, the probe window
+ * directly), which keeps the code small and the state in SGPRs. */
 __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, const Src &src, uint32_t *pvT, uint32_t *srecT,
                                                uint32_t base, uint32_t limit, uint32_t n, uint32_t nh, uint32_t lane,
                                                RepState &st, uint32_t dbg = 0u)
 {
-    const uint32_t tileLim = umin(base + kTile, nh);
+    const uint32_t tileLim = umin(base + kTile, nh), stop = umin(limit, nh);
     uint32_t wv = 0, cw0 = kNone; /* parse words of the window the chase is in */
-    while (st.cur < limit && st.cur < nh) {
-        const uint32_t w0 = st.cur & ~63u, c = st.cur & 63u;
-        uint32_t q, off, L;
-        bool needOv = false;
+    while (st.cur < stop) {
+        uint32_t q = 0, off = 0, L = 0;
+        uint32_t from = pf.capLen; /* a length equal to this is a capped one: extend */
+        bool have = false;
         if (st.arrival && st.rep1 != 0u && !(dbg & 64u)) {
+            st.arrival = 0u;
             const uint32_t W = umin(pf.repWin, tileLim - st.cur), V = umin(W + 2u, tileLim - st.cur);
-            const uint32_t p = st.cur + lane; /* lanes 0..V-1 stand on the positions of the probe window */
-            /* one LDS round trip: the position's parse word (never overwritten at or after the cursor), its
-             * own 16 bytes, and the 16 bytes one repeat offset back, for both offsets */
-            uint32_t wd = 0, rl1 = 0, rl2 = 0;
-            if (lane < V) wd = pvT[p - base];
+            /* the probe, byte-wise across the wave: lane b (< 32) compares byte cursor+b with the byte one
+             * repeat-1 offset back, lane 32+b with repeat 2; the ballot is the equality bitmap of the next 32
+             * bytes for both offsets, and the match length at position cursor+k is the run of ones from
+             * bit k (8 positions x 16 bytes fit in 32).  One LDS round trip, a handful of instructions. */
+            const uint32_t bpos = st.cur + (lane & 31u);
+            const uint32_t rp = lane < 32u ? st.rep1 : st.rep2;
+            uint32_t wd = 0;
+            if (lane < V) wd = pvT[st.cur + lane - base]; /* parse word of the window position (same round trip) */
+            bool eq = false;
+            if (rp != 0u && bpos < n) {
+                const uint32_t A = ring_byte(src, bpos, false);
+                uint32_t Bv;
+                if (umax(st.rep1, st.rep2) <= kNear) Bv = ring_byte(src, bpos - rp, false); /* uniform: the usual case */
+                else Bv = ring_byte(src, bpos - rp, rp > kNear);
+                eq = A == Bv;
+            }
+            const u64 M = __ballot(eq);
+            const uint32_t M1 = (uint32_t)M, M2 = (uint32_t)(M >> 32);
+            uint32_t rl1 = 0, rl2 = 0;
             if (lane < W) {
-                const uint32_t q1 = p - st.rep1, q2 = p - (st.rep2 != 0u ? st.rep2 : st.rep1);
-                uint32_t own[5], Q1[5], Q2[5];
-                load_dw<5>(src, p, false, own);
-                if (umax(st.rep1, st.rep2) <= kNear) { /* uniform: both sources in the ring (the usual case) */
-                    load_dw<5>(src, q1, false, Q1);
-                    load_dw<5>(src, q2, false, Q2);
-                } else {
-                    load_dw<5>(src, q1, st.rep1 > kNear, Q1);
-                    load_dw<5>(src, q2, st.rep2 > kNear, Q2);
-                }
-                rl1 = umin(cmp16(own, p & 3u, Q1, q1 & 3u), n - p);
-                rl2 = st.rep2 != 0u ? umin(cmp16(own, p & 3u, Q2, q2 & 3u), n - p) : 0u;
+                rl1 = umin((uint32_t)__builtin_ctz(~(M1 >> lane) | 0x10000u), kRepCap);
+                rl2 = umin((uint32_t)__builtin_ctz(~(M2 >> lane) | 0x10000u), kRepCap);
             }
             const uint32_t rg1 = rl1 < kRepMin ? 0u : (rl1 >= kRepCap ? 1000u : 4u * rl1 + 36u);
             const uint32_t rg2 = rl2 < kRepMin ? 0u : (rl2 >= kRepCap ? 999u : 4u * rl2 + 35u);
-            if (!__ballot((rg1 | rg2) != 0u) || (dbg & 128u)) { /* no repeat in reach: the plain start flags decide from here */
-                st.arrival = 0u;
-                continue;
+            if (__ballot((rg1 | rg2) != 0u) && !(dbg & 128u)) { /* else: no repeat in reach, the start flags decide */
+                const uint32_t cl = (wd >> 7) & 0x7Fu, co = wd >> 14;
+                uint32_t G = 0, opt = 0;
+                if (cl != 0u && cl >= min_len(pf, co)) G = 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(co + 1u));
+                if (rg1 > G) { G = rg1; opt = 1u; }
+                if (rg2 > G) { G = rg2; opt = 2u; }
+                /* the gains one and two positions on: DPP row shifts (the window lives in lanes 0-15 = one row) */
+                const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x101, 0xF, 0xF, true);
+                const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x102, 0xF, 0xF, true);
+                const bool ok = lane < W && G != 0u && !(G1 > G + 4u) && !(G2 > G + 11u);
+                const u64 m = __ballot(ok);
+                if (m) {
+                    const uint32_t ks = (uint32_t)__builtin_ctzll(m);
+                    const uint32_t o = rdlane(opt, ks);
+                    q = st.cur + ks;
+                    if (o == 0u) {
+                        off = rdlane(co, ks);
+                        L = rdlane(cl, ks);
+                    } else {
+                        off = o == 1u ? st.rep1 : st.rep2;
+                        L = rdlane(o == 1u ? rl1 : rl2, ks);
+                        from = kRepCap;
+                    }
+                    have = true;
+                } else {
+                    st.cur += W;
+                }
             }
-            const uint32_t cl = (wd >> 7) & 0x7Fu, co = wd >> 14;
-            uint32_t G = 0, opt = 0;
-            if (cl != 0u && cl >= min_len(pf, co)) G = 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(co + 1u));
-            if (rg1 > G) { G = rg1; opt = 1u; }
-            if (rg2 > G) { G = rg2; opt = 2u; }
-            /* the gains one and two positions on: DPP row shifts (the window lives in lanes 0-15 = one row) */
-            const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x101, 0xF, 0xF, true);
-            const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x102, 0xF, 0xF, true);
-            const bool ok = lane < W && G != 0u && !(G1 > G + 4u) && !(G2 > G + 11u);
-            const u64 m = __ballot(ok);
-            if (!m) {
-                st.cur += W;
-                st.arrival = 0u;
-                continue;
-            }
-            const uint32_t ks = (uint32_t)__builtin_ctzll(m);
-            const uint32_t o = rdlane(opt, ks);
-            q = st.cur + ks;
-            uint32_t from;
-            if (o == 0u) {
-                off = rdlane(co, ks);
-                L = rdlane(cl, ks);
-                from = pf.capLen;
-            } else {
-                off = o == 1u ? st.rep1 : st.rep2;
-                L = rdlane(o == 1u ? rl1 : rl2, ks);
-                from = kRepCap;
-                needOv = true;
-            }
-            if (L == from) {
-                L = extend_match(src, q, off, from, umin(n, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
-                needOv = true;
-            }
-        } else {
-            if (w0 != cw0) {
-                wv = pvT[w0 - base + lane];
-                cw0 = w0;
-            }
-            const uint32_t j = rdlane(wv, c) & 0x7Fu; /* next start flag at/after the cursor */
-            if (j >= 64u) {
+        }
+        if (!have) { /* chase the start flags from the cursor */
+            for (;;) {
+                if (st.cur >= stop) return;
+                const uint32_t w0 = st.cur & ~63u;
+                if (w0 != cw0) {
+                    wv = pvT[w0 - base + lane];
+                    cw0 = w0;
+                }
+                const uint32_t j = rdlane(wv, st.cur & 63u) & 0x7Fu; /* next start flag at/after the cursor */
+                if (j < 64u) {
+                    const uint32_t wd = rdlane(wv, j);
+                    q = w0 + j;
+                    L = (wd >> 7) & 0x7Fu;
+                    off = wd >> 14;
+                    break;
+                }
                 st.cur = w0 + 64u;
-                continue;
-            }
-            const uint32_t wd = rdlane(wv, j);
-            q = w0 + j;
-            L = (wd >> 7) & 0x7Fu;
-            off = wd >> 14;
-            if (L == pf.capLen) {
-                L = extend_match(src, q, off, L, umin(n, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
-                needOv = true;
             }
         }
-        if (needOv && lane == 0u) {
-            pvT[q - base] = off;
-            pvT[q - base + 1u] = L;
+        if (L == from) L = extend_match(src, q, off, from, umin(n, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
+        /* record, branch-free: the three parse-word slots at the start of the match (all behind the new cursor,
+         * L >= 3) become {chosen | offset, length | index in tile, literal anchor} for the emitting wave */
+        if (lane == 0u) {
+            uint32_t *r = pvT + (q - base);
+            r[0] = kChosenBit | off;
+            r[1] = L | ((st.nseq - st.tileSeq) << 17);
+            r[2] = st.anchor;
         }
-        if ((q & ~63u) != st.win) {
-            rep_flush(st, srecT, base, lane);
-            st.win = q & ~63u;
-            st.chosen = st.ov = 0ull;
-            st.anchorIn = st.anchor;
-            st.seqBase = st.nseq;
-        }
-        st.chosen |= 1ull << (q & 63u);
-        if (needOv) st.ov |= 1ull << (q & 63u);
         st.nseq++;
         if (off != st.rep1) {
             st.rep2 = st.rep1;
@@ -468,28 +445,34 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
 template <bool REP>
 __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *srec,
                                             const uint32_t *pvW, uint32_t off, uint32_t len, uint32_t w0, uint32_t lane,
-                                            uint4 *out, uint32_t seqCap)
+                                            uint4 *out, uint32_t seqCap, uint32_t tileSeq)
 {
-    const uint4 rec = *reinterpret_cast<const uint4 *>(srec);
-    const u64 chosen = (u64)rec.x | ((u64)rec.y << 32);
-    if (!chosen) return;
-    const uint32_t anchorIn = rec.z, seqBase = rec.w, ext0 = srec[4], ext1 = srec[5];
-    if (REP) { /* words 4-5 = mask of the chosen matches the parse wave rewrote (repeat offset / extended) */
-        if ((((u64)ext0 | ((u64)ext1 << 32)) >> lane) & 1ull) {
-            off = pvW[lane];
-            len = pvW[lane + 1u];
-        }
+    bool ch;
+    uint32_t prevEnd, idx;
+    if (REP) { /* the parse wave left a complete record in the slots of every chosen match (parse_rep_span) */
+        const uint32_t r0 = pvW[lane];
+        ch = (r0 & kChosenBit) != 0u;
+        if (!__ballot(ch)) return;
+        const uint32_t r1 = pvW[lane + 1u];
+        prevEnd = pvW[lane + 2u];
+        off = r0 & 0x1FFFFu;
+        len = r1 & 0x1FFFFu;
+        idx = tileSeq + (r1 >> 17);
     } else {
+        const uint4 rec = *reinterpret_cast<const uint4 *>(srec);
+        const u64 chosen = (u64)rec.x | ((u64)rec.y << 32);
+        if (!chosen) return;
+        const uint32_t anchorIn = rec.z, seqBase = rec.w, ext0 = srec[4], ext1 = srec[5];
         if (ext0 && (ext0 >> 24) == lane) len = ext0 & 0xFFFFFFu; /* extended by the parse wave */
         if (ext1 && (ext1 >> 24) == lane) len = ext1 & 0xFFFFFFu;
+        ch = (chosen >> lane) & 1ull;
+        const u64 lower = chosen & below(lane);
+        const uint32_t myEnd = w0 + lane + len;
+        const int jprev = lower ? 63 - __builtin_clzll(lower) : 0;
+        prevEnd = __shfl(myEnd, jprev);
+        if (!lower) prevEnd = anchorIn;
+        idx = seqBase + (uint32_t)__popcll(lower);
     }
-    const bool ch = (chosen >> lane) & 1ull;
-    const u64 lower = chosen & below(lane);
-    const uint32_t rank = (uint32_t)__popcll(lower);
-    const uint32_t myEnd = w0 + lane + len;
-    const int jprev = lower ? 63 - __builtin_clzll(lower) : 0;
-    uint32_t prevEnd = __shfl(myEnd, jprev);
-    if (!lower) prevEnd = anchorIn;
     if (ch) {
         const uint32_t p = w0 + lane, q = p - off;
         const uint32_t lit = p - prevEnd;
@@ -503,7 +486,6 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
             const uint32_t x = pb ^ qb;
             b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
         }
-        const uint32_t idx = seqBase + rank;
         if (idx < seqCap) out[idx] = make_uint4(off, lit - b, len + b, 0u);
     }
 }
@@ -582,22 +564,20 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #endif
         uint32_t nseqEnd, anchorEnd;
         if (REP) {
-            RepState st = { 0u, 0u, 0u, 0u, 0u, 0u, kNone, 0u, 0u, 0ull, 0ull };
+            RepState st = { 0u, 0u, 0u, 0u, 0u, 0u, 0u };
             for (uint32_t it = 0; it < nTiles + 2u; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u, base = k << kTileLog;
                 uint32_t *pvT = pv + (k & 1u) * kPvStride, *srecT = srec + (k & 1u) * kWin * kSrecWords;
                 if (work) {
-                    if (lane < kWin) *reinterpret_cast<uint2 *>(srecT + lane * kSrecWords) = make_uint2(0u, 0u); /* nothing chosen yet */
+                    st.tileSeq = st.nseq;
+                    if (lane == 0u) srecT[0] = st.nseq; /* the records carry indices relative to this */
                     parse_rep_span(pf, src, pvT, srecT, base, base + 64u * kSplit, n, nh, lane, st, QZ_DBG);
                 }
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
                 QZ_PLAP(pW1)
-                if (work) {
-                    parse_rep_span(pf, src, pvT, srecT, base, base + kTile, n, nh, lane, st, QZ_DBG);
-                    rep_flush(st, srecT, base, lane);
-                }
+                if (work) parse_rep_span(pf, src, pvT, srecT, base, base + kTile, n, nh, lane, st, QZ_DBG);
                 QZ_PLAP(pI2)
                 __syncthreads(); /* B2 */
                 QZ_PLAP(pW2)
@@ -674,7 +654,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         if (refill) fresh = g128[fpos >> 4];
         if (it >= 2u && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
             emit_window<REP>(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, pv + (it & 1u) * kPvStride + 64u * wave,
-                             offB, lenB, t0 - 2u * kTile + 64u * wave, lane, out, blk.seqCap);
+                             offB, lenB, t0 - 2u * kTile + 64u * wave, lane, out, blk.seqCap,
+                             REP ? srec[(it & 1u) * kWin * kSrecWords] : 0u);
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
         const bool validL = HAS_LONG && valid && p + 8u <= n;
         if (valid) { /* phase A(it) */

@@ -86,7 +86,7 @@ typedef struct {
  * lone caller).  Every caller copies its own block into the batch's pinned staging area and its
  * own result out of it, so those copies run in parallel on the callers' threads.
  */
-#define QZ_BATCH_MAX 32
+#define QZ_BATCH_MAX 64
 typedef struct {
     const void *src;
     size_t srcSize, cap, rc;
@@ -100,12 +100,14 @@ typedef struct {
     ZSTD_Sequence *hSeqs;     /* pinned, QZ_BATCH_MAX x seqStride */
     qzstd_hip_block_t *hDesc; /* pinned */
     unsigned int *hCount;     /* pinned */
+    pthread_cond_t cvLead;    /* the batch's leader (its first member) waits here: device idle / members staged */
+    pthread_cond_t cvDone;    /* the other members wait here for the results */
 } QZSTD_Batch_T;
 
 typedef struct {
     int device, ready, running, open; /* open = index of the batch that accepts requests */
     pthread_mutex_t mu;
-    pthread_cond_t cv;
+    pthread_cond_t cvOpen; /* callers that found no batch to join wait here */
     QZSTD_Batch_T batch[2];
     void *stream;
     unsigned char *dSrc;
@@ -255,7 +257,11 @@ static void qzFreeCoalescer(QZSTD_Coalescer_T *c)
     if (c->stream) qzstd_hip_stream_destroy(c->device, c->stream);
     QZ_LOG(2, "device %d: %lu block(s) in %lu coalesced launch(es)\n", c->device, c->blocks, c->launches);
     pthread_mutex_destroy(&c->mu);
-    pthread_cond_destroy(&c->cv);
+    pthread_cond_destroy(&c->cvOpen);
+    for (b = 0; b < 2; b++) {
+        pthread_cond_destroy(&c->batch[b].cvLead);
+        pthread_cond_destroy(&c->batch[b].cvDone);
+    }
 }
 
 /* lazy, under c->mu */
@@ -339,7 +345,7 @@ static size_t qzCoalescedBlock(int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCa
     for (;;) { /* join the open batch (same level only) */
         bt = &c->batch[c->open];
         if (bt->state == 0 && bt->n < QZ_BATCH_MAX && (bt->n == 0 || bt->level == level)) break;
-        pthread_cond_wait(&c->cv, &c->mu);
+        pthread_cond_wait(&c->cvOpen, &c->mu);
     }
     i = bt->n++;
     bt->level = level;
@@ -353,23 +359,26 @@ static size_t qzCoalescedBlock(int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCa
 
     pthread_mutex_lock(&c->mu);
     bt->copied++;
-    pthread_cond_broadcast(&c->cv);
-    while (bt->state != 2) {
-        if (bt->state == 0 && !c->running && bt == &c->batch[c->open] && c->batch[c->open ^ 1].state == 0) {
-            /* device idle and nobody leads this batch yet: lead it */
-            c->running = 1;
-            bt->state = 1;
-            c->open ^= 1; /* newcomers now collect in the other batch */
-            while (bt->copied < bt->n) pthread_cond_wait(&c->cv, &c->mu); /* members still staging */
-            pthread_mutex_unlock(&c->mu);
-            qzRunBatch(c, bt);
-            pthread_mutex_lock(&c->mu);
-            bt->state = 2;
-            c->running = 0;
-            pthread_cond_broadcast(&c->cv);
-            break;
-        }
-        pthread_cond_wait(&c->cv, &c->mu);
+    if (i == 0) {
+        /* the first member leads its batch: it keeps collecting while the device works on the other batch,
+         * then closes it and launches.  Every waiter has its own condition variable (no thundering herd
+         * when more threads than cores wait here). */
+        while (c->running) pthread_cond_wait(&bt->cvLead, &c->mu);
+        c->running = 1;
+        bt->state = 1;
+        c->open ^= 1; /* newcomers now collect in the other batch (once its results are handed out) */
+        pthread_cond_broadcast(&c->cvOpen);
+        while (bt->copied < bt->n) pthread_cond_wait(&bt->cvLead, &c->mu); /* members still staging */
+        pthread_mutex_unlock(&c->mu);
+        qzRunBatch(c, bt);
+        pthread_mutex_lock(&c->mu);
+        bt->state = 2;
+        c->running = 0;
+        pthread_cond_broadcast(&bt->cvDone);
+        pthread_cond_signal(&c->batch[c->open].cvLead); /* the other batch's leader may go now */
+    } else {
+        if (bt->state == 1 && bt->copied == bt->n) pthread_cond_signal(&bt->cvLead);
+        while (bt->state != 2) pthread_cond_wait(&bt->cvDone, &c->mu);
     }
     pthread_mutex_unlock(&c->mu);
 
@@ -381,7 +390,7 @@ static size_t qzCoalescedBlock(int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCa
     if (++bt->consumed == bt->n) { /* last one out re-opens the batch */
         bt->n = bt->copied = bt->consumed = 0;
         bt->state = 0;
-        pthread_cond_broadcast(&c->cv);
+        pthread_cond_broadcast(&c->cvOpen);
     }
     pthread_mutex_unlock(&c->mu);
     return rc;
@@ -422,7 +431,11 @@ static int qzBuildSlots(void)
     for (i = 0; i < nDev; i++) {
         gProc.coal[i].device = i;
         pthread_mutex_init(&gProc.coal[i].mu, NULL);
-        pthread_cond_init(&gProc.coal[i].cv, NULL);
+        pthread_cond_init(&gProc.coal[i].cvOpen, NULL);
+        pthread_cond_init(&gProc.coal[i].batch[0].cvLead, NULL);
+        pthread_cond_init(&gProc.coal[i].batch[0].cvDone, NULL);
+        pthread_cond_init(&gProc.coal[i].batch[1].cvLead, NULL);
+        pthread_cond_init(&gProc.coal[i].batch[1].cvDone, NULL);
     }
     return QZSTD_OK;
 }
