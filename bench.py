@@ -101,8 +101,8 @@ def cpu_oracle_leg(data: bytes, block: int, level: int, seconds: float):
             "sample": "oracle/qzstd_oracle.c qzo_find_sequences, first %d blocks of the batch, 1 thread" % (done // block)}
 
 
-def c_benchmark(sample: bytes, block: int, level: int, threads: int, mode: int, hint: bool = False, ext_rep: int = 0,
-                loops: int = 2):
+def c_benchmark(sample: bytes, block: int, level: int, threads: int, mode: int, hint: int = 0, ext_rep: int = 0,
+                loops: int = 2, env: dict | None = None):
     """run qat-zstd-plugin_amd/test/benchmark (counterpart of the reference's test/benchmark.c: T threads,
     one CCtx each, one ZSTD_compress2 per chunk, each chunk its own frame) on a sample file"""
     import re
@@ -117,9 +117,9 @@ def c_benchmark(sample: bytes, block: int, level: int, threads: int, mode: int, 
             f.write(sample)
             name = f.name
         cmd = [os.path.join(tdir, "benchmark"), "-m%d" % mode, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level,
-               "-E%d" % ext_rep] + (["-H1"] if hint else []) + [name]
+               "-E%d" % ext_rep] + (["-H%d" % hint] if hint else []) + [name]
         t0 = time.perf_counter()
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
         wall = time.perf_counter() - t0
         os.unlink(name)
         agg = re.search(r"aggregate compression ([0-9.]+) MB/s", out.stderr)
@@ -245,13 +245,22 @@ def main():
             sw = c_benchmark(sample, block, level, thr, mode=0, loops=6)
             out["cpu_libzstd_sw"] = {"lib": os.path.basename(B.find_libzstd()), "host_cores": ncpu, **sw}
             # end to end through ZSTD_compress2 with the plugin registered: 4 MiB look-ahead hints (the GPU match-finds
-            # segment k+1 while the thread entropy-codes segment k), then without hints (per-block, coalesced)
-            e2e = c_benchmark(sample, block, level, thr, mode=1, hint=True, loops=6)
+            # segment k+1 while the thread entropy-codes segment k) ...
+            e2e = c_benchmark(sample, block, level, thr, mode=1, hint=1, loops=6)
             if "csize" in e2e and "csize" in sw:
                 e2e["csize_vs_sw"] = round(e2e["csize"] / sw["csize"], 4)
                 e2e["ratio_within_2pct"] = e2e["csize"] <= sw["csize"] * 1.02
             out["e2e_zstd_compress2_plugin"] = e2e
-            out["e2e_zstd_compress2_plugin_per_block_sync"] = c_benchmark(sample[:64 * block], block, level, thr, mode=1)
+            # ... the same with ZSTD_c_searchForExternalRepcodes on (-E1) and the repeat-offset aware parse ...
+            rep = c_benchmark(sample, block, level, thr, mode=1, hint=16, ext_rep=1, loops=6,
+                              env={"QZSTD_HIP_EXT_REPCODES": "1"})
+            if "csize" in rep and "csize" in sw:
+                rep["csize_vs_sw"] = round(rep["csize"] / sw["csize"], 4)
+            out["e2e_zstd_compress2_plugin_repcodes"] = rep
+            # ... and for unchanged callers (no hints: per-block callbacks merged by the coalescer; the callback
+            # blocks its thread for the GPU's per-block latency, so more threads than cores is the way to use it)
+            out["e2e_zstd_compress2_plugin_unchanged_callers"] = c_benchmark(sample[:128 * block], block, level, 4 * thr,
+                                                                             mode=1, loops=4)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -92,9 +92,17 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState);
  * not match the hint take the normal single-block path.  `blockSize` is the block grid
  * (131072 for plain ZSTD_compress2; the frame/chunk size when each chunk is its own
  * frame).  Returns 0 when the hint was accepted.
+ *
+ * The call is asynchronous: it copies at most 16 MiB into pinned memory, queues the
+ * transfers and the launch, and returns.  A state holds two announcements, so a caller
+ * announces segment k+1 and then compresses segment k.
  * ------------------------------------------------------------------------------------ */
 int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize,
                      size_t blockSize, int compressionLevel);
+
+/* Diagnostics for the above: stats[0] = blocks served from an announcement, [1] = blocks that took
+ * the per-block path, [2] = announcements accepted, [3] = microseconds spent waiting for the GPU. */
+void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4]);
 
 #if defined(__cplusplus)
 }

@@ -708,6 +708,16 @@ static int qzTryGrabSlot(int hint)
     return -1;
 }
 
+void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4])
+{
+    const QZSTD_Session_T *s = (const QZSTD_Session_T *)sequenceProducerState;
+    if (!stats) return;
+    stats[0] = s ? s->servedFromBatch : 0;
+    stats[1] = s ? s->servedSync : 0;
+    stats[2] = s ? s->hintCalls : 0;
+    stats[3] = s ? s->hintWaitNs / 1000 : 0;
+}
+
 int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
                      int compressionLevel)
 {

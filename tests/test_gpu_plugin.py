@@ -214,6 +214,63 @@ def test_compress_stream2_chunked_frames(started, zstd):
     assert b"".join(zstd.decompress(f, n) for f, n in frames) == data
 
 
+def test_config5_shape_stream_frames_with_lookahead(started, zstd, oracle):
+    """BASELINE config #5 in small: mixed-entropy data fed to ZSTD_compressStream2 as 4 MiB frames
+    (one call with ZSTD_e_end per frame, level 3), the next frame announced while the current one is
+    compressed.  With the whole frame handed over at once libzstd reads the caller's buffer directly, so
+    every one of the 32 callbacks per frame is served from the announcement (QZSTD_hintStats), and the
+    frames equal the oracle's.  libzstd 1.5.7 pre-splits the blocks of multi-block frames from level 3 on
+    (callbacks of ~30 KiB that no longer sit on a block grid and take the per-block path);
+    ZSTD_c_blockSplitterLevel = 1 switches that off."""
+    L = zstd.lib
+
+    class InB(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    class OutB(C.Structure):
+        _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(OutB), C.POINTER(InB), C.c_int]
+    L.ZSTD_compressStream2.restype = C.c_size_t
+    frame, nframes, level = 4 << 20, 5, 3
+    data = K.mixed_entropy(5, nframes * frame)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    cap = L.ZSTD_compressBound(frame)
+    dst = C.create_string_buffer(cap)
+
+    def run(producer, state, hints, split_off=True):
+        zc = zstd.cctx(level, producer=producer, state=state, fallback=False, validate=True,
+                       **({"blockSplitterLevel": 1} if split_off else {}))
+        frames = []
+        if hints:
+            assert started.lib.QZSTD_hintSource(state, buf, frame, 131072, level) == 0
+        for f in range(nframes):
+            if hints and f + 1 < nframes:
+                assert started.lib.QZSTD_hintSource(state, C.byref(buf, (f + 1) * frame), frame, 131072, level) == 0
+            out = OutB(C.cast(dst, C.c_void_p), cap, 0)
+            inp = InB(C.cast(C.byref(buf, f * frame), C.c_void_p), frame, 0)
+            r = L.ZSTD_compressStream2(zc, C.byref(out), C.byref(inp), B.e_end)
+            assert r == 0 and inp.pos == frame, zstd.err(r)
+            frames.append(dst.raw[:out.pos])
+        zstd.free(zc)
+        return frames
+
+    st = started.lib.QZSTD_createSeqProdState()
+    got = run(started.producer_addr, st, True)
+    stats = (C.c_ulong * 4)()
+    started.lib.QZSTD_hintStats(st, C.byref(stats))
+    started.lib.QZSTD_freeSeqProdState(st)
+    want = run(oracle.producer_addr, None, False)
+    assert got == want
+    assert b"".join(zstd.decompress(f, frame) for f in got) == data
+    assert stats[2] == nframes and stats[1] == 0 and stats[0] == nframes * 32, list(stats)
+    # with libzstd's pre-splitter left on, the output is still right (per-block path)
+    st = started.lib.QZSTD_createSeqProdState()
+    got = run(started.producer_addr, st, True, split_off=False)
+    started.lib.QZSTD_freeSeqProdState(st)
+    assert b"".join(zstd.decompress(f, frame) for f in got) == data
+
+
 def test_benchmark_tool_gpu_modes(started, tmp_path):
     """the C benchmark (counterpart of reference test/benchmark.c) with the producer registered"""
     import os

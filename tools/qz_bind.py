@@ -239,7 +239,7 @@ NSEQ_ERROR = 0xFFFFFFFF
 # every symbol include/qatseqprod.h and include/qzstd_hip.h declare
 PLUGIN_SYMBOLS = [
     "QZSTD_version", "qatSequenceProducer", "QZSTD_startQatDevice", "QZSTD_stopQatDevice",
-    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource",
+    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource", "QZSTD_hintStats",
     "qzstd_hip_last_error", "qzstd_hip_profile_for_level", "qzstd_hip_sequence_bound", "qzstd_hip_lds_bytes",
     "qzstd_hip_device_count", "qzstd_hip_device_name", "qzstd_hip_malloc", "qzstd_hip_free",
     "qzstd_hip_host_alloc", "qzstd_hip_host_free", "qzstd_hip_stream_create", "qzstd_hip_stream_destroy",
@@ -259,6 +259,8 @@ class Plugin:
         L.QZSTD_createSeqProdState.restype = C.c_void_p
         L.QZSTD_freeSeqProdState.argtypes = [C.c_void_p]
         L.QZSTD_hintSource.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.QZSTD_hintStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong * 4)]
+        L.QZSTD_hintStats.restype = None
         L.qatSequenceProducer.restype = C.c_size_t
         L.qatSequenceProducer.argtypes = [C.c_void_p, C.POINTER(Sequence), C.c_size_t, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]
