@@ -177,13 +177,15 @@ def main():
         desc[i].seqCap = stride
     d_desc = torch.empty(C.sizeof(desc), dtype=torch.uint8, device=dev)
     d_desc.copy_(torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8))
+    work = L.qzstd_hip_workspace_bytes(level, nb, block)  # levels >= 6: hash chains in device memory
+    d_work = torch.empty(max(work, 4), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
 
     def step():
         rc = L.qzstd_hip_find_sequences(local, C.c_void_p(stream.cuda_stream), level, C.c_void_p(d_src.data_ptr()),
                                         C.c_void_p(d_desc.data_ptr()), nb, block, C.c_void_p(d_seqs.data_ptr()),
-                                        C.c_void_p(d_cnt.data_ptr()))
+                                        C.c_void_p(d_cnt.data_ptr()), C.c_void_p(d_work.data_ptr()), work)
         if rc != 0:
             raise RuntimeError(plug.err())
 

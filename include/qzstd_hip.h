@@ -55,6 +55,8 @@ typedef struct {
     uint32_t repWin;    /* 0 = plain parse; n = repeat-offset aware parse: after every match the next n positions
                          * are also tried with the last two offsets (for callers with
                          * ZSTD_c_searchForExternalRepcodes on, which is libzstd's default from level 10) */
+    uint32_t chainDepth; /* 0 = table probes only; n = also walk the main table's predecessor chain (a per-block
+                         * array in device memory: chain[p] = the slot's content before p's tile), n candidates deep */
 } qzstd_hip_profile_t;
 
 /* One work item = one <=128 KiB block, parsed with no history
@@ -109,12 +111,17 @@ int qzstd_hip_memcpy2d_d2h(int device, void *stream, void *dst, size_t dpitch, c
  *   d_nseq    per block: number of sequences INCLUDING the trailing-literals delimiter
  *             (what qatSequenceProducer returns, src/qatseqprod.c:1090,:1323), or
  *             QZSTD_HIP_NSEQ_ERROR when count >= seqCap-1 (src/qatseqprod.c:1318)
+ *   d_work    device scratch of at least qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen)
+ *             bytes, private to this launch until it completes (levels >= 6 keep their hash
+ *             chains there; may be NULL when that size is 0)
  *
  * One workgroup per block; block bytes, hash table and parse scratch live in LDS.
  */
+size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockLen);
 int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_src,
                              const qzstd_hip_block_t *d_blocks, uint32_t nBlocks,
-                             uint32_t maxBlockLen, void *d_seqs, uint32_t *d_nseq);
+                             uint32_t maxBlockLen, void *d_seqs, uint32_t *d_nseq,
+                             void *d_work, size_t workBytes);
 
 #if defined(__cplusplus)
 }

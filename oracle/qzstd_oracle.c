@@ -74,6 +74,8 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     /* libzstd turns repeat offsets of external sequences into repcodes only from level 10 (or when the
      * caller sets ZSTD_c_searchForExternalRepcodes); without that, short repeat matches cost a full offset */
     out->repWin = (repcodes || level >= 10) ? 8u : 0u;
+    /* levels >= 6 (zstd: lazy, 8 attempts, then lazy2 / btlazy2): walk the hash chain */
+    out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : 0u);
     return 0;
 }
 
@@ -122,7 +124,7 @@ static inline uint32_t qzo_mix8(const uint8_t *p)
 }
 
 static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t n,
-                           qzo_cand_t *cand, uint32_t *tbl, uint32_t *near, uint32_t *tblL)
+                           qzo_cand_t *cand, uint32_t *tbl, uint32_t *near, uint32_t *tblL, uint32_t *chain)
 {
     const uint32_t nl = pf->longSize && n >= 8u ? n - 7u : 0u; /* positions that have 8 bytes for the long table */
     const uint32_t nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0; /* hashable positions */
@@ -182,6 +184,26 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
                         /* longer wins; on a tie the nearer source (this one) wins */
                         if (l >= bestLen) { bestLen = l; bestOff = p - q; }
                     }
+                }
+            }
+            /* probes 4.. (levels >= 6): the predecessor chain of the main-table slot.  chain[x] = what the
+             * slot held before x's tile (position + 1, any tag; 0 = end).  The head itself was probe 1; a
+             * chain candidate replaces the best so far only with a strictly higher gain (4 per matched
+             * byte minus the bit length of the offset).  On the GPU chain[] lives in device memory. */
+            if (pf->chainDepth) {
+                const uint32_t head = e >> QZO_TAG_BITS; /* position + 1, or 0 */
+                uint32_t link, d;
+                int bg = bestLen ? (int)(4u * bestLen) - (int)(31u - (uint32_t)__builtin_clz(bestOff + 1u)) : -1000000;
+                chain[p] = head;
+                link = head ? chain[head - 1u] : 0u;
+                for (d = 1; d < pf->chainDepth && link != 0u; d++) {
+                    const uint32_t q = link - 1u;
+                    if ((pf->window == 0 || p - q <= pf->window) && qzo_rd32(src + q) == v) {
+                        const uint32_t l = qzo_prefix_len(src, q, p, cap);
+                        const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
+                        if (l >= 4u && g > bg) { bestLen = l; bestOff = p - q; bg = g; }
+                    }
+                    link = chain[q];
                 }
             }
             cand[p].len = bestLen;
@@ -340,13 +362,13 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
     const uint32_t n = (uint32_t)srcSize;
     uint32_t nh;
     qzo_cand_t *cand;
-    uint32_t *tbl, *near, *tblL;
+    uint32_t *tbl, *near, *tblL, *chain;
     uint32_t p = 0, anchor = 0;
     size_t ns = 0;
 
     if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
-        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
+        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->chainDepth > 64 || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
         return QZO_ERROR;
     nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
 
@@ -354,9 +376,10 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
     tbl = (uint32_t *)malloc(sizeof(uint32_t) * pf->tableSize);
     near = (uint32_t *)malloc(sizeof(uint32_t) << pf->tileLog);
     tblL = (uint32_t *)malloc(sizeof(uint32_t) * (pf->longSize ? pf->longSize : 1u));
-    if (!cand || !tbl || !near || !tblL) { free(cand); free(tbl); free(near); free(tblL); return QZO_ERROR; }
+    chain = (uint32_t *)calloc((size_t)n + 1u, sizeof(uint32_t));
+    if (!cand || !tbl || !near || !tblL || !chain) { free(cand); free(tbl); free(near); free(tblL); free(chain); return QZO_ERROR; }
 
-    qzo_candidates(pf, src, n, cand, tbl, near, tblL);
+    qzo_candidates(pf, src, n, cand, tbl, near, tblL, chain);
 
     if (pf->repWin) {
         ns = qzo_parse_rep(pf, src, n, nh, cand, out, cap);
@@ -410,7 +433,7 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
     ns++;
     if (ns >= cap - 1) ns = QZO_ERROR; /* src/qatseqprod.c:1318 */
 done:
-    free(cand); free(tbl); free(near); free(tblL);
+    free(cand); free(tbl); free(near); free(tblL); free(chain);
     return ns;
 }
 

@@ -70,6 +70,8 @@ struct LaunchArgs {
     uint4 *seqs; /* ZSTD_Sequence = 4 x u32 */
     uint32_t *nseq;
     qzstd_hip_profile_t prof; /* the level's search profile (block-size independent) */
+    uint32_t *chain;          /* levels >= 6: per-block predecessor chains, chainStride words per block */
+    uint32_t chainStride;
 #ifdef QZ_DEBUG_DUMP
     uint32_t dbg; /* profiling build only: ablation switches (QZSTD_HIP_ABLATE) */
 #endif
@@ -503,9 +505,10 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
  *                                parse wave: windows 2-7 of tile it-1
  *   barrier
  *
- * HAS_LONG selects the level >= 3 variant with the second (8-byte-key) table.
+ * HAS_LONG selects the level >= 3 variant with the second (8-byte-key) table, REP the repeat-offset aware
+ * parse, CHAIN (levels >= 6) the walk along the main table's predecessor chain in device memory.
  */
-template <bool HAS_LONG, bool REP>
+template <bool HAS_LONG, bool REP, bool CHAIN>
 __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -731,6 +734,43 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             if (l3 >= 4u && l3 > cl) { cl = l3; off = p - q3; }   /* 8-byte table: only if strictly longer */
             if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }  /* same tile: ties go to the nearer source */
         }
+        if (CHAIN && it < nTiles) {
+            /* candidates 4..: the predecessor chain of the main-table slot, in device memory (L2/MALL resident:
+             * 4 B per position).  chain[x] = what the slot held before x's tile (position + 1, any tag); every
+             * link points into an earlier tile, i.e. was stored at least two barriers ago.  A chain candidate
+             * replaces the best so far only with a strictly higher gain.  Dependent loads, ~1 us each: the
+             * matcher waves have that time at these levels (oracle: qzo_candidates, probes 4..). */
+            uint32_t *chainB = args.chain + (size_t)blockIdx.x * args.chainStride;
+            uint32_t link = 0;
+            int bg = cl ? (int)(4u * cl) - (int)(31u - (uint32_t)__builtin_clz(off + 1u)) : -1000000;
+            const uint32_t cap = valid ? umin(pf.capLen, n - p) : 0u;
+            if (valid) {
+                const uint32_t head = old >> kTagBits;
+                chainB[p] = head;
+                if (head) link = __hip_atomic_load(chainB + (head - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (uint32_t d = 1; d < pf.chainDepth; d++) {
+                if (!__ballot(link != 0u)) break;
+                if (link != 0u) {
+                    const uint32_t q = link - 1u;
+                    const bool far = p - q > kNear;
+                    link = __hip_atomic_load(chainB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* next link: in flight during the compare */
+                    if (pf.window == 0u || p - q <= pf.window) {
+                        uint32_t l = head_len(src, own, p & 3u, q, far);
+                        if (l == 16u && cap > 16u) {
+                            for (;;) {
+                                const uint32_t c = chunk_len(src, p + l, q + l, far);
+                                l += c;
+                                if (c < 32u || l >= cap) break;
+                            }
+                        }
+                        l = umin(l, cap);
+                        const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
+                        if (l >= 4u && g > bg) { cl = l; off = p - q; bg = g; }
+                    }
+                }
+            }
+        }
         if (it < nTiles && !QZ_ABLATED(4u)) {
             /* start flags: the lazy rules compare capped lengths and never look across the window edge */
             const bool take = cl != 0u && cl >= min_len(pf, off);
@@ -894,7 +934,7 @@ int qzstd_hip_memcpy2d_d2h(int device, void *stream, void *dst, size_t dpitch, c
 
 int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_src,
                              const qzstd_hip_block_t *d_blocks, uint32_t nBlocks, uint32_t maxBlockLen,
-                             void *d_seqs, uint32_t *d_nseq)
+                             void *d_seqs, uint32_t *d_nseq, void *d_work, size_t workBytes)
 {
     static thread_local int attrDevice = -1;
     static thread_local size_t attrBytes = 0;
@@ -905,21 +945,32 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (qzstd_hip_profile_for_level(level, maxBlockLen, &a.prof))
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12 (optionally | QZSTD_HIP_LEVEL_REPCODES)");
     if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
-        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 8)
+        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 8 || a.prof.chainDepth > 64)
         return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");
     QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    const void *variants[6] = { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false>),
+                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, false>),
+                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false>),
+                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, false>),
+                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, true>),
+                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, true>) };
     if (attrDevice != device || attrBytes < lds) {
-        const void *variants[4] = { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false>),
-                                    reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false>),
-                                    reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true>),
-                                    reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true>) };
-        for (int v = 0; v < 4; v++)
+        for (int v = 0; v < 6; v++)
             QZ_CHECK(hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         attrDevice = device;
         attrBytes = lds;
+    }
+    a.chain = nullptr;
+    a.chainStride = 0;
+    if (a.prof.chainDepth) {
+        const size_t need = qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen);
+        if (!a.prof.longSize) return fail_msg("qzstd_hip_find_sequences: unsupported profile (chains without the long table)");
+        if (!d_work || workBytes < need) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
+        a.chain = static_cast<uint32_t *>(d_work);
+        a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint32_t));
     }
     a.src = static_cast<const uint8_t *>(d_src);
     a.blocks = d_blocks;
@@ -929,14 +980,9 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
 #endif
     const dim3 grid(nBlocks), wg(kThreads);
-    if (a.prof.longSize && a.prof.repWin)
-        hipLaunchKernelGGL((qzstd_find_sequences_kernel<true, true>), grid, wg, lds, (hipStream_t)stream, a);
-    else if (a.prof.longSize)
-        hipLaunchKernelGGL((qzstd_find_sequences_kernel<true, false>), grid, wg, lds, (hipStream_t)stream, a);
-    else if (a.prof.repWin)
-        hipLaunchKernelGGL((qzstd_find_sequences_kernel<false, true>), grid, wg, lds, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((qzstd_find_sequences_kernel<false, false>), grid, wg, lds, (hipStream_t)stream, a);
+    const int which = a.prof.chainDepth ? (a.prof.repWin ? 5 : 4) : ((a.prof.longSize ? 1 : 0) + (a.prof.repWin ? 2 : 0));
+    void *kargs[1] = { &a };
+    QZ_CHECK(hipLaunchKernel(variants[which], grid, wg, kargs, lds, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;
 }

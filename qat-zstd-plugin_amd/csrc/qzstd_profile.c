@@ -45,12 +45,22 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     /* libzstd turns repeat offsets of external sequences into repcodes only from level 10 (or when the
      * caller sets ZSTD_c_searchForExternalRepcodes); without that, short repeat matches cost a full offset */
     out->repWin = (repcodes || level >= 10) ? 8u : 0u;
+    /* levels >= 6 (zstd: lazy, 8 attempts, then lazy2 / btlazy2): walk the hash chain */
+    out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : 0u);
     return 0;
 }
 
 size_t qzstd_hip_sequence_bound(size_t srcSize)
 {
     return srcSize / 3 + 1 + srcSize / 1024 + 1;
+}
+
+/* device scratch of one launch: the predecessor chains of levels >= 6, 4 B per position of every block */
+size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockLen)
+{
+    qzstd_hip_profile_t p;
+    if (maxBlockLen > QZSTD_HIP_BLOCK_MAX || qzstd_hip_profile_for_level(level, maxBlockLen, &p) || !p.chainDepth) return 0;
+    return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * sizeof(uint32_t);
 }
 
 #define QZ_RING_BYTES (49152u + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip) */

@@ -74,6 +74,9 @@ typedef struct {
     unsigned char *dBatchSrc; size_t dBatchSrcCap;
     ZSTD_Sequence *dBatchSeqs; size_t dBatchSeqsCap;
     qzstd_hip_block_t *dBatchDesc; unsigned int *dBatchCount; size_t dBatchBlocksCap;
+    /* launch scratch (hash chains of levels >= 6), grow-only: one block / a hinted batch */
+    void *dWork; size_t dWorkCap;
+    void *dBatchWork; size_t dBatchWorkCap;
 } QZSTD_Slot_T;
 
 /*
@@ -114,6 +117,8 @@ typedef struct {
     ZSTD_Sequence *dSeqs;
     qzstd_hip_block_t *dDesc;
     unsigned int *dCount;
+    void *dWork; /* launch scratch, grow-only */
+    size_t dWorkCap;
     size_t seqStride;
     unsigned long launches, blocks;
 } QZSTD_Coalescer_T;
@@ -183,6 +188,8 @@ static void qzFreeSlot(QZSTD_Slot_T *s)
     qzstd_hip_free(s->device, s->dBatchSeqs);
     qzstd_hip_free(s->device, s->dBatchDesc);
     qzstd_hip_free(s->device, s->dBatchCount);
+    qzstd_hip_free(s->device, s->dWork);
+    qzstd_hip_free(s->device, s->dBatchWork);
     if (s->stream) qzstd_hip_stream_destroy(s->device, s->stream);
     {
         const int dev = s->device;
@@ -254,6 +261,7 @@ static void qzFreeCoalescer(QZSTD_Coalescer_T *c)
     qzstd_hip_free(c->device, c->dSeqs);
     qzstd_hip_free(c->device, c->dDesc);
     qzstd_hip_free(c->device, c->dCount);
+    qzstd_hip_free(c->device, c->dWork);
     if (c->stream) qzstd_hip_stream_destroy(c->device, c->stream);
     QZ_LOG(2, "device %d: %lu block(s) in %lu coalesced launch(es)\n", c->device, c->blocks, c->launches);
     pthread_mutex_destroy(&c->mu);
@@ -292,6 +300,8 @@ static int qzSetupCoalescer(QZSTD_Coalescer_T *c)
     return QZSTD_OK;
 }
 
+static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need);
+
 /* the leader's job: one launch for the whole batch (called WITHOUT c->mu held) */
 static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
 {
@@ -305,10 +315,15 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         bt->hDesc[i].seqCap = (unsigned int)(bt->req[i].cap < c->seqStride ? bt->req[i].cap : c->seqStride);
         if (bt->hDesc[i].srcLen > maxLen) maxLen = bt->hDesc[i].srcLen;
     }
-    failed = qzstd_hip_memcpy_h2d(dev, c->stream, c->dSrc, bt->hSrc, (size_t)n * QZ_SRC_STRIDE) ||
+    {
+        const size_t work = qzstd_hip_workspace_bytes(bt->level, (unsigned int)n, maxLen);
+        if (work) c->dWork = qzGrowDev(dev, c->dWork, &c->dWorkCap, work);
+        failed = work && !c->dWork;
+    }
+    failed = failed || qzstd_hip_memcpy_h2d(dev, c->stream, c->dSrc, bt->hSrc, (size_t)n * QZ_SRC_STRIDE) ||
              qzstd_hip_memcpy_h2d(dev, c->stream, c->dDesc, bt->hDesc, (size_t)n * sizeof(qzstd_hip_block_t)) ||
              qzstd_hip_find_sequences(dev, c->stream, bt->level, c->dSrc, c->dDesc, (unsigned int)n, maxLen, c->dSeqs,
-                                      c->dCount) ||
+                                      c->dCount, c->dWork, c->dWorkCap) ||
              qzstd_hip_memcpy_d2h(dev, c->stream, bt->hCount, c->dCount, (size_t)n * sizeof(unsigned int)) ||
              qzstd_hip_stream_sync(dev, c->stream);
     for (i = 0; i < n && !failed; i++) { /* gather every block's used prefix */
@@ -565,10 +580,15 @@ static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeq
     sl->hDesc->seqOff = 0;
     sl->hDesc->srcLen = (unsigned int)srcSize;
     sl->hDesc->seqCap = (unsigned int)cap;
+    {
+        const size_t work = qzstd_hip_workspace_bytes(level, 1, (unsigned int)srcSize);
+        if (work) sl->dWork = qzGrowDev(sl->device, sl->dWork, &sl->dWorkCap, work);
+        if (work && !sl->dWork) goto fail;
+    }
     if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dSrc, sl->hSrc, (srcSize + 15) & ~(size_t)15) ||
         qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dDesc, sl->hDesc, sizeof(*sl->hDesc)) ||
         qzstd_hip_find_sequences(sl->device, sl->stream, level, sl->dSrc, sl->dDesc, 1, (unsigned int)srcSize,
-                                 sl->dSeqs, sl->dCount))
+                                 sl->dSeqs, sl->dCount, sl->dWork, sl->dWorkCap))
         goto fail;
     first = cap < QZ_FIRST_COPY_SEQS ? cap : QZ_FIRST_COPY_SEQS;
     if (qzstd_hip_memcpy_d2h(sl->device, sl->stream, sl->hCount, sl->dCount, sizeof(unsigned int)) ||
@@ -772,6 +792,11 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
         if (!sl->dBatchBlocksCap) goto fail;
     }
     tq = qzNowNs();
+    {
+        const size_t work = qzstd_hip_workspace_bytes(compressionLevel | gProc.levelFlags, (unsigned int)nb, (unsigned int)blockSize);
+        if (work) sl->dBatchWork = qzGrowDev(sl->device, sl->dBatchWork, &sl->dBatchWorkCap, work);
+        if (work && !sl->dBatchWork) goto fail;
+    }
     memcpy(h->hSrc, src, srcSize); /* pinned staging: the H2D below is then truly asynchronous */
     for (b = 0; b < nb; b++) {
         const size_t o = b * blockSize;
@@ -786,7 +811,8 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc, srcBytes) ||
         qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchDesc, h->hDesc, blocksBytes) ||
         qzstd_hip_find_sequences(sl->device, sl->stream, compressionLevel | gProc.levelFlags, sl->dBatchSrc, sl->dBatchDesc,
-                                 (unsigned int)nb, (unsigned int)blockSize, sl->dBatchSeqs, sl->dBatchCount) ||
+                                 (unsigned int)nb, (unsigned int)blockSize, sl->dBatchSeqs, sl->dBatchCount, sl->dBatchWork,
+                                 sl->dBatchWorkCap) ||
         qzstd_hip_memcpy_d2h(sl->device, sl->stream, h->hCount, sl->dBatchCount, nb * sizeof(unsigned int)) ||
         qzstd_hip_memcpy2d_d2h(sl->device, sl->stream, h->hSeqs, QZ_HINT_PITCH * sizeof(ZSTD_Sequence), sl->dBatchSeqs,
                                stride * sizeof(ZSTD_Sequence),

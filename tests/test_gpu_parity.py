@@ -53,7 +53,7 @@ def test_edge_sizes(gpu_plugin, oracle):
     check_blocks(gpu_plugin, oracle, [base[:s] for s in sizes])
 
 
-@pytest.mark.parametrize("level", [1, 12, 0x102])
+@pytest.mark.parametrize("level", [1, 12, 0x102, 7])
 def test_degenerate_blocks(gpu_plugin, oracle, level):
     blocks = [bytes(131072), b"\xff" * 70000, b"ab" * 50000, b"abc" * 40000, (b"0123456789" * 13108)[:131072],
               bytes(range(256)) * 512, b"x" + bytes(5000), K.incompressible(9, 131072),
@@ -61,7 +61,7 @@ def test_degenerate_blocks(gpu_plugin, oracle, level):
     check_blocks(gpu_plugin, oracle, blocks, level)
 
 
-@pytest.mark.parametrize("level", [1, 3, 6, 10, 12, 0x101, 0x103, 0x106])  # 0x100 = QZSTD_HIP_LEVEL_REPCODES
+@pytest.mark.parametrize("level", [1, 3, 6, 9, 10, 12, 0x101, 0x103, 0x106])  # 0x100 = QZSTD_HIP_LEVEL_REPCODES
 def test_levels(gpu_plugin, oracle, level):
     data = K.mix(11, 6 * 131072)
     check_blocks(gpu_plugin, oracle, [data[o:o + 131072] for o in range(0, len(data), 131072)], level)
@@ -86,7 +86,7 @@ def test_capacity_rule(gpu_plugin, oracle):
     assert oracle.find(prof, blk, cap=n_full + 1)[0] == B.SEQ_ERROR
 
 
-@pytest.mark.parametrize("level,seed", [(1, 1), (1, 2), (3, 3), (0x101, 4), (12, 5), (0x104, 6)])
+@pytest.mark.parametrize("level,seed", [(1, 1), (1, 2), (3, 3), (0x101, 4), (12, 5), (0x104, 6), (6, 7), (0x108, 8)])
 def test_randomised_blocks(gpu_plugin, oracle, level, seed):
     """ragged random batch: random sizes (incl. tiny and ring-wrapping ones), random content kinds,
     repeated / shifted copies that create far (> 40 KiB) and very long matches"""

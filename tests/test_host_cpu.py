@@ -77,6 +77,18 @@ def test_profile_tables_agree(plugin, oracle, level, block):
     assert plugin.profile(level, block).as_dict() == oracle.profile(level, block).as_dict()
 
 
+def test_workspace_only_for_chain_levels(plugin):
+    """levels >= 6 keep their hash chains in device memory: 4 B per position of every block"""
+    W = plugin.lib.qzstd_hip_workspace_bytes
+    for level in range(1, 6):
+        assert W(level, 100, 131072) == 0 and plugin.profile(level, 131072).chainDepth == 0
+    for level in range(6, 13):
+        assert plugin.profile(level, 131072).chainDepth in (8, 16)
+        assert W(level, 100, 131072) == 100 * 131072 * 4
+        assert W(level, 3, 1000) == 3 * 1024 * 4
+    assert W(6, 1, 131073) == 0 and W(0, 1, 1000) == 0
+
+
 def test_repcode_aware_parse_follows_libzstd_default(plugin):
     """libzstd resolves ZSTD_c_searchForExternalRepcodes = auto to "on" from level 10; below that the
     caller has to ask for it (level | QZSTD_HIP_LEVEL_REPCODES, env QZSTD_HIP_EXT_REPCODES=1)"""
@@ -236,7 +248,7 @@ def test_hot_path_fails_loudly_without_gpu(plugin):
         pytest.skip("needs the no-device condition")
     blk = B.HipBlock()
     dummy = C.create_string_buffer(64)
-    rc = plugin.lib.qzstd_hip_find_sequences(0, None, 1, dummy, C.byref(blk), 1, 16, dummy, dummy)
+    rc = plugin.lib.qzstd_hip_find_sequences(0, None, 1, dummy, C.byref(blk), 1, 16, dummy, dummy, None, 0)
     assert rc != 0 and plugin.err()
     assert plugin.lib.qzstd_hip_malloc(0, 4096) is None
 

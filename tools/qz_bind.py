@@ -174,7 +174,7 @@ class Zstd:
 class OracleProfile(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("tableSize", "tileLog", "capLen", "minMatch", "farLog1",
                                           "farLog2", "lazy", "backExt", "nearTab", "window",
-                                          "hashBytes", "extLog", "longSize", "repWin")]
+                                          "hashBytes", "extLog", "longSize", "repWin", "chainDepth")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -244,7 +244,7 @@ PLUGIN_SYMBOLS = [
     "qzstd_hip_device_count", "qzstd_hip_device_name", "qzstd_hip_malloc", "qzstd_hip_free",
     "qzstd_hip_host_alloc", "qzstd_hip_host_free", "qzstd_hip_stream_create", "qzstd_hip_stream_destroy",
     "qzstd_hip_stream_sync", "qzstd_hip_stream_query", "qzstd_hip_memcpy_h2d", "qzstd_hip_memcpy_d2h",
-    "qzstd_hip_memset", "qzstd_hip_memcpy2d_d2h", "qzstd_hip_find_sequences",
+    "qzstd_hip_memset", "qzstd_hip_memcpy2d_d2h", "qzstd_hip_workspace_bytes", "qzstd_hip_find_sequences",
 ]
 
 
@@ -289,7 +289,9 @@ class Plugin:
         L.qzstd_hip_memcpy_d2h.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.qzstd_hip_memset.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
         L.qzstd_hip_find_sequences.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32,
-                                               C.c_uint32, C.c_void_p, C.c_void_p]
+                                               C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.qzstd_hip_workspace_bytes.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+        L.qzstd_hip_workspace_bytes.restype = C.c_size_t
         self.producer_addr = C.cast(L.qatSequenceProducer, C.c_void_p)
 
     def err(self) -> str:
@@ -331,14 +333,16 @@ class Plugin:
         d_desc = L.qzstd_hip_malloc(device, C.sizeof(desc))
         d_seqs = L.qzstd_hip_malloc(device, nb * stride * 16)
         d_cnt = L.qzstd_hip_malloc(device, nb * 4)
+        work = L.qzstd_hip_workspace_bytes(level, nb, maxlen)
+        d_work = L.qzstd_hip_malloc(device, work) if work else None
         try:
-            if not (d_src and d_desc and d_seqs and d_cnt):
+            if not (d_src and d_desc and d_seqs and d_cnt and (d_work or not work)):
                 raise RuntimeError("qzstd_hip_malloc: " + self.err())
             src_buf = (C.c_char * total).from_buffer(host_src)
             self.check(L.qzstd_hip_memcpy_h2d(device, None, d_src, src_buf, total), "h2d src")
             self.check(L.qzstd_hip_memcpy_h2d(device, None, d_desc, desc, C.sizeof(desc)), "h2d desc")
             self.check(L.qzstd_hip_memset(device, None, d_cnt, 0, nb * 4), "memset")
-            self.check(L.qzstd_hip_find_sequences(device, None, level, d_src, d_desc, nb, maxlen, d_seqs, d_cnt),
+            self.check(L.qzstd_hip_find_sequences(device, None, level, d_src, d_desc, nb, maxlen, d_seqs, d_cnt, d_work, work),
                        "qzstd_hip_find_sequences")
             cnt = (C.c_uint32 * nb)()
             seqs = (Sequence * (nb * stride))()
@@ -346,7 +350,7 @@ class Plugin:
             self.check(L.qzstd_hip_memcpy_d2h(device, None, seqs, d_seqs, nb * stride * 16), "d2h seqs")
             self.check(L.qzstd_hip_stream_sync(device, None), "sync")
         finally:
-            for p in (d_src, d_desc, d_seqs, d_cnt):
+            for p in (d_src, d_desc, d_seqs, d_cnt, d_work):
                 if p:
                     L.qzstd_hip_free(device, p)
         return list(cnt), seqs, stride
