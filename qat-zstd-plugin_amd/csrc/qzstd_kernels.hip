@@ -126,6 +126,14 @@ __device__ __forceinline__ void load_dw(const Src &s, uint32_t a, bool far, uint
     }
 }
 
+/* index of the first non-zero byte of x (little endian), or 0x1FFFFFFF when x == 0 */
+__device__ __forceinline__ uint32_t first_diff(uint32_t x)
+{
+    uint32_t r; /* v_ffbl_b32 returns -1 for 0: exactly the "no difference" value the min chain wants */
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r >> 3;
+}
+
 /* 4 bytes at an arbitrary position: two aligned dwords + v_alignbyte_b32 */
 __device__ __forceinline__ uint32_t rd32u(const Src &s, uint32_t a, bool far)
 {
@@ -142,11 +150,13 @@ __device__ __forceinline__ uint32_t chunk_len(const Src &s, uint32_t p, uint32_t
     uint32_t P[9], Q[9];
     load_dw<9>(s, p, false, P);
     load_dw<9>(s, q, far, Q);
+    /* first differing byte of dword i = 4i + (v_ffbl_b32(x) >> 3); v_ffbl gives -1 for "no difference", which the
+     * unsigned min chain then ignores: xor / ffbl / shift-add per dword plus a few v_min3, no compare-select chain */
     uint32_t L = 32u;
 #pragma unroll
-    for (int i = 7; i >= 0; i--) {
+    for (int i = 0; i < 8; i++) {
         const uint32_t x = __builtin_amdgcn_alignbyte(P[i + 1], P[i], ps) ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
-        if (x) L = 4u * (uint32_t)i + ((uint32_t)__builtin_ctz(x) >> 3);
+        L = umin(L, first_diff(x) + 4u * (uint32_t)i);
     }
     return L;
 }
@@ -159,9 +169,9 @@ __device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&own)
     load_dw<5>(s, q, far, Q);
     uint32_t L = 16u;
 #pragma unroll
-    for (int i = 3; i >= 0; i--) {
+    for (int i = 0; i < 4; i++) {
         const uint32_t x = __builtin_amdgcn_alignbyte(own[i + 1], own[i], ps) ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
-        if (x) L = 4u * (uint32_t)i + ((uint32_t)__builtin_ctz(x) >> 3);
+        L = umin(L, first_diff(x) + 4u * (uint32_t)i);
     }
     return L;
 }
@@ -775,7 +785,11 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             /* start flags: the lazy rules compare capped lengths and never look across the window edge */
             const bool take = cl != 0u && cl >= min_len(pf, off);
             const uint32_t tl = take ? cl : 0u; /* length if this position could start a match, else 0 */
-            const uint32_t tl1 = __shfl_down(tl, 1), tl2 = __shfl_down(tl, 2), tl3 = __shfl_down(tl, 3);
+            /* the next three positions' values: whole-wave DPP shifts (wave_shl:1 = lane i reads lane i+1), three
+             * VALU moves instead of three LDS permutes; what lane 63/62/61 read is masked by the edge rule below */
+            const uint32_t tl1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x130, 0xF, 0xF, true);
+            const uint32_t tl2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl1, 0x130, 0xF, 0xF, true);
+            const uint32_t tl3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl2, 0x130, 0xF, 0xF, true);
             const bool defer1 = pf.lazy >= 1u && lane < 63u && tl1 > cl;      /* next position: strictly longer */
             const bool defer2 = pf.lazy >= 2u && lane < 62u && tl2 > cl;      /* two on: strictly longer */
             const bool defer3 = pf.lazy >= 3u && lane < 61u && tl3 > cl + 2u; /* three on: longer by more than two */
