@@ -111,6 +111,25 @@ __device__ __forceinline__ uint32_t ring_dw(uint32_t a)
     return umin(m, m - kRing) >> 2;
 }
 
+/* ring offsets kept incrementally (the matchers' hot path): x mod kRing moved by d < kRing, one add + one min */
+__device__ __forceinline__ uint32_t ring_fwd(uint32_t r, uint32_t d) { const uint32_t t = r + d; return umin(t, t - kRing); }
+__device__ __forceinline__ uint32_t ring_back(uint32_t r, uint32_t d) { const uint32_t t = r - d; return umin(t, t + kRing); }
+
+/* the same with the ring offset r of position a already known */
+template <int N>
+__device__ __forceinline__ void load_dw_r(const Src &s, uint32_t a, uint32_t r, bool far, uint32_t (&D)[N])
+{
+    if (far) {
+        const uint32_t d = a >> 2;
+#pragma unroll
+        for (int i = 0; i < N; i++) D[i] = s.g[d + i];
+    } else {
+        const uint32_t d = r >> 2;
+#pragma unroll
+        for (int i = 0; i < N; i++) D[i] = s.ring[d + i];
+    }
+}
+
 /* N consecutive aligned dwords covering byte position a: from the ring, or from HBM when `far` */
 template <int N>
 __device__ __forceinline__ void load_dw(const Src &s, uint32_t a, bool far, uint32_t (&D)[N])
@@ -144,12 +163,12 @@ __device__ __forceinline__ uint32_t rd32u(const Src &s, uint32_t a, bool far)
 
 /* first mismatching byte (0..32) of the 32 bytes at p (ring) and at q (ring or HBM): 9 aligned
  * dwords per side are fetched with independent loads (ONE round trip), then compared in registers */
-__device__ __forceinline__ uint32_t chunk_len(const Src &s, uint32_t p, uint32_t q, bool far)
+__device__ __forceinline__ uint32_t chunk_len(const Src &s, uint32_t p, uint32_t rp, uint32_t off, bool far)
 {
-    const uint32_t ps = p & 3u, qs = q & 3u;
+    const uint32_t q = p - off, ps = p & 3u, qs = q & 3u; /* rp = ring offset of p; the source sits `off` before */
     uint32_t P[9], Q[9];
-    load_dw<9>(s, p, false, P);
-    load_dw<9>(s, q, far, Q);
+    load_dw_r<9>(s, p, rp, false, P);
+    load_dw_r<9>(s, q, ring_back(rp, off), far, Q);
     /* first differing byte of dword i = 4i + (v_ffbl_b32(x) >> 3); v_ffbl gives -1 for "no difference", which the
      * unsigned min chain then ignores: xor / ffbl / shift-add per dword plus a few v_min3, no compare-select chain */
     uint32_t L = 32u;
@@ -162,11 +181,12 @@ __device__ __forceinline__ uint32_t chunk_len(const Src &s, uint32_t p, uint32_t
 }
 
 /* first mismatching byte (0..16) of the 16 bytes at p (5 aligned dwords already in `own`) and at q */
-__device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&own)[5], uint32_t ps, uint32_t q, bool far)
+__device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&own)[5], uint32_t ps, uint32_t q, uint32_t rq,
+                                             bool far)
 {
     const uint32_t qs = q & 3u;
     uint32_t Q[5];
-    load_dw<5>(s, q, far, Q);
+    load_dw_r<5>(s, q, rq, far, Q);
     uint32_t L = 16u;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -639,6 +659,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 
     /* (offset, jump length) of this thread's position in tiles it-1 and it-2 */
     uint32_t offA = 0, lenA = 0, offB = 0, lenB = 0;
+    uint32_t rp = tid; /* ring offset of the own position, advanced by one tile per iteration */
 #ifdef QZ_DEBUG_DUMP
     u64 dI1 = 0, dW1 = 0, dI2 = 0, dW2 = 0, tP = __builtin_amdgcn_s_memtime();
 #define QZ_LAP(acc) { const u64 tN = __builtin_amdgcn_s_memtime(); acc += tN - tP; tP = tN; }
@@ -657,7 +678,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         /* the position's own first 20 bytes (5 aligned dwords): issued first so that their LDS latency
          * hides behind the emission below; used by the hash now and by the candidate compare later */
         uint32_t own[5];
-        load_dw<5>(src, valid ? p : 0u, false, own);
+        load_dw_r<5>(src, p, rp, false, own);
         /* refill: the 512 bytes that enter the look-ahead window this iteration (HBM -> registers now,
          * registers -> ring after the barrier; the ring slots they replace left everyone's reach
          * three tiles ago) */
@@ -716,24 +737,24 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             if (QZ_ABLATED(2u)) q1 = kNone;
             uint32_t l1 = 0, l2 = 0, l3 = 0;
             const bool far1 = q1 != kNone && p - q1 > kNear;
-            if (q1 != kNone) l1 = head_len(src, own, p & 3u, q1, far1);
+            if (q1 != kNone) l1 = head_len(src, own, p & 3u, q1, ring_back(rp, p - q1), far1);
             /* candidate 3 (levels >= 3): newest earlier-tile position whose first 8 bytes hash alike */
             uint32_t q3 = kNone;
             if (HAS_LONG && validL && oldL != 0u && (oldL & kTagMask) == tagL && !QZ_ABLATED(2u)) q3 = (oldL >> kTagBits) - 1u;
             const bool far3 = q3 != kNone && p - q3 > kNear;
-            if (q3 != kNone) l3 = head_len(src, own, p & 3u, q3, far3);
+            if (q3 != kNone) l3 = head_len(src, own, p & 3u, q3, ring_back(rp, p - q3), far3);
             if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
                 if (q < p && !QZ_ABLATED(2u)) q2 = q;
             }
-            if (q2 != kNone) l2 = head_len(src, own, p & 3u, q2, false); /* same tile: always near */
+            if (q2 != kNone) l2 = head_len(src, own, p & 3u, q2, ring_back(rp, p - q2), false); /* same tile: always near */
             /* survivors of the 16-byte head: 32 more bytes per step, all candidates in one loop */
             bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u, need3 = HAS_LONG && l3 == 16u && cap > 16u;
             while (need1 || need2 || need3) {
                 const int which = need1 ? 1 : (need3 ? 3 : 2);
                 const uint32_t q = which == 1 ? q1 : (which == 3 ? q3 : q2);
                 const uint32_t L = which == 1 ? l1 : (which == 3 ? l3 : l2);
-                const uint32_t l = chunk_len(src, p + L, q + L, which == 1 ? far1 : (which == 3 ? far3 : false));
+                const uint32_t l = chunk_len(src, p + L, ring_fwd(rp, L), p - q, which == 1 ? far1 : (which == 3 ? far3 : false));
                 const bool more = l == 32u && L + 32u < cap;
                 if (which == 1) { l1 = L + l; need1 = more; }
                 else if (which == 3) { l3 = L + l; need3 = more; }
@@ -766,10 +787,10 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                     const bool far = p - q > kNear;
                     link = __hip_atomic_load(chainB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* next link: in flight during the compare */
                     if (pf.window == 0u || p - q <= pf.window) {
-                        uint32_t l = head_len(src, own, p & 3u, q, far);
+                        uint32_t l = head_len(src, own, p & 3u, q, ring_back(rp, p - q), far);
                         if (l == 16u && cap > 16u) {
                             for (;;) {
-                                const uint32_t c = chunk_len(src, p + l, q + l, far);
+                                const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q, far);
                                 l += c;
                                 if (c < 32u || l >= cap) break;
                             }
@@ -807,6 +828,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         }
         offA = off;
         lenA = cl;
+        rp = ring_fwd(rp, kTile);
         QZ_LAP(dI2)
         __syncthreads(); /* B2 */
         QZ_LAP(dW2)
