@@ -145,12 +145,13 @@ __device__ __forceinline__ void load_dw(const Src &s, uint32_t a, bool far, uint
     }
 }
 
-/* index of the first non-zero byte of x (little endian), or 0x1FFFFFFF when x == 0 */
-__device__ __forceinline__ uint32_t first_diff(uint32_t x)
+/* bit index of the lowest set bit of x, or 0xFFFFFFFF when x == 0 (raw v_ffbl_b32: exactly the "no
+ * difference" value an unsigned min chain wants; OR-ing 32*i into it cannot wrap) */
+__device__ __forceinline__ uint32_t first_diff_bit(uint32_t x)
 {
-    uint32_t r; /* v_ffbl_b32 returns -1 for 0: exactly the "no difference" value the min chain wants */
+    uint32_t r;
     asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
-    return r >> 3;
+    return r;
 }
 
 /* 4 bytes at an arbitrary position: two aligned dwords + v_alignbyte_b32 */
@@ -169,31 +170,30 @@ __device__ __forceinline__ uint32_t chunk_len(const Src &s, uint32_t p, uint32_t
     uint32_t P[9], Q[9];
     load_dw_r<9>(s, p, rp, false, P);
     load_dw_r<9>(s, q, ring_back(rp, off), far, Q);
-    /* first differing byte of dword i = 4i + (v_ffbl_b32(x) >> 3); v_ffbl gives -1 for "no difference", which the
-     * unsigned min chain then ignores: xor / ffbl / shift-add per dword plus a few v_min3, no compare-select chain */
-    uint32_t L = 32u;
+    /* first differing bit of dword i, | 32 i; -1 = "no difference" drops out of the unsigned min chain:
+     * xor / ffbl / or per dword plus a few v_min3 and one shift, no compare-select chain */
+    uint32_t B = 256u;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t x = __builtin_amdgcn_alignbyte(P[i + 1], P[i], ps) ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
-        L = umin(L, first_diff(x) + 4u * (uint32_t)i);
+        B = umin(B, first_diff_bit(x) | (32u * (uint32_t)i));
     }
-    return L;
+    return B >> 3;
 }
 
-/* first mismatching byte (0..16) of the 16 bytes at p (5 aligned dwords already in `own`) and at q */
-__device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&own)[5], uint32_t ps, uint32_t q, uint32_t rq,
-                                             bool far)
+/* first mismatching byte (0..16) of the 16 bytes at p (already byte-aligned in `oa`) and at q */
+__device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&oa)[4], uint32_t q, uint32_t rq, bool far)
 {
     const uint32_t qs = q & 3u;
     uint32_t Q[5];
     load_dw_r<5>(s, q, rq, far, Q);
-    uint32_t L = 16u;
+    uint32_t B = 128u;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const uint32_t x = __builtin_amdgcn_alignbyte(own[i + 1], own[i], ps) ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
-        L = umin(L, first_diff(x) + 4u * (uint32_t)i);
+        const uint32_t x = oa[i] ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
+        B = umin(B, first_diff_bit(x) | (32u * (uint32_t)i));
     }
-    return L;
+    return B >> 3;
 }
 
 __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint32_t off)
@@ -692,18 +692,20 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                              REP ? srec[(it & 1u) * kWin * kSrecWords] : 0u);
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
         const bool validL = HAS_LONG && valid && p + 8u <= n;
+        uint32_t oa[4]; /* the position's first 16 bytes, byte-aligned: hashed now, compared against every candidate later */
+#pragma unroll
+        for (int i = 0; i < 4; i++) oa[i] = __builtin_amdgcn_alignbyte(own[i + 1], own[i], p & 3u);
         if (valid) { /* phase A(it) */
-            const uint32_t s = p & 3u;
-            const uint32_t v = __builtin_amdgcn_alignbyte(own[1], own[0], s);
+            const uint32_t v = oa[0];
             uint32_t hi = 0;
-            if (pf.hashBytes > 4) hi = __builtin_amdgcn_alignbyte(own[2], own[1], s) & hiMask;
+            if (pf.hashBytes > 4) hi = oa[1] & hiMask;
             mix = (v * kPrime1) ^ (hi * kPrime2);
             slot = __umulhi(mix, pf.tableSize);
             nslot = mix >> nearShift;
             old = tbl[slot];
             if (pf.nearTab) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
             if (validL) { /* second table, keyed by the first 8 bytes */
-                const uint32_t m8 = (v * kPrime1) ^ (__builtin_amdgcn_alignbyte(own[2], own[1], s) * kPrime2);
+                const uint32_t m8 = (v * kPrime1) ^ (oa[1] * kPrime2);
                 slotL = __umulhi(m8, pf.longSize);
                 tagL = (m8 >> 3) & kTagMask;
                 oldL = tblL[slotL];
@@ -737,17 +739,17 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             if (QZ_ABLATED(2u)) q1 = kNone;
             uint32_t l1 = 0, l2 = 0, l3 = 0;
             const bool far1 = q1 != kNone && p - q1 > kNear;
-            if (q1 != kNone) l1 = head_len(src, own, p & 3u, q1, ring_back(rp, p - q1), far1);
+            if (q1 != kNone) l1 = head_len(src, oa, q1, ring_back(rp, p - q1), far1);
             /* candidate 3 (levels >= 3): newest earlier-tile position whose first 8 bytes hash alike */
             uint32_t q3 = kNone;
             if (HAS_LONG && validL && oldL != 0u && (oldL & kTagMask) == tagL && !QZ_ABLATED(2u)) q3 = (oldL >> kTagBits) - 1u;
             const bool far3 = q3 != kNone && p - q3 > kNear;
-            if (q3 != kNone) l3 = head_len(src, own, p & 3u, q3, ring_back(rp, p - q3), far3);
+            if (q3 != kNone) l3 = head_len(src, oa, q3, ring_back(rp, p - q3), far3);
             if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
                 if (q < p && !QZ_ABLATED(2u)) q2 = q;
             }
-            if (q2 != kNone) l2 = head_len(src, own, p & 3u, q2, ring_back(rp, p - q2), false); /* same tile: always near */
+            if (q2 != kNone) l2 = head_len(src, oa, q2, ring_back(rp, p - q2), false); /* same tile: always near */
             /* survivors of the 16-byte head: 32 more bytes per step, all candidates in one loop */
             bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u, need3 = HAS_LONG && l3 == 16u && cap > 16u;
             while (need1 || need2 || need3) {
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                     const bool far = p - q > kNear;
                     link = __hip_atomic_load(chainB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* next link: in flight during the compare */
                     if (pf.window == 0u || p - q <= pf.window) {
-                        uint32_t l = head_len(src, own, p & 3u, q, ring_back(rp, p - q), far);
+                        uint32_t l = head_len(src, oa, q, ring_back(rp, p - q), far);
                         if (l == 16u && cap > 16u) {
                             for (;;) {
                                 const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q, far);
