@@ -87,6 +87,9 @@ int qzstd_hip_device_name(int device, char *buf, size_t bufLen);
 void *qzstd_hip_malloc(int device, size_t bytes);
 void qzstd_hip_free(int device, void *dptr);
 void *qzstd_hip_host_alloc(size_t bytes); /* pinned, portable across devices */
+/* device-side address of a qzstd_hip_host_alloc() buffer: kernels may read descriptors from and write results
+ * to pinned host memory directly (small latency-bound requests skip the D2H copies that way) */
+void *qzstd_hip_host_device_ptr(void *hptr);
 void qzstd_hip_host_free(void *hptr);
 void *qzstd_hip_stream_create(int device);
 void qzstd_hip_stream_destroy(int device, void *stream);

@@ -900,9 +900,18 @@ void qzstd_hip_free(int device, void *dptr)
 void *qzstd_hip_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped);
     if (e != hipSuccess) { fail("hipHostMalloc", e); return nullptr; }
     return p;
+}
+
+void *qzstd_hip_host_device_ptr(void *hptr)
+{
+    void *d = nullptr;
+    if (!hptr) return nullptr;
+    hipError_t e = hipHostGetDevicePointer(&d, hptr, 0);
+    if (e != hipSuccess) { fail("hipHostGetDevicePointer", e); return nullptr; }
+    return d;
 }
 
 void qzstd_hip_host_free(void *hptr)

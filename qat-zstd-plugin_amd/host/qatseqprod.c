@@ -103,6 +103,7 @@ typedef struct {
     ZSTD_Sequence *hSeqs;     /* pinned, QZ_BATCH_MAX x seqStride */
     qzstd_hip_block_t *hDesc; /* pinned */
     unsigned int *hCount;     /* pinned */
+    void *dvSeqs, *dvDesc, *dvCount; /* device-side addresses of hSeqs / hDesc / hCount */
     pthread_cond_t cvLead;    /* the batch's leader (its first member) waits here: device idle / members staged */
     pthread_cond_t cvDone;    /* the other members wait here for the results */
 } QZSTD_Batch_T;
@@ -114,9 +115,6 @@ typedef struct {
     QZSTD_Batch_T batch[2];
     void *stream;
     unsigned char *dSrc;
-    ZSTD_Sequence *dSeqs;
-    qzstd_hip_block_t *dDesc;
-    unsigned int *dCount;
     void *dWork; /* launch scratch, grow-only */
     size_t dWorkCap;
     size_t seqStride;
@@ -258,9 +256,6 @@ static void qzFreeCoalescer(QZSTD_Coalescer_T *c)
         qzstd_hip_host_free(c->batch[b].hCount);
     }
     qzstd_hip_free(c->device, c->dSrc);
-    qzstd_hip_free(c->device, c->dSeqs);
-    qzstd_hip_free(c->device, c->dDesc);
-    qzstd_hip_free(c->device, c->dCount);
     qzstd_hip_free(c->device, c->dWork);
     if (c->stream) qzstd_hip_stream_destroy(c->device, c->stream);
     QZ_LOG(2, "device %d: %lu block(s) in %lu coalesced launch(es)\n", c->device, c->blocks, c->launches);
@@ -280,17 +275,17 @@ static int qzSetupCoalescer(QZSTD_Coalescer_T *c)
     c->seqStride = qzstd_hip_sequence_bound(QZSTD_HIP_BLOCK_MAX);
     c->stream = qzstd_hip_stream_create(c->device);
     c->dSrc = (unsigned char *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * QZ_SRC_STRIDE);
-    c->dSeqs = (ZSTD_Sequence *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * c->seqStride * sizeof(ZSTD_Sequence));
-    c->dDesc = (qzstd_hip_block_t *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * sizeof(qzstd_hip_block_t));
-    c->dCount = (unsigned int *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * sizeof(unsigned int));
-    ok = c->stream && c->dSrc && c->dSeqs && c->dDesc && c->dCount;
+    ok = c->stream && c->dSrc;
     for (b = 0; b < 2 && ok; b++) {
         QZSTD_Batch_T *bt = &c->batch[b];
         bt->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SRC_STRIDE);
         bt->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(QZ_BATCH_MAX * c->seqStride * sizeof(ZSTD_Sequence));
         bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(qzstd_hip_block_t));
         bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(unsigned int));
-        ok = bt->hSrc && bt->hSeqs && bt->hDesc && bt->hCount;
+        bt->dvSeqs = qzstd_hip_host_device_ptr(bt->hSeqs);
+        bt->dvDesc = qzstd_hip_host_device_ptr(bt->hDesc);
+        bt->dvCount = qzstd_hip_host_device_ptr(bt->hCount);
+        ok = bt->hSrc && bt->hSeqs && bt->hDesc && bt->hCount && bt->dvSeqs && bt->dvDesc && bt->dvCount;
     }
     if (!ok) {
         QZ_LOG(1, "coalescer setup failed on device %d: %s\n", c->device, qzstd_hip_last_error());
@@ -320,19 +315,14 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         if (work) c->dWork = qzGrowDev(dev, c->dWork, &c->dWorkCap, work);
         failed = work && !c->dWork;
     }
+    /* one copy in, one launch, one wait: the kernel reads the descriptors from and writes the sequences and
+     * counts to this batch's pinned host buffers directly (posted PCIe writes while it runs), which takes two
+     * copies and one synchronisation off the latency of a request */
     failed = failed || qzstd_hip_memcpy_h2d(dev, c->stream, c->dSrc, bt->hSrc, (size_t)n * QZ_SRC_STRIDE) ||
-             qzstd_hip_memcpy_h2d(dev, c->stream, c->dDesc, bt->hDesc, (size_t)n * sizeof(qzstd_hip_block_t)) ||
-             qzstd_hip_find_sequences(dev, c->stream, bt->level, c->dSrc, c->dDesc, (unsigned int)n, maxLen, c->dSeqs,
-                                      c->dCount, c->dWork, c->dWorkCap) ||
-             qzstd_hip_memcpy_d2h(dev, c->stream, bt->hCount, c->dCount, (size_t)n * sizeof(unsigned int)) ||
+             qzstd_hip_find_sequences(dev, c->stream, bt->level, c->dSrc, (const qzstd_hip_block_t *)bt->dvDesc,
+                                      (unsigned int)n, maxLen, bt->dvSeqs, (unsigned int *)bt->dvCount, c->dWork,
+                                      c->dWorkCap) ||
              qzstd_hip_stream_sync(dev, c->stream);
-    for (i = 0; i < n && !failed; i++) { /* gather every block's used prefix */
-        const size_t cnt = bt->hCount[i];
-        if (cnt == QZSTD_HIP_NSEQ_ERROR || cnt == 0 || cnt >= bt->req[i].cap - 1) continue;
-        failed = qzstd_hip_memcpy_d2h(dev, c->stream, bt->hSeqs + (size_t)i * c->seqStride,
-                                      c->dSeqs + (size_t)i * c->seqStride, cnt * sizeof(ZSTD_Sequence));
-    }
-    if (!failed) failed = qzstd_hip_stream_sync(dev, c->stream);
     for (i = 0; i < n; i++) {
         const size_t cnt = failed ? QZSTD_HIP_NSEQ_ERROR : bt->hCount[i];
         /* capacity rule, reference :1318-1322 */
