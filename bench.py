@@ -261,6 +261,17 @@ def main():
             out["e2e_zstd_compress2_plugin_repcodes"] = rep
             # ... and for unchanged callers (no hints: per-block callbacks merged by the coalescer; the callback
             # blocks its thread for the GPU's per-block latency, so more threads than cores is the way to use it)
+            # BASELINE config 3's level on the same framing: software level 6 vs the plugin (hash chains + repeat-offset
+            # aware parse, -E1), a quarter of the sample
+            if level == 1:
+                s6 = sample[:len(sample) // 4]
+                sw6 = c_benchmark(s6, block, 6, thr, mode=0, loops=2)
+                p6 = c_benchmark(s6, block, 6, thr, mode=1, hint=16, ext_rep=1, loops=4, env={"QZSTD_HIP_EXT_REPCODES": "1"})
+                if "csize" in p6 and "csize" in sw6:
+                    p6["csize_vs_sw"] = round(p6["csize"] / sw6["csize"], 4)
+                    p6["speedup_vs_sw"] = round(p6["MBps"] / max(sw6["MBps"], 1e-9), 2)
+                out["level6_cpu_libzstd_sw"] = sw6
+                out["level6_e2e_plugin_repcodes"] = p6
             out["e2e_zstd_compress2_plugin_unchanged_callers"] = c_benchmark(sample[:128 * block], block, level, 4 * thr,
                                                                              mode=1, loops=4)
         print(json.dumps(out))

@@ -72,8 +72,6 @@ typedef struct {
     size_t seqCap;
     /* grow-only buffers of the batched (hinted) path */
     unsigned char *dBatchSrc; size_t dBatchSrcCap;
-    ZSTD_Sequence *dBatchSeqs; size_t dBatchSeqsCap;
-    qzstd_hip_block_t *dBatchDesc; unsigned int *dBatchCount; size_t dBatchBlocksCap;
     /* launch scratch (hash chains of levels >= 6), grow-only: one block / a hinted batch */
     void *dWork; size_t dWorkCap;
     void *dBatchWork; size_t dBatchWorkCap;
@@ -149,6 +147,7 @@ typedef struct {
     ZSTD_Sequence *hSeqs;     /* pinned, nb x QZ_HINT_PITCH */
     unsigned int *hCount;     /* pinned */
     qzstd_hip_block_t *hDesc; /* pinned */
+    void *dvSeqs, *dvCount, *dvDesc; /* device-side addresses of the three: the kernel uses them directly */
     size_t hSrcCap, hSeqsCap, hCountCap, hDescCap; /* bytes */
 } QZSTD_Hint_T;
 
@@ -183,9 +182,6 @@ static void qzFreeSlot(QZSTD_Slot_T *s)
     qzstd_hip_free(s->device, s->dDesc);
     qzstd_hip_free(s->device, s->dCount);
     qzstd_hip_free(s->device, s->dBatchSrc);
-    qzstd_hip_free(s->device, s->dBatchSeqs);
-    qzstd_hip_free(s->device, s->dBatchDesc);
-    qzstd_hip_free(s->device, s->dBatchCount);
     qzstd_hip_free(s->device, s->dWork);
     qzstd_hip_free(s->device, s->dBatchWork);
     if (s->stream) qzstd_hip_stream_destroy(s->device, s->stream);
@@ -757,7 +753,10 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     h->hDesc = (qzstd_hip_block_t *)qzGrowHost(h->hDesc, &h->hDescCap, blocksBytes);
     h->hCount = (unsigned int *)qzGrowHost(h->hCount, &h->hCountCap, nb * sizeof(unsigned int));
     h->hSeqs = (ZSTD_Sequence *)qzGrowHost(h->hSeqs, &h->hSeqsCap, nb * QZ_HINT_PITCH * sizeof(ZSTD_Sequence));
-    if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs) return -1;
+    h->dvDesc = qzstd_hip_host_device_ptr(h->hDesc);
+    h->dvCount = qzstd_hip_host_device_ptr(h->hCount);
+    h->dvSeqs = qzstd_hip_host_device_ptr(h->hSeqs);
+    if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs || !h->dvDesc || !h->dvCount || !h->dvSeqs) return -1;
 
     i = qzTryGrabSlot(s->slotHint);
     if (i < 0) {
@@ -770,43 +769,30 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     sl = &gProc.slots[i];
     if (qzSetupSlot(sl) != QZSTD_OK) goto fail;
     sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, srcBytes);
-    sl->dBatchSeqs = (ZSTD_Sequence *)qzGrowDev(sl->device, sl->dBatchSeqs, &sl->dBatchSeqsCap,
-                                                nb * stride * sizeof(ZSTD_Sequence));
-    if (!sl->dBatchSrc || !sl->dBatchSeqs) goto fail;
-    if (sl->dBatchBlocksCap < nb) {
-        qzstd_hip_free(sl->device, sl->dBatchDesc);
-        qzstd_hip_free(sl->device, sl->dBatchCount);
-        sl->dBatchDesc = (qzstd_hip_block_t *)qzstd_hip_malloc(sl->device, blocksBytes);
-        sl->dBatchCount = (unsigned int *)qzstd_hip_malloc(sl->device, nb * sizeof(unsigned int));
-        sl->dBatchBlocksCap = sl->dBatchDesc && sl->dBatchCount ? nb : 0;
-        if (!sl->dBatchBlocksCap) goto fail;
-    }
-    tq = qzNowNs();
+    if (!sl->dBatchSrc) goto fail;
     {
         const size_t work = qzstd_hip_workspace_bytes(compressionLevel | gProc.levelFlags, (unsigned int)nb, (unsigned int)blockSize);
         if (work) sl->dBatchWork = qzGrowDev(sl->device, sl->dBatchWork, &sl->dBatchWorkCap, work);
         if (work && !sl->dBatchWork) goto fail;
     }
+    tq = qzNowNs();
     memcpy(h->hSrc, src, srcSize); /* pinned staging: the H2D below is then truly asynchronous */
     for (b = 0; b < nb; b++) {
         const size_t o = b * blockSize;
         h->hDesc[b].srcOff = o;
-        h->hDesc[b].seqOff = b * stride;
+        /* results go straight into the pinned buffer, QZ_HINT_PITCH entries per block: a block with more
+         * sequences reports an error and is redone by the per-block path when its callback comes */
+        h->hDesc[b].seqOff = b * QZ_HINT_PITCH;
         h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
-        h->hDesc[b].seqCap = (unsigned int)stride;
+        h->hDesc[b].seqCap = (unsigned int)(stride < QZ_HINT_PITCH ? stride : QZ_HINT_PITCH);
     }
     s->hintStageNs += qzNowNs() - tq;
     tq = qzNowNs();
     /* everything below is queued on the slot's stream and returns immediately */
     if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc, srcBytes) ||
-        qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchDesc, h->hDesc, blocksBytes) ||
-        qzstd_hip_find_sequences(sl->device, sl->stream, compressionLevel | gProc.levelFlags, sl->dBatchSrc, sl->dBatchDesc,
-                                 (unsigned int)nb, (unsigned int)blockSize, sl->dBatchSeqs, sl->dBatchCount, sl->dBatchWork,
-                                 sl->dBatchWorkCap) ||
-        qzstd_hip_memcpy_d2h(sl->device, sl->stream, h->hCount, sl->dBatchCount, nb * sizeof(unsigned int)) ||
-        qzstd_hip_memcpy2d_d2h(sl->device, sl->stream, h->hSeqs, QZ_HINT_PITCH * sizeof(ZSTD_Sequence), sl->dBatchSeqs,
-                               stride * sizeof(ZSTD_Sequence),
-                               (stride < QZ_HINT_PITCH ? stride : QZ_HINT_PITCH) * sizeof(ZSTD_Sequence), nb)) {
+        qzstd_hip_find_sequences(sl->device, sl->stream, compressionLevel | gProc.levelFlags, sl->dBatchSrc,
+                                 (const qzstd_hip_block_t *)h->dvDesc, (unsigned int)nb, (unsigned int)blockSize, h->dvSeqs,
+                                 (unsigned int *)h->dvCount, sl->dBatchWork, sl->dBatchWorkCap)) {
         (void)qzstd_hip_stream_sync(sl->device, sl->stream);
         goto fail;
     }
