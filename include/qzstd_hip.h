@@ -57,6 +57,8 @@ typedef struct {
                          * ZSTD_c_searchForExternalRepcodes on, which is libzstd's default from level 10) */
     uint32_t chainDepth; /* 0 = table probes only; n = also walk the main table's predecessor chain (a per-block
                          * array in device memory: chain[p] = the slot's content before p's tile), n candidates deep */
+    uint32_t subTileLog; /* 0 = the tables are updated once per tile; n = per 1<<n positions, in position order
+                         * (GPU: the matcher waves take turns), so a position also sees the earlier sub-tiles of its tile */
 } qzstd_hip_profile_t;
 
 /* One work item = one <=128 KiB block, parsed with no history

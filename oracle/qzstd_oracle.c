@@ -76,6 +76,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->repWin = (repcodes || level >= 10) ? 8u : 0u;
     /* levels >= 6 (zstd: lazy, 8 attempts, then lazy2 / btlazy2): walk the hash chain */
     out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : 0u);
+    out->subTileLog = level >= 6 ? 6u : 0u; /* the waves of those levels have the time to take turns */
     return 0;
 }
 
@@ -129,7 +130,9 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
     const uint32_t nl = pf->longSize && n >= 8u ? n - 7u : 0u; /* positions that have 8 bytes for the long table */
     const uint32_t nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0; /* hashable positions */
     const uint32_t T = 1u << pf->tileLog;
-    uint32_t t0, p;
+    const uint32_t S = pf->subTileLog ? 1u << pf->subTileLog : T;
+    uint32_t old0[1u << 10];
+    uint32_t t0, s0, p;
 
     memset(tbl, 0, sizeof(uint32_t) * pf->tableSize);
     if (pf->longSize) memset(tblL, 0, sizeof(uint32_t) * pf->longSize);
@@ -147,75 +150,84 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
                 if (e < near[hn]) near[hn] = e;
             }
         }
-        for (p = t0; p < t1; p++) {
-            const uint32_t v = qzo_rd32(src + p);
-            const uint32_t m = qzo_mix(src + p, pf->hashBytes);
-            const uint32_t cap = pf->capLen < n - p ? pf->capLen : n - p;
-            uint32_t bestLen = 0, bestOff = 0;
-            /* probe 1: newest position of EARLIER tiles in this slot (table as it was before the tile) */
-            const uint32_t e = tbl[qzo_slot(m, pf->tableSize)];
-            if (e != 0 && (e & QZO_TAG_MASK) == qzo_tag(m)) {
-                const uint32_t q = (e >> QZO_TAG_BITS) - 1u;
-                const uint32_t off = p - q;
-                if ((pf->window == 0 || off <= pf->window) && qzo_rd32(src + q) == v) {
-                    bestLen = qzo_prefix_len(src, q, p, cap);
-                    bestOff = off;
-                }
-            }
-            /* probe 3 (levels >= 3): newest position of EARLIER tiles whose first 8 bytes hash alike */
-            if (p < nl) {
-                const uint32_t m8 = qzo_mix8(src + p);
-                const uint32_t eL = tblL[qzo_slot(m8, pf->longSize)];
-                if (eL != 0 && (eL & QZO_TAG_MASK) == qzo_tag(m8)) {
-                    const uint32_t q = (eL >> QZO_TAG_BITS) - 1u;
-                    if (qzo_rd32(src + q) == v) {
-                        const uint32_t l = qzo_prefix_len(src, q, p, cap);
-                        if (l > bestLen) { bestLen = l; bestOff = p - q; } /* must be strictly longer */
+        /* levels with chains remember what every slot held before the tile: chain links never point into
+         * the tile that is being processed (on the GPU they live in device memory) */
+        if (pf->chainDepth)
+            for (p = t0; p < t1; p++) old0[p - t0] = tbl[qzo_slot(qzo_mix(src + p, pf->hashBytes), pf->tableSize)] >> QZO_TAG_BITS;
+        /* look-up and insertion go sub-tile by sub-tile (= the whole tile when subTileLog is 0) */
+        for (s0 = t0; s0 < t1; s0 += S) {
+            const uint32_t s1 = s0 + S < t1 ? s0 + S : t1;
+            for (p = s0; p < s1; p++) {
+                const uint32_t v = qzo_rd32(src + p);
+                const uint32_t m = qzo_mix(src + p, pf->hashBytes);
+                const uint32_t cap = pf->capLen < n - p ? pf->capLen : n - p;
+                uint32_t bestLen = 0, bestOff = 0;
+                /* probe 1: newest position of EARLIER (sub-)tiles in this slot (table as it was before the sub-tile) */
+                const uint32_t e = tbl[qzo_slot(m, pf->tableSize)];
+                if (e != 0 && (e & QZO_TAG_MASK) == qzo_tag(m)) {
+                    const uint32_t q = (e >> QZO_TAG_BITS) - 1u;
+                    const uint32_t off = p - q;
+                    if ((pf->window == 0 || off <= pf->window) && qzo_rd32(src + q) == v) {
+                        bestLen = qzo_prefix_len(src, q, p, cap);
+                        bestOff = off;
                     }
                 }
-            }
-            /* probe 2: earliest position of THIS tile in the near slot, if it lies before p */
-            if (pf->nearTab) {
-                const uint32_t en = near[qzo_near_slot(m, pf->tileLog)];
-                if (en != QZO_NEAR_EMPTY && (en & QZO_TAG_MASK) == qzo_tag(m)) {
-                    const uint32_t q = t0 + (en >> QZO_TAG_BITS);
-                    if (q < p && qzo_rd32(src + q) == v) {
-                        const uint32_t l = qzo_prefix_len(src, q, p, cap);
-                        /* longer wins; on a tie the nearer source (this one) wins */
-                        if (l >= bestLen) { bestLen = l; bestOff = p - q; }
+                /* probe 3 (levels >= 3): newest position of EARLIER tiles whose first 8 bytes hash alike */
+                if (p < nl) {
+                    const uint32_t m8 = qzo_mix8(src + p);
+                    const uint32_t eL = tblL[qzo_slot(m8, pf->longSize)];
+                    if (eL != 0 && (eL & QZO_TAG_MASK) == qzo_tag(m8)) {
+                        const uint32_t q = (eL >> QZO_TAG_BITS) - 1u;
+                        if (qzo_rd32(src + q) == v) {
+                            const uint32_t l = qzo_prefix_len(src, q, p, cap);
+                            if (l > bestLen) { bestLen = l; bestOff = p - q; } /* must be strictly longer */
+                        }
                     }
                 }
-            }
-            /* probes 4.. (levels >= 6): the predecessor chain of the main-table slot.  chain[x] = what the
-             * slot held before x's tile (position + 1, any tag; 0 = end).  The head itself was probe 1; a
-             * chain candidate replaces the best so far only with a strictly higher gain (4 per matched
-             * byte minus the bit length of the offset).  On the GPU chain[] lives in device memory. */
-            if (pf->chainDepth) {
-                const uint32_t head = e >> QZO_TAG_BITS; /* position + 1, or 0 */
-                uint32_t link, d;
-                int bg = bestLen ? (int)(4u * bestLen) - (int)(31u - (uint32_t)__builtin_clz(bestOff + 1u)) : -1000000;
-                chain[p] = head;
-                link = head ? chain[head - 1u] : 0u;
-                for (d = 1; d < pf->chainDepth && link != 0u; d++) {
-                    const uint32_t q = link - 1u;
-                    if ((pf->window == 0 || p - q <= pf->window) && qzo_rd32(src + q) == v) {
-                        const uint32_t l = qzo_prefix_len(src, q, p, cap);
-                        const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
-                        if (l >= 4u && g > bg) { bestLen = l; bestOff = p - q; bg = g; }
+                /* probe 2: earliest position of THIS tile in the near slot, if it lies before p */
+                if (pf->nearTab) {
+                    const uint32_t en = near[qzo_near_slot(m, pf->tileLog)];
+                    if (en != QZO_NEAR_EMPTY && (en & QZO_TAG_MASK) == qzo_tag(m)) {
+                        const uint32_t q = t0 + (en >> QZO_TAG_BITS);
+                        if (q < p && qzo_rd32(src + q) == v) {
+                            const uint32_t l = qzo_prefix_len(src, q, p, cap);
+                            /* longer wins; on a tie the nearer source (this one) wins */
+                            if (l >= bestLen) { bestLen = l; bestOff = p - q; }
+                        }
                     }
-                    link = chain[q];
                 }
+                /* probes 4.. (levels >= 6): the predecessor chain of the main-table slot.  chain[x] = what the
+                 * slot held before x's tile (position + 1, any tag; 0 = end).  The head itself was probe 1; a
+                 * chain candidate replaces the best so far only with a strictly higher gain (4 per matched
+                 * byte minus the bit length of the offset).  On the GPU chain[] lives in device memory. */
+                if (pf->chainDepth) {
+                    const uint32_t head = old0[p - t0]; /* position + 1, or 0: the slot BEFORE the whole tile */
+                    uint32_t link = head, d;
+                    int bg = bestLen ? (int)(4u * bestLen) - (int)(31u - (uint32_t)__builtin_clz(bestOff + 1u)) : -1000000;
+                    chain[p] = head;
+                    /* probe 1 looked at the slot's current head; if that still is `head`, start one link further */
+                    if (link == (e >> QZO_TAG_BITS)) link = link ? chain[link - 1u] : 0u;
+                    for (d = 1; d < pf->chainDepth && link != 0u; d++) {
+                        const uint32_t q = link - 1u;
+                        if ((pf->window == 0 || p - q <= pf->window) && qzo_rd32(src + q) == v) {
+                            const uint32_t l = qzo_prefix_len(src, q, p, cap);
+                            const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
+                            if (l >= 4u && g > bg) { bestLen = l; bestOff = p - q; bg = g; }
+                        }
+                        link = chain[q];
+                    }
+                }
+                cand[p].len = bestLen;
+                cand[p].off = bestOff;
             }
-            cand[p].len = bestLen;
-            cand[p].off = bestOff;
-        }
-        /* insert the tile: ascending order == "largest position wins" (GPU: ds_max_u32) */
-        for (p = t0; p < t1; p++) {
-            const uint32_t m = qzo_mix(src + p, pf->hashBytes);
-            tbl[qzo_slot(m, pf->tableSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m);
-            if (p < nl) {
-                const uint32_t m8 = qzo_mix8(src + p);
-                tblL[qzo_slot(m8, pf->longSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m8);
+            /* insert the sub-tile: ascending order == "largest position wins" (GPU: ds_max_u32) */
+            for (p = s0; p < s1; p++) {
+                const uint32_t m = qzo_mix(src + p, pf->hashBytes);
+                tbl[qzo_slot(m, pf->tableSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m);
+                if (p < nl) {
+                    const uint32_t m8 = qzo_mix8(src + p);
+                    tblL[qzo_slot(m8, pf->longSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m8);
+                }
             }
         }
     }
@@ -368,7 +380,7 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
 
     if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
-        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->chainDepth > 64 || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
+        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->chainDepth > 64 || pf->subTileLog > pf->tileLog || (pf->subTileLog && pf->subTileLog < 4) || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
         return QZO_ERROR;
     nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
 

@@ -562,6 +562,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     uint32_t *nearTab = tblL + pf.longSize;
     uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
     uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kPvStride] per-position parse words         */
+    uint32_t *turnCtr = pv + 2u * kPvStride;           /* whose turn it is to update the tables (CHAIN)   */
     const uint8_t *gsrc = args.src + blk.srcOff;
     const uint4 *g128 = reinterpret_cast<const uint4 *>(gsrc);
     Src src;
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         }
         for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
-        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride; i += kThreads) srec[i] = 0u; /* srec, pv */
+        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
     }
     __syncthreads();
 
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 const uint32_t m8 = (v * kPrime1) ^ (oa[1] * kPrime2);
                 slotL = __umulhi(m8, pf.longSize);
                 tagL = (m8 >> 3) & kTagMask;
-                oldL = tblL[slotL];
+                if (!CHAIN) oldL = tblL[slotL];
             }
         }
         QZ_LAP(dI1)
@@ -723,11 +724,31 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         }
         offB = offA; lenB = lenA;
         uint32_t cl = 0, off = 0; /* capped candidate length, offset */
+        const uint32_t old0 = old; /* the main-table slot before the tile: head of the chain (CHAIN) */
+        if (CHAIN) {
+            /* levels >= 6 update the tables per 64 positions, in position order: the matcher waves take turns
+             * (LDS counter, acquire/release at workgroup scope), each reading its slots before inserting its own
+             * positions, so a position also sees the earlier waves of its tile (profile.subTileLog = 6).  The spin is
+             * bounded: a lost turn would give wrong candidates, never a hung GPU. */
+            const uint32_t turn = it * (uint32_t)kMatchWaves + wave;
+            uint32_t spins = 0;
+            while (__hip_atomic_load(turnCtr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != turn && ++spins < (1u << 22))
+                __builtin_amdgcn_s_sleep(1);
+            if (valid) {
+                old = tbl[slot];
+                if (validL) oldL = tblL[slotL];
+                atomicMax(&tbl[slot], ((p + 1u) << kTagBits) | ((mix >> 3) & kTagMask));
+                if (validL) atomicMax(&tblL[slotL], ((p + 1u) << kTagBits) | tagL);
+            }
+            if (lane == 0u) __hip_atomic_store(turnCtr, turn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         if (valid) {
             const uint32_t tag = (mix >> 3) & kTagMask;
             const uint32_t en = pf.nearTab ? nearTab[nslot] : 0xFFFFFFFFu;
-            atomicMax(&tbl[slot], ((p + 1u) << kTagBits) | tag);
-            if (validL) atomicMax(&tblL[slotL], ((p + 1u) << kTagBits) | tagL);
+            if (!CHAIN) {
+                atomicMax(&tbl[slot], ((p + 1u) << kTagBits) | tag);
+                if (validL) atomicMax(&tblL[slotL], ((p + 1u) << kTagBits) | tagL);
+            }
             const uint32_t cap = umin(pf.capLen, n - p);
             /* candidate 1: newest position of earlier tiles (known since interval 1: its bytes are fetched
              * while the near-table read is still in flight); candidate 2: earliest of this tile */
@@ -778,9 +799,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             int bg = cl ? (int)(4u * cl) - (int)(31u - (uint32_t)__builtin_clz(off + 1u)) : -1000000;
             const uint32_t cap = valid ? umin(pf.capLen, n - p) : 0u;
             if (valid) {
-                const uint32_t head = old >> kTagBits;
+                const uint32_t head = old0 >> kTagBits; /* what the slot held before the tile */
                 chainB[p] = head;
-                if (head) link = __hip_atomic_load(chainB + (head - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                link = head;
+                /* candidate 1 looked at the slot's current head; if that still is `head`, start one link further */
+                if (head == (old >> kTagBits) && head)
+                    link = __hip_atomic_load(chainB + (head - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             for (uint32_t d = 1; d < pf.chainDepth; d++) {
                 if (!__ballot(link != 0u)) break;
@@ -992,7 +1016,8 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (qzstd_hip_profile_for_level(level, maxBlockLen, &a.prof))
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12 (optionally | QZSTD_HIP_LEVEL_REPCODES)");
     if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
-        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 8 || a.prof.chainDepth > 64)
+        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 8 || a.prof.chainDepth > 64 ||
+        (a.prof.chainDepth ? a.prof.subTileLog != 6u : a.prof.subTileLog != 0u))
         return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");

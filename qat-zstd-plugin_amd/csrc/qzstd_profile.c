@@ -47,6 +47,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     out->repWin = (repcodes || level >= 10) ? 8u : 0u;
     /* levels >= 6 (zstd: lazy, 8 attempts, then lazy2 / btlazy2): walk the hash chain */
     out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : 0u);
+    out->subTileLog = level >= 6 ? 6u : 0u; /* the waves of those levels have the time to take turns */
     return 0;
 }
 

@@ -82,8 +82,9 @@ def test_workspace_only_for_chain_levels(plugin):
     W = plugin.lib.qzstd_hip_workspace_bytes
     for level in range(1, 6):
         assert W(level, 100, 131072) == 0 and plugin.profile(level, 131072).chainDepth == 0
+        assert plugin.profile(level, 131072).subTileLog == 0
     for level in range(6, 13):
-        assert plugin.profile(level, 131072).chainDepth in (8, 16)
+        assert plugin.profile(level, 131072).chainDepth in (8, 16) and plugin.profile(level, 131072).subTileLog == 6
         assert W(level, 100, 131072) == 100 * 131072 * 4
         assert W(level, 3, 1000) == 3 * 1024 * 4
     assert W(6, 1, 131073) == 0 and W(0, 1, 1000) == 0

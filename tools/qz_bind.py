@@ -174,7 +174,7 @@ class Zstd:
 class OracleProfile(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("tableSize", "tileLog", "capLen", "minMatch", "farLog1",
                                           "farLog2", "lazy", "backExt", "nearTab", "window",
-                                          "hashBytes", "extLog", "longSize", "repWin", "chainDepth")]
+                                          "hashBytes", "extLog", "longSize", "repWin", "chainDepth", "subTileLog")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
