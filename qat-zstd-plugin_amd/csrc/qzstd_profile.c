@@ -45,9 +45,9 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     /* libzstd turns repeat offsets of external sequences into repcodes only from level 10 (or when the
      * caller sets ZSTD_c_searchForExternalRepcodes); without that, short repeat matches cost a full offset */
     out->repWin = (repcodes || level >= 10) ? 8u : 0u;
-    /* levels >= 6 (zstd: lazy, 8 attempts, then lazy2 / btlazy2): walk the hash chain */
-    out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : 0u);
-    out->subTileLog = level >= 6 ? 6u : 0u; /* the waves of those levels have the time to take turns */
+    /* levels >= 5 (zstd: greedy, then lazy with 8 attempts, lazy2, btlazy2): walk the hash chain */
+    out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : (level >= 5 ? 4u : 0u));
+    out->subTileLog = level >= 5 ? 6u : 0u; /* the waves of those levels have the time to take turns */
     return 0;
 }
 
