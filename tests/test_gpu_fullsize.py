@@ -1,0 +1,94 @@
+"""BASELINE config #2 at full size on the GPU (8192 x 128 KiB = 1 GiB resident in HBM, level 1): the sizes the
+oracle cannot walk in seconds are covered by size-independent properties, checked on the device with torch —
+every block's sequences add up to the block, every offset is in range, every match is a true copy (first and
+last 4 bytes of each of the ~53 M matches), the run is deterministic — plus exact parity with the oracle on a
+random sample of the blocks."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  imported at collection time, BEFORE any fixture loads libqatseqprod.so: the process must
+#                     end up with ONE HIP runtime (torch's bundled copy), as in bench.py
+
+import qz_bind as B
+import qz_corpus as K
+
+pytestmark = pytest.mark.gpu
+
+NB, BLOCK = 8192, 131072
+
+
+def test_config2_full_size_properties_and_sampled_parity(gpu_plugin, oracle):
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    L = gpu_plugin.lib
+    data = K.by_name("system", NB * BLOCK)
+    stride = B.sequence_bound(BLOCK)
+    d_src = torch.zeros(NB * BLOCK + 64, dtype=torch.uint8, device=dev)
+    d_src[:NB * BLOCK].copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+    d_seqs = torch.zeros((NB, stride, 4), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(NB, dtype=torch.int32, device=dev)
+    desc = (B.HipBlock * NB)()
+    for i in range(NB):
+        desc[i].srcOff, desc[i].seqOff, desc[i].srcLen, desc[i].seqCap = i * BLOCK, i * stride, BLOCK, stride
+    d_desc = torch.empty(C.sizeof(desc), dtype=torch.uint8, device=dev)
+    d_desc.copy_(torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8))
+    torch.cuda.synchronize()
+
+    def launch():
+        rc = L.qzstd_hip_find_sequences(0, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1, C.c_void_p(d_src.data_ptr()),
+                                        C.c_void_p(d_desc.data_ptr()), NB, BLOCK, C.c_void_p(d_seqs.data_ptr()),
+                                        C.c_void_p(d_cnt.data_ptr()), None, 0)
+        assert rc == 0, gpu_plugin.err()
+        torch.cuda.synchronize()
+
+    launch()
+    cnt = d_cnt.to(torch.int64)
+    assert int((cnt <= 0).sum()) == 0 and int((cnt >= stride - 1).sum()) == 0  # no error blocks, capacity rule holds
+    first = (d_seqs[:, :, :3].to(torch.int64).sum(dim=(1, 2)) * 0).sum()  # touch: keeps the tensor alive
+    assert int(first) == 0
+    src64 = d_src.to(torch.int64)
+    bad_sum = bad_off = bad_copy = bad_delim = 0
+    total_seq = 0
+    for b0 in range(0, NB, 256):  # a slab of blocks at a time (bounded scratch)
+        s = d_seqs[b0:b0 + 256].to(torch.int64)
+        c = cnt[b0:b0 + 256]
+        idx = torch.arange(stride, device=dev).unsqueeze(0)
+        used = idx < c.unsqueeze(1)
+        off, lit, ml = s[:, :, 0] * used, s[:, :, 1] * used, s[:, :, 2] * used
+        bad_sum += int(((lit + ml).sum(dim=1) != BLOCK).sum())
+        pos = torch.cumsum(lit + ml, dim=1) - ml  # start of each match inside its block
+        is_match = used & (idx < (c - 1).unsqueeze(1))
+        bad_delim += int((((ml != 0) | (off != 0)) & used & ~is_match).sum())  # the last entry is the delimiter
+        bad_delim += int((is_match & (ml < 3)).sum())
+        bad_off += int((is_match & ((off < 1) | (off > pos))).sum())
+        base = (torch.arange(b0, b0 + s.shape[0], device=dev) * BLOCK).unsqueeze(1)
+        p, q, m = (base + pos)[is_match], (base + pos - off)[is_match], ml[is_match]
+        for k in range(4):  # first 4 and last 4 bytes of every match equal their source
+            kk = torch.minimum(torch.full_like(m, k), m - 1)
+            bad_copy += int((src64[p + kk] != src64[q + kk]).sum())
+            bad_copy += int((src64[p + m - 1 - kk] != src64[q + m - 1 - kk]).sum())
+        total_seq += int(c.sum())
+    assert (bad_sum, bad_off, bad_copy, bad_delim) == (0, 0, 0, 0)
+    assert total_seq > NB * 1000
+
+    # deterministic: a second launch gives the same counts and the same sequences
+    chk1 = (d_seqs[:, :, :3].to(torch.int64) * torch.tensor([1, 3, 7], device=dev)).sum(dim=(1, 2)) + cnt
+    keep = [d_seqs[i, :int(cnt[i]), :3].cpu().numpy().copy() for i in (0, NB // 2, NB - 1)]
+    d_seqs.zero_()
+    launch()
+    chk2 = (d_seqs[:, :, :3].to(torch.int64) * torch.tensor([1, 3, 7], device=dev)).sum(dim=(1, 2)) + d_cnt.to(torch.int64)
+    assert torch.equal(chk1, chk2)
+    for i, want in zip((0, NB // 2, NB - 1), keep):
+        assert np.array_equal(d_seqs[i, :len(want), :3].cpu().numpy(), want)
+
+    # exact parity with the oracle on a random sample of blocks
+    rng = random.Random(20250928)
+    for i in rng.sample(range(NB), 24):
+        blk = data[i * BLOCK:(i + 1) * BLOCK]
+        n, want = oracle.find(oracle.profile(1, BLOCK), blk, cap=stride)
+        assert int(cnt[i]) == n, i
+        w = np.frombuffer(want, dtype=np.uint32).reshape(-1, 4)[:n, :3].astype(np.int64)
+        g = d_seqs[i, :n, :3].cpu().numpy().astype(np.int64)
+        assert np.array_equal(g, w), "block %d differs from the oracle" % i
