@@ -274,6 +274,10 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
     uint32_t word[kWin];
 #pragma unroll
     for (uint32_t w = W_BEGIN; w < W_END; w++) word[w] = pv[64u * w + lane];
+    /* pin the loads here: otherwise the compiler sinks each one into its window and the serial chain pays the LDS
+     * latency once per window instead of once per call */
+#pragma unroll
+    for (uint32_t w = W_BEGIN; w < W_END; w++) asm volatile("" : "+v"(word[w]));
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0; /* lane w collects window w's record */
 #pragma unroll
     for (uint32_t w = W_BEGIN; w < W_END; w++) {
