@@ -41,7 +41,7 @@
 #define QZ_LEVEL_MIN 1
 #define QZ_LEVEL_MAX 12
 #define QZ_RETRY_INTERVAL_BLOCKS 1000 /* re-probe a dead device every N failed blocks */
-#define QZ_GRAB_SWEEPS 10000
+#define QZ_GRAB_SWEEPS 40000 /* 64 yields, then 50 us naps: about two seconds */
 #define QZ_MAX_DEVICES 64
 #define QZ_MAX_SLOTS 1024
 #define QZ_DEFAULT_SLOTS_PER_DEVICE 64
@@ -224,12 +224,20 @@ static int qzGrabSlot(int hint)
     const int n = gProc.numSlots;
     if (n <= 0) return -1;
     if (hint < 0 || hint >= n) hint = 0;
+    /* The reference sweeps its instances 10 times and then fails the block (src/qatseqprod.c:905-928, :915);
+     * here a caller WAITS for a slot: short spins first, then 50 us naps, giving up only after about two seconds
+     * (the reference's own time-out for a stuck request, :1261-1285) */
     for (sweep = 0; sweep < QZ_GRAB_SWEEPS; sweep++) {
         for (k = 0; k < n; k++) {
             const int i = (hint + k) % n;
             if (__sync_lock_test_and_set(&gProc.slots[i].lock, 1) == 0) return i;
         }
-        sched_yield(); /* every slot busy: more threads than slots; let the holders finish */
+        if (sweep < 64) {
+            sched_yield(); /* every slot busy: more threads than slots; let the holders finish */
+        } else {
+            const struct timespec nap = { 0, 50000 };
+            nanosleep(&nap, NULL);
+        }
     }
     return -1;
 }

@@ -287,6 +287,24 @@ def test_benchmark_tool_gpu_modes(started, tmp_path):
         assert out.stderr.count("PASS") == 3, out.stderr
 
 
+@pytest.mark.parametrize("level", [1, 6])
+def test_per_slot_path_without_coalescing(started, tmp_path, level):
+    """QZSTD_HIP_COALESCE=0: every caller owns a slot with its own stream and buffers for the duration of a
+    call, the reference's instance model (src/qatseqprod.c:905-933, :1156-1334); level 6 also exercises the
+    per-slot chain workspace"""
+    import os
+    import subprocess
+    tdir = os.path.join(B.PKG_DIR, "test")
+    subprocess.check_call(["make", "-C", tdir, "benchmark", "ZSTDLIB=" + B.find_libzstd()], stdout=subprocess.DEVNULL)
+    f = tmp_path / "corpus.bin"
+    f.write_bytes(K.by_name("system", 16 * 131072 + 4567))
+    env = dict(os.environ, QZSTD_HIP_COALESCE="0", QZSTD_HIP_SLOTS="4")
+    out = subprocess.run([os.path.join(tdir, "benchmark"), "-m1", "-t6", "-l1", "-c128K", "-L%d" % level, str(f)],
+                         capture_output=True, text=True, env=env)  # more threads than slots: callers wait for one
+    assert out.returncode == 0, out.stderr
+    assert out.stderr.count("PASS") == 6, out.stderr
+
+
 def test_coalescer_stress_mixed_levels_and_sizes(started, zstd, oracle):
     """many callers, two levels, ragged chunk sizes: the group-commit coalescer must hand every
     caller exactly its own block's sequences (frames identical to the oracle's)"""
