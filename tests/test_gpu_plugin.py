@@ -333,3 +333,31 @@ def test_coalescer_stress_mixed_levels_and_sizes(started, zstd, oracle):
         level, chunk, data = jobs[t]
         assert res[t] is not None
         assert res[t] == compress_with(zstd, oracle.producer_addr, None, data, chunk, level), "thread %d" % t
+
+
+def test_hinting_and_plain_callers_side_by_side(started, zstd, oracle):
+    """threads that announce their buffers (slots held while announcements are in flight) next to threads that
+    do not (coalescer), at a chain level and a plain one: everybody gets exactly the oracle's frames"""
+    nthreads = 12
+    jobs = []
+    for t in range(nthreads):
+        level = 6 if t % 4 == 0 else 1
+        chunk = 131072 if t % 3 else 65536  # both are 16-aligned block grids
+        data = K.by_name(["text", "binary", "weblog", "mix"][t % 4], chunk * 9 + 17 * t, seed=300 + t)
+        jobs.append((level, chunk, data, t % 2 == 0))
+    res = [None] * nthreads
+
+    def work(t):
+        level, chunk, data, hint = jobs[t]
+        z = B.Zstd(zstd.path)
+        st = started.lib.QZSTD_createSeqProdState()
+        res[t] = compress_with(z, started.producer_addr, st, data, chunk, level, hint_lib=started.lib if hint else None)
+        started.lib.QZSTD_freeSeqProdState(st)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for t in range(nthreads):
+        level, chunk, data, _ = jobs[t]
+        assert res[t] is not None, "thread %d died" % t
+        assert res[t] == compress_with(zstd, oracle.producer_addr, None, data, chunk, level), "thread %d" % t
