@@ -19,15 +19,23 @@
  *     not depend on wave scheduling; a tile-local ds_min_u32 table finds sources inside the
  *     current tile;
  *   - the 8 matcher waves measure the candidate lengths (16 bytes, then 32 per step), apply the
- *     lazy start rules with three shuffles, and reduce every position to one packed word;
+ *     lazy start rules with three DPP shifts, and reduce every position to one packed word;
  *   - a dedicated 9th wave runs the serial greedy chain as a 4-instruction scalar pointer chase
  *     (bitset / readlane / compare / select), extends capped matches cooperatively when it
  *     takes them, and publishes per-window records; the matcher waves then emit their chosen
  *     {offset, litLength, matchLength} entries ranked by a popcount prefix.
  *
+ * Kernel variants (template parameters of qzstd_find_sequences_kernel):
+ *   HAS_LONG  levels >= 3: the second table;
+ *   CHAIN     levels >= 5: hash chains, 4 B per position in DEVICE memory (the workspace argument of
+ *             qzstd_hip_find_sequences), walked after the table probes; and the tables are updated
+ *             per 64 positions, the matcher waves taking turns in position order;
+ *   REP       levels >= 10, or any level | QZSTD_HIP_LEVEL_REPCODES: the repeat-offset aware parse
+ *             (byte-wise ballot probe of the last two offsets on arrival at every match end).
+ *
  * Integer byte matching: no MFMA.  The roofline that bounds it is HBM (block read once,
- * 16 B per sequence written); in practice it is bound by LDS latency and instruction issue at
- * 18 waves per CU (profiles/).
+ * 16 B per sequence written); in practice it is bound by instruction issue at 18 waves per CU
+ * (profiles/).
  *
  * The sequential definition of exactly this computation is oracle/qzstd_oracle.c
  * (test infrastructure); tests compare the two sequence-for-sequence.
