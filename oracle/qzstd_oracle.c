@@ -76,7 +76,8 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->repWin = (repcodes || level >= 10) ? 8u : 0u;
     /* levels >= 5 (zstd: greedy, then lazy with 8 attempts, lazy2, btlazy2): walk the hash chain */
     out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : (level >= 5 ? 4u : 0u));
-    out->subTileLog = level >= 5 ? 6u : 0u; /* the waves of those levels have the time to take turns */
+    /* per-wave turns where the waves have the time (chains) and at level 2, which buys its better ratio with them */
+    out->subTileLog = (level >= 5 || level == 2) ? 6u : 0u;
     return 0;
 }
 

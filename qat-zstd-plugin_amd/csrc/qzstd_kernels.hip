@@ -28,8 +28,9 @@
  * Kernel variants (template parameters of qzstd_find_sequences_kernel):
  *   HAS_LONG  levels >= 3: the second table;
  *   CHAIN     levels >= 5: hash chains, 4 B per position in DEVICE memory (the workspace argument of
- *             qzstd_hip_find_sequences), walked after the table probes; and the tables are updated
- *             per 64 positions, the matcher waves taking turns in position order;
+ *             qzstd_hip_find_sequences), walked after the table probes;
+ *   TURNS     level 2 and levels >= 5: the tables are updated per 64 positions, the matcher waves taking
+ *             turns in position order;
  *   REP       levels >= 10, or any level | QZSTD_HIP_LEVEL_REPCODES: the repeat-offset aware parse
  *             (byte-wise ballot probe of the last two offsets on arrival at every match end).
  *
@@ -548,9 +549,10 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
  *   barrier
  *
  * HAS_LONG selects the level >= 3 variant with the second (8-byte-key) table, REP the repeat-offset aware
- * parse, CHAIN (levels >= 6) the walk along the main table's predecessor chain in device memory.
+ * parse, CHAIN (levels >= 5) the walk along the main table's predecessor chain in device memory, TURNS (level 2 and
+ * levels >= 5) the per-wave ordered table updates.
  */
-template <bool HAS_LONG, bool REP, bool CHAIN>
+template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
 __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -715,13 +717,13 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             mix = (v * kPrime1) ^ (hi * kPrime2);
             slot = __umulhi(mix, pf.tableSize);
             nslot = mix >> nearShift;
-            old = tbl[slot];
+            if (!TURNS || CHAIN) old = tbl[slot]; /* with turns only the chain needs the pre-tile content */
             if (pf.nearTab) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
             if (validL) { /* second table, keyed by the first 8 bytes */
                 const uint32_t m8 = (v * kPrime1) ^ (oa[1] * kPrime2);
                 slotL = __umulhi(m8, pf.longSize);
                 tagL = (m8 >> 3) & kTagMask;
-                if (!CHAIN) oldL = tblL[slotL];
+                if (!TURNS) oldL = tblL[slotL];
             }
         }
         QZ_LAP(dI1)
@@ -737,8 +739,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         offB = offA; lenB = lenA;
         uint32_t cl = 0, off = 0; /* capped candidate length, offset */
         const uint32_t old0 = old; /* the main-table slot before the tile: head of the chain (CHAIN) */
-        if (CHAIN) {
-            /* levels >= 6 update the tables per 64 positions, in position order: the matcher waves take turns
+        if (TURNS) {
+            /* level 2 and levels >= 5 update the tables per 64 positions, in position order: the matcher waves take turns
              * (LDS counter, acquire/release at workgroup scope), each reading its slots before inserting its own
              * positions, so a position also sees the earlier waves of its tile (profile.subTileLog = 6).  The spin is
              * bounded: a lost turn would give wrong candidates, never a hung GPU. */
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         if (valid) {
             const uint32_t tag = (mix >> 3) & kTagMask;
             const uint32_t en = pf.nearTab ? nearTab[nslot] : 0xFFFFFFFFu;
-            if (!CHAIN) {
+            if (!TURNS) {
                 atomicMax(&tbl[slot], ((p + 1u) << kTagBits) | tag);
                 if (validL) atomicMax(&tblL[slotL], ((p + 1u) << kTagBits) | tagL);
             }
@@ -1029,21 +1031,27 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12 (optionally | QZSTD_HIP_LEVEL_REPCODES)");
     if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
         a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 8 || a.prof.chainDepth > 64 ||
-        (a.prof.chainDepth ? a.prof.subTileLog != 6u : a.prof.subTileLog != 0u))
+        (a.prof.subTileLog != 0u && a.prof.subTileLog != 6u) || (a.prof.chainDepth && a.prof.subTileLog != 6u))
         return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");
     QZ_CHECK(hipSetDevice(device), "hipSetDevice");
-    const void *variants[6] = { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false>),
-                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, false>),
-                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false>),
-                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, false>),
-                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, true>),
-                                reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, true>) };
+    /* [long][rep][chain/turns: 0 none, 1 turns, 2 chain + turns] */
+    const void *variants[2][2][3] = {
+        { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, false>),
+            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, true>), nullptr },
+          { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, false>),
+            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, true>), nullptr } },
+        { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, false, false>), nullptr,
+            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, true, true>) },
+          { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, false, false>), nullptr,
+            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, true, true>) } } };
     if (attrDevice != device || attrBytes < lds) {
-        for (int v = 0; v < 6; v++)
-            QZ_CHECK(hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                     "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        for (int v = 0; v < 12; v++) {
+            const void *f = variants[v / 6][(v / 3) % 2][v % 3];
+            if (f) QZ_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        }
         attrDevice = device;
         attrBytes = lds;
     }
@@ -1064,9 +1072,10 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
 #endif
     const dim3 grid(nBlocks), wg(kThreads);
-    const int which = a.prof.chainDepth ? (a.prof.repWin ? 5 : 4) : ((a.prof.longSize ? 1 : 0) + (a.prof.repWin ? 2 : 0));
+    const void *kernel = variants[a.prof.longSize ? 1 : 0][a.prof.repWin ? 1 : 0][a.prof.chainDepth ? 2 : (a.prof.subTileLog ? 1 : 0)];
     void *kargs[1] = { &a };
-    QZ_CHECK(hipLaunchKernel(variants[which], grid, wg, kargs, lds, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
+    if (!kernel) return fail_msg("qzstd_hip_find_sequences: unsupported profile (no kernel variant)");
+    QZ_CHECK(hipLaunchKernel(kernel, grid, wg, kargs, lds, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     return 0;
 }

@@ -61,7 +61,7 @@ def test_degenerate_blocks(gpu_plugin, oracle, level):
     check_blocks(gpu_plugin, oracle, blocks, level)
 
 
-@pytest.mark.parametrize("level", [1, 3, 5, 6, 9, 10, 12, 0x101, 0x103, 0x105, 0x106])  # 0x100 = QZSTD_HIP_LEVEL_REPCODES
+@pytest.mark.parametrize("level", [1, 2, 3, 5, 6, 9, 10, 12, 0x101, 0x102, 0x103, 0x105, 0x106])  # 0x100 = QZSTD_HIP_LEVEL_REPCODES
 def test_levels(gpu_plugin, oracle, level):
     data = K.mix(11, 6 * 131072)
     check_blocks(gpu_plugin, oracle, [data[o:o + 131072] for o in range(0, len(data), 131072)], level)

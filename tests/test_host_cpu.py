@@ -82,7 +82,7 @@ def test_workspace_only_for_chain_levels(plugin):
     W = plugin.lib.qzstd_hip_workspace_bytes
     for level in range(1, 5):
         assert W(level, 100, 131072) == 0 and plugin.profile(level, 131072).chainDepth == 0
-        assert plugin.profile(level, 131072).subTileLog == 0
+        assert plugin.profile(level, 131072).subTileLog == (6 if level == 2 else 0)
     for level in range(5, 13):
         assert plugin.profile(level, 131072).chainDepth in (4, 8, 16) and plugin.profile(level, 131072).subTileLog == 6
         assert W(level, 100, 131072) == 100 * 131072 * 4
