@@ -660,8 +660,8 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
 
     if (gProc.coalesce) {
         /* sticky device per state, states spread round-robin over the GPUs */
-        static volatile int nextDev = 0;
-        if (s->slotHint < 0) s->slotHint = __sync_fetch_and_add(&nextDev, 1);
+        static volatile unsigned int nextDev = 0;
+        if (s->slotHint < 0) s->slotHint = (int)(__sync_fetch_and_add(&nextDev, 1u) & 0x3FFFFFFFu);
         rc = qzCoalescedBlock(s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize,
                               compressionLevel | gProc.levelFlags);
         if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
