@@ -259,8 +259,15 @@ def main():
             if "csize" in rep and "csize" in sw:
                 rep["csize_vs_sw"] = round(rep["csize"] / sw["csize"], 4)
             out["e2e_zstd_compress2_plugin_repcodes"] = rep
-            # ... and for unchanged callers (no hints: per-block callbacks merged by the coalescer; the callback
-            # blocks its thread for the GPU's per-block latency, so more threads than cores is the way to use it)
+            # ... and for unchanged callers (no hints at all): the plugin's transparent look-ahead guesses that the bytes
+            # behind the current block come next (fault-safe read, verified when used); what misses goes per block
+            # through the coalescer
+            un = c_benchmark(sample, block, level, thr, mode=1, loops=6)
+            if "csize" in un and "csize" in sw:
+                un["csize_vs_sw"] = round(un["csize"] / sw["csize"], 4)
+            out["e2e_zstd_compress2_plugin_unchanged_callers"] = un
+            out["e2e_zstd_compress2_plugin_unchanged_callers_no_lookahead"] = c_benchmark(
+                sample[:128 * block], block, level, thr, mode=1, loops=4, env={"QZSTD_HIP_LOOKAHEAD": "0"})
             # BASELINE config 3's level on the same framing: software level 6 vs the plugin (hash chains + repeat-offset
             # aware parse, -E1), a quarter of the sample
             if level == 1:
@@ -272,8 +279,6 @@ def main():
                     p6["speedup_vs_sw"] = round(p6["MBps"] / max(sw6["MBps"], 1e-9), 2)
                 out["level6_cpu_libzstd_sw"] = sw6
                 out["level6_e2e_plugin_repcodes"] = p6
-            out["e2e_zstd_compress2_plugin_unchanged_callers"] = c_benchmark(sample[:128 * block], block, level, 4 * thr,
-                                                                             mode=1, loops=4)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -24,6 +24,9 @@
  *
  * No QAT / icp_sal / cpa symbol is used or emulated.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* process_vm_readv: the fault-safe read behind the transparent look-ahead */
+#endif
 #include "qatseqprod.h"
 #include "qzstd_hip.h"
 
@@ -32,7 +35,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
+#include <sys/uio.h>
 #include <time.h>
+#include <unistd.h>
 
 #ifndef DEBUGLEVEL
 #define DEBUGLEVEL 0
@@ -44,7 +50,7 @@
 #define QZ_GRAB_SWEEPS 40000 /* 64 yields, then 50 us naps: about two seconds */
 #define QZ_MAX_DEVICES 64
 #define QZ_MAX_SLOTS 1024
-#define QZ_DEFAULT_SLOTS_PER_DEVICE 64
+#define QZ_DEFAULT_SLOTS_PER_DEVICE 128
 #define QZ_FIRST_COPY_SEQS 16384u /* sequences fetched together with the count */
 
 static int qzLogLevel = DEBUGLEVEL; /* 0 silent, 1 errors, 2 events, 3 every sequence */
@@ -128,10 +134,11 @@ typedef struct {
     QZSTD_Coalescer_T *coal; /* one per device */
     int coalesce;            /* QZSTD_HIP_COALESCE (default 1) */
     int levelFlags;          /* QZSTD_HIP_LEVEL_REPCODES when QZSTD_HIP_EXT_REPCODES=1 */
+    int lookahead;           /* QZSTD_HIP_LOOKAHEAD (default 1) and the fault-safe read works */
     pthread_mutex_t mutex;
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, PTHREAD_MUTEX_INITIALIZER };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, PTHREAD_MUTEX_INITIALIZER };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously on a slot's stream,
  * results (count + the first QZ_HINT_PITCH sequences of every block) copied back asynchronously. */
@@ -157,11 +164,19 @@ typedef struct {
     unsigned int failOffloadCnt;
     /* look-ahead batches served to later callbacks (QZSTD_hintSource): two, so that the GPU can
      * work on the next buffer while libzstd entropy-codes the current one on this thread */
-    QZSTD_Hint_T hint[2];
-    int hintNext;
+    QZSTD_Hint_T hint[4]; /* [0..1] announced by the caller, [2..3] speculative (transparent look-ahead) */
+    int hintNext, autoNext;
+    unsigned autoDepth, autoBackoff, autoFails; /* blocks to speculate on, callbacks to sit out, misses in a row */
+    unsigned long autoLaunched, autoServed;
     unsigned long servedFromBatch, servedSync;
     unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs; /* event log only */
 } QZSTD_Session_T;
+
+#define QZ_AUTO_DEPTH_MIN 2u  /* transparent look-ahead: blocks guessed ahead, doubling while guesses are consumed */
+#define QZ_AUTO_DEPTH_MAX 32u
+static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block);
+static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t blockSize, int compressionLevel);
+
 
 const char *QZSTD_version(void)
 {
@@ -460,6 +475,12 @@ int QZSTD_startQatDevice(void)
         /* the caller promises ZSTD_c_searchForExternalRepcodes = enable on its CCtx (libzstd's default only
          * from level 10): repeat-offset aware sequences at every level */
         gProc.levelFlags = (rep && atoi(rep) > 0) ? QZSTD_HIP_LEVEL_REPCODES : 0;
+        {
+            /* transparent look-ahead needs the fault-safe read: probe it once on ourselves */
+            char probe[16] = "qzstd", back[16];
+            gProc.lookahead = qzEnvInt("QZSTD_HIP_LOOKAHEAD", 1, 0, 1) && qzSafeRead(back, probe, 16, 16) == 16 &&
+                              memcmp(back, probe, 16) == 0;
+        }
     }
     if (gProc.status == QZSTD_FAIL) {
         /* runtime up? (reference: QZSTD_salUserStart, :498-527) */
@@ -532,10 +553,11 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
     QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
     int k;
     if (!s) return;
-    QZ_LOG(2, "state %p: %lu block(s) served from a look-ahead batch, %lu per block; %lu hint(s): staging %.2f ms, "
-              "queueing %.2f ms, waited %.2f ms for the GPU\n", (void *)s, s->servedFromBatch, s->servedSync,
-           s->hintCalls, s->hintStageNs / 1e6, s->hintQueueNs / 1e6, s->hintWaitNs / 1e6);
-    for (k = 0; k < 2; k++) {
+    QZ_LOG(2, "state %p: %lu block(s) served from a look-ahead batch (%lu of them speculative, %lu speculation(s)), %lu per "
+              "block; %lu hint(s): staging %.2f ms, queueing %.2f ms, waited %.2f ms for the GPU\n", (void *)s,
+           s->servedFromBatch, s->autoServed, s->autoLaunched, s->servedSync, s->hintCalls, s->hintStageNs / 1e6,
+           s->hintQueueNs / 1e6, s->hintWaitNs / 1e6);
+    for (k = 0; k < 4; k++) {
         qzHintFinish(&s->hint[k]);
         qzstd_hip_host_free(s->hint[k].hSrc);
         qzstd_hip_host_free(s->hint[k].hSeqs);
@@ -627,10 +649,10 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     if (!s || !outSeqs || !src || srcSize > QZSTD_HIP_BLOCK_MAX || outSeqsCapacity < 3) return ZSTD_SEQUENCE_PRODUCER_ERROR;
     if (!qzDeviceUsable(s)) return ZSTD_SEQUENCE_PRODUCER_ERROR;
 
-    /* look-ahead batch hit?  (src, srcSize) must sit exactly on an announced block grid */
+    /* look-ahead batch hit?  (src, srcSize) must sit exactly on an announced (k < 2) or guessed (k >= 2) block grid */
     {
-        int k;
-        for (k = 0; k < 2; k++) {
+        int k, guessMissed = 0;
+        for (k = 0; k < 4; k++) {
             QZSTD_Hint_T *h = &s->hint[k];
             const unsigned char *p = (const unsigned char *)src;
             size_t rel, b;
@@ -638,6 +660,11 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
             rel = (size_t)(p - h->base);
             b = rel / h->block;
             if (rel % h->block != 0 || b >= h->nb || h->hDesc[b].srcLen != srcSize) continue;
+            if (k >= 2 && memcmp(h->hSrc + rel, src, srcSize) != 0) { /* the guess was read before these bytes were final */
+                h->st = h->st == 1 ? 1 : 0;
+                guessMissed = 1;
+                continue;
+            }
             if (h->st == 1) { /* first use: wait for the GPU (usually long done) */
                 const unsigned long w0 = qzNowNs();
                 qzHintFinish(h);
@@ -649,12 +676,38 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 if (count != QZSTD_HIP_NSEQ_ERROR && count != 0 && count < outSeqsCapacity - 1 && count <= QZ_HINT_PITCH) {
                     memcpy(outSeqs, h->hSeqs + b * QZ_HINT_PITCH, count * sizeof(ZSTD_Sequence));
                     s->servedFromBatch++;
+                    if (k >= 2) {
+                        s->autoServed++;
+                        s->autoFails = 0;
+                        /* keep the pipeline full: once past the middle of a guess, guess what follows it */
+                        if (b + 1 == (h->nb + 1) / 2 || h->nb == 1) {
+                            const QZSTD_Hint_T *o = &s->hint[2 + ((k - 2) ^ 1)];
+                            const unsigned char *nxt = h->base + h->size;
+                            if (!(o->st != 0 && o->base == nxt)) {
+                                if (s->autoDepth < QZ_AUTO_DEPTH_MAX) s->autoDepth *= 2;
+                                s->autoNext = (k - 2) ^ 1;
+                                qzSpeculate(s, nxt, h->block, compressionLevel);
+                            }
+                        }
+                    }
                     if (last) h->st = 0; /* last block consumed */
                     return count;
                 }
                 if (last) h->st = 0;
             }
             break; /* announced but unusable (too many sequences, failed launch): per-block path */
+        }
+        /* nothing to serve from.  Unannounced caller: guess that the bytes after this block come next */
+        if (s->hint[0].st == 0 && s->hint[1].st == 0) {
+            const int pending = s->hint[2].st != 0 || s->hint[3].st != 0;
+            if (guessMissed || pending) { /* an earlier guess was wrong: back off exponentially, start small again */
+                s->autoFails++;
+                s->autoBackoff = s->autoFails < 8 ? (1u << s->autoFails) : 256u;
+                s->autoDepth = QZ_AUTO_DEPTH_MIN;
+                for (k = 2; k < 4; k++)
+                    if (s->hint[k].st == 2) s->hint[k].st = 0;
+            }
+            qzSpeculate(s, (const unsigned char *)src + srcSize, srcSize, compressionLevel);
         }
     }
 
@@ -732,24 +785,38 @@ void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4])
     stats[3] = s ? s->hintWaitNs / 1000 : 0;
 }
 
-int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
-                     int compressionLevel)
+/* Copy [src, src + len) into dst without ever faulting: whole blocks of `block` bytes as long as they are
+ * readable.  process_vm_readv on ourselves is the kernel's copy_from_user: an unmapped or PROT_NONE page ends the
+ * transfer (at iovec granularity) instead of raising SIGSEGV.  Returns the bytes copied (a multiple of block). */
+static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block)
 {
-    QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
-    QZSTD_Hint_T *h;
+    struct iovec rem[QZ_HINT_MAX_BYTES / 4096 > 1024 ? 1024 : 64], loc;
+    const size_t nb = len / block;
+    size_t b, done = 0;
+    ssize_t n;
+    if (nb == 0 || nb > sizeof(rem) / sizeof(rem[0])) return 0;
+    for (b = 0; b < nb; b++) {
+        rem[b].iov_base = (void *)((uintptr_t)src + b * block);
+        rem[b].iov_len = block;
+    }
+    loc.iov_base = dst;
+    loc.iov_len = nb * block;
+    n = process_vm_readv(getpid(), &loc, 1, rem, (unsigned long)nb, 0);
+    if (n > 0) done = ((size_t)n / block) * block;
+    return done;
+}
+
+/* Stage a buffer, queue its match-finding on a slot's stream and remember it in *h (asynchronous, see
+ * QZSTD_hintSource).  speculative: the buffer is a GUESS (what follows the block of the current callback): read it
+ * fault-safely, take only whole readable blocks, never wait for a slot.  Returns the bytes announced, 0 if none. */
+static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, size_t srcSize, size_t blockSize,
+                         int compressionLevel, int speculative)
+{
     QZSTD_Slot_T *sl;
     size_t nb, b, stride, blocksBytes, srcBytes;
     unsigned long tq;
-    int i, rc = -1;
+    int i;
 
-    if (!s || !src || srcSize == 0 || srcSize > QZ_HINT_MAX_BYTES || blockSize == 0 || blockSize > QZSTD_HIP_BLOCK_MAX ||
-        (blockSize & 15))
-        return -1;
-    if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) return -1;
-    if (!qzDeviceUsable(s)) return -1;
-
-    h = &s->hint[s->hintNext];
-    s->hintNext ^= 1;
     qzHintFinish(h); /* an old announcement that was never consumed */
     h->st = 0;
     nb = (srcSize + blockSize - 1) / blockSize;
@@ -764,14 +831,22 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     h->dvDesc = qzstd_hip_host_device_ptr(h->hDesc);
     h->dvCount = qzstd_hip_host_device_ptr(h->hCount);
     h->dvSeqs = qzstd_hip_host_device_ptr(h->hSeqs);
-    if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs || !h->dvDesc || !h->dvCount || !h->dvSeqs) return -1;
+    if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs || !h->dvDesc || !h->dvCount || !h->dvSeqs) return 0;
 
+    tq = qzNowNs();
+    if (speculative) {
+        srcSize = qzSafeRead(h->hSrc, src, srcSize, blockSize);
+        if (srcSize == 0) return 0;
+        nb = srcSize / blockSize;
+        srcBytes = (srcSize + 63) & ~(size_t)63;
+    }
     i = qzTryGrabSlot(s->slotHint);
     if (i < 0) {
+        if (speculative) return 0;
         /* every slot is busy: give back what this state still holds, then wait for one */
-        qzHintFinish(&s->hint[s->hintNext]);
+        for (b = 0; b < 4; b++) qzHintFinish(&s->hint[b]);
         i = qzGrabSlot(s->slotHint);
-        if (i < 0) return -1;
+        if (i < 0) return 0;
     }
     s->slotHint = i;
     sl = &gProc.slots[i];
@@ -783,8 +858,7 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
         if (work) sl->dBatchWork = qzGrowDev(sl->device, sl->dBatchWork, &sl->dBatchWorkCap, work);
         if (work && !sl->dBatchWork) goto fail;
     }
-    tq = qzNowNs();
-    memcpy(h->hSrc, src, srcSize); /* pinned staging: the H2D below is then truly asynchronous */
+    if (!speculative) memcpy(h->hSrc, src, srcSize); /* pinned staging: the H2D below is then truly asynchronous */
     for (b = 0; b < nb; b++) {
         const size_t o = b * blockSize;
         h->hDesc[b].srcOff = o;
@@ -812,10 +886,52 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     h->slot = i;
     h->st = 1; /* in flight; the slot stays ours until qzHintFinish() */
     s->hintQueueNs += qzNowNs() - tq;
+    return srcSize;
+fail:
+    QZ_LOG(1, "look-ahead not taken: %s\n", qzstd_hip_last_error());
+    qzReleaseSlot(i);
+    return 0;
+}
+
+int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
+                     int compressionLevel)
+{
+    QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
+    QZSTD_Hint_T *h;
+
+    if (!s || !src || srcSize == 0 || srcSize > QZ_HINT_MAX_BYTES || blockSize == 0 || blockSize > QZSTD_HIP_BLOCK_MAX ||
+        (blockSize & 15))
+        return -1;
+    if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) return -1;
+    if (!qzDeviceUsable(s)) return -1;
+    h = &s->hint[s->hintNext];
+    s->hintNext ^= 1;
+    if (qzAnnounce(s, h, src, srcSize, blockSize, compressionLevel, 0) == 0) return -1;
     s->hintCalls++;
     return 0;
-fail:
-    QZ_LOG(1, "look-ahead hint not taken: %s\n", qzstd_hip_last_error());
-    qzReleaseSlot(i);
-    return rc;
+}
+
+/* Transparent look-ahead for callers that announce nothing.  libzstd hands over one block per callback and waits,
+ * but most callers walk a contiguous buffer (a file in chunks, a multi-block frame), so the bytes that FOLLOW the
+ * current block are very likely the next blocks.  On a callback that had to take the per-block path, guess: read
+ * the following blocks fault-safely, and let the GPU match-find them while this block is being served and its
+ * frame entropy-coded.  A later callback is served from a guess only if its (src, srcSize) sits on the guessed
+ * grid AND its bytes still equal the staged copy (memcmp), so a wrong guess costs GPU time, never correctness.
+ * The depth doubles while guesses are consumed (2 .. 32 blocks); misses back off exponentially. */
+static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t blockSize, int compressionLevel)
+{
+    QZSTD_Hint_T *h;
+    /* only with the coalescer: there the per-block path needs no slot, so guesses that hold slots cannot starve it */
+    if (!gProc.lookahead || !gProc.coalesce || (blockSize & 15) || blockSize < 4096) return;
+    if (s->autoBackoff) { s->autoBackoff--; return; }
+    if (s->autoDepth < QZ_AUTO_DEPTH_MIN) s->autoDepth = QZ_AUTO_DEPTH_MIN;
+    h = &s->hint[2 + s->autoNext];
+    if (h->st == 1 && qzstd_hip_stream_query(gProc.slots[h->slot].device, gProc.slots[h->slot].stream) == 1)
+        return; /* the buffer we would reuse is still on the GPU: do not wait for a guess */
+    if (qzAnnounce(s, h, next, (size_t)s->autoDepth * blockSize, blockSize, compressionLevel, 1) != 0) {
+        s->autoNext ^= 1;
+        s->autoLaunched++;
+    } else {
+        s->autoBackoff = 16; /* unreadable, or no slot free: try again later */
+    }
 }

@@ -361,3 +361,83 @@ def test_hinting_and_plain_callers_side_by_side(started, zstd, oracle):
         level, chunk, data, _ = jobs[t]
         assert res[t] is not None, "thread %d died" % t
         assert res[t] == compress_with(zstd, oracle.producer_addr, None, data, chunk, level), "thread %d" % t
+
+
+def _compress_chunks_raw(zstd, plug, st, buf_addr, total, chunk, level, order=None, before=None):
+    """one ZSTD_compress2 per chunk straight from memory at buf_addr (no copies: the producer sees the real addresses)"""
+    zc = zstd.cctx(level, producer=plug.producer_addr, state=st, fallback=False, validate=True)
+    cap = zstd.lib.ZSTD_compressBound(chunk)
+    dst = C.create_string_buffer(cap)
+    frames = {}
+    idx = list(range((total + chunk - 1) // chunk))
+    for c in (order or idx):
+        if before:
+            before(c)
+        n = min(chunk, total - c * chunk)
+        r = zstd.lib.ZSTD_compress2(zc, dst, cap, C.c_void_p(buf_addr + c * chunk), n)
+        assert not zstd.is_error(r), zstd.err(r)
+        frames[c] = dst.raw[:r]
+    zstd.free(zc)
+    return [frames[c] for c in idx]
+
+
+def test_transparent_lookahead_serves_unchanged_callers(started, zstd, oracle):
+    """no hints: the plugin guesses that the bytes after the current block come next (fault-safe read, verified by
+    memcmp when used).  A caller walking a contiguous buffer is served from guesses; the frames are the oracle's."""
+    data = K.by_name("system", 40 * 131072 + 333)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    st = started.lib.QZSTD_createSeqProdState()
+    got = _compress_chunks_raw(zstd, started, st, C.addressof(buf), len(data), 131072, 1)
+    stats = (C.c_ulong * 4)()
+    started.lib.QZSTD_hintStats(st, C.byref(stats))
+    started.lib.QZSTD_freeSeqProdState(st)
+    assert got == compress_with(zstd, oracle.producer_addr, None, data, 131072, 1)
+    assert stats[2] == 0 and stats[0] >= 30, list(stats)  # nothing announced, yet most blocks came from look-ahead
+
+
+def test_transparent_lookahead_never_trusts_a_stale_guess(started, zstd, oracle):
+    """the caller rewrites every chunk just before compressing it (after the guess read it), jumps around, and the
+    buffer ends right in front of an unreadable page: output must still be exact, nothing may fault"""
+    import mmap
+    import random
+    libc = C.CDLL(None, use_errno=True)
+    page = mmap.PAGESIZE
+    nblk, chunk = 12, 65536
+    total = nblk * chunk
+    mm = mmap.mmap(-1, total + page)
+    base = C.addressof(C.c_char.from_buffer(mm))
+    assert libc.mprotect(C.c_void_p(base + total), C.c_size_t(page), 0) == 0  # PROT_NONE right behind the data
+    final = K.by_name("mix", total, seed=77)
+    mm[:total] = K.by_name("text", total, seed=5)  # what a too-early guess would see
+
+    def rewrite(c):
+        mm[c * chunk:(c + 1) * chunk] = final[c * chunk:(c + 1) * chunk]
+
+    st = started.lib.QZSTD_createSeqProdState()
+    got = _compress_chunks_raw(zstd, started, st, base, total, chunk, 1, before=rewrite)
+    assert got == compress_with(zstd, oracle.producer_addr, None, final, chunk, 1)
+    order = list(range(nblk))
+    random.Random(3).shuffle(order)
+    got = _compress_chunks_raw(zstd, started, st, base, total, chunk, 3, order=order)  # now the content is stable
+    started.lib.QZSTD_freeSeqProdState(st)
+    assert got == compress_with(zstd, oracle.producer_addr, None, final, chunk, 3)
+    assert libc.mprotect(C.c_void_p(base + total), C.c_size_t(page), 3) == 0
+    del got
+
+
+def test_lookahead_can_be_switched_off(started, tmp_path):
+    import os
+    import subprocess
+    tdir = os.path.join(B.PKG_DIR, "test")
+    subprocess.check_call(["make", "-C", tdir, "benchmark", "ZSTDLIB=" + B.find_libzstd()], stdout=subprocess.DEVNULL)
+    f = tmp_path / "corpus.bin"
+    f.write_bytes(K.by_name("system", 20 * 131072))
+    for val, expect in (("0", "0 of them speculative"), ("1", None)):
+        env = dict(os.environ, QZSTD_HIP_LOOKAHEAD=val, QZSTD_HIP_DEBUG="2")
+        out = subprocess.run([os.path.join(tdir, "benchmark"), "-m1", "-t2", "-l1", "-c128K", "-L1", str(f)],
+                             capture_output=True, text=True, env=env)
+        assert out.returncode == 0 and out.stderr.count("PASS") == 2, out.stderr[-600:]
+        if expect:
+            assert expect in out.stderr, out.stderr[-600:]
+        else:
+            assert "0 of them speculative" not in out.stderr, out.stderr[-600:]
