@@ -143,7 +143,7 @@ static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, PTHREAD_
 /* One announced buffer: staged in pinned memory, match-found asynchronously on a slot's stream,
  * results (count + the first QZ_HINT_PITCH sequences of every block) copied back asynchronously. */
 #define QZ_HINT_MAX_BYTES ((size_t)16 << 20)
-#define QZ_HINT_PITCH ((size_t)12288) /* blocks with more sequences take the per-block path */
+#define QZ_HINT_PITCH ((size_t)16384) /* blocks with more sequences take the per-block path */
 typedef struct {
     int st;   /* 0 empty, 1 in flight on the GPU (slot held), 2 ready */
     int slot; /* index of the slot held while in flight */
