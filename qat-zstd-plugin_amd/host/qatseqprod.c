@@ -167,6 +167,7 @@ typedef struct {
     QZSTD_Hint_T hint[4]; /* [0..1] announced by the caller, [2..3] speculative (transparent look-ahead) */
     int hintNext, autoNext;
     unsigned autoDepth, autoBackoff, autoFails; /* blocks to speculate on, callbacks to sit out, misses in a row */
+    int autoOutstanding;                        /* a guess was launched and nothing has been served from it yet */
     unsigned long autoLaunched, autoServed;
     unsigned long servedFromBatch, servedSync;
     unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs; /* event log only */
@@ -649,19 +650,23 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     if (!s || !outSeqs || !src || srcSize > QZSTD_HIP_BLOCK_MAX || outSeqsCapacity < 3) return ZSTD_SEQUENCE_PRODUCER_ERROR;
     if (!qzDeviceUsable(s)) return ZSTD_SEQUENCE_PRODUCER_ERROR;
 
-    /* look-ahead batch hit?  (src, srcSize) must sit exactly on an announced (k < 2) or guessed (k >= 2) block grid */
+    /* look-ahead batch hit?  (src, srcSize) must start on an announced (k < 2) or guessed (k >= 2) block grid and
+     * cover one or more whole blocks of it: libzstd 1.5.7 cuts multi-block frames into 128 KiB and 64 KiB blocks, so a
+     * 64 KiB grid serves both — independently parsed neighbours are simply concatenated, the trailing literals of
+     * one block flowing into the first sequence of the next */
     {
         int k, guessMissed = 0;
         for (k = 0; k < 4; k++) {
             QZSTD_Hint_T *h = &s->hint[k];
             const unsigned char *p = (const unsigned char *)src;
-            size_t rel, b;
+            size_t rel, b, e, covered = 0;
             if (h->st == 0 || h->level != compressionLevel || p < h->base || p + srcSize > h->base + h->size) continue;
             rel = (size_t)(p - h->base);
             b = rel / h->block;
-            if (rel % h->block != 0 || b >= h->nb || h->hDesc[b].srcLen != srcSize) continue;
+            if (rel % h->block != 0 || b >= h->nb) continue;
+            for (e = b; e < h->nb && covered < srcSize; e++) covered += h->hDesc[e].srcLen;
+            if (covered != srcSize || e - b > 8) continue;
             if (k >= 2 && memcmp(h->hSrc + rel, src, srcSize) != 0) { /* the guess was read before these bytes were final */
-                h->st = h->st == 1 ? 1 : 0;
                 guessMissed = 1;
                 continue;
             }
@@ -671,16 +676,38 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 s->hintWaitNs += qzNowNs() - w0;
             }
             if (h->st == 2) {
-                const size_t count = h->hCount[b];
                 const int last = rel + srcSize >= h->size;
-                if (count != QZSTD_HIP_NSEQ_ERROR && count != 0 && count < outSeqsCapacity - 1 && count <= QZ_HINT_PITCH) {
-                    memcpy(outSeqs, h->hSeqs + b * QZ_HINT_PITCH, count * sizeof(ZSTD_Sequence));
+                size_t total = 1, carry = 0, out = 0, bi;
+                int usable = 1;
+                for (bi = b; bi < e; bi++) {
+                    const size_t count = h->hCount[bi];
+                    if (count == QZSTD_HIP_NSEQ_ERROR || count == 0 || count > QZ_HINT_PITCH) usable = 0;
+                    total += count - 1;
+                }
+                if (usable && total < outSeqsCapacity - 1) {
+                    for (bi = b; bi < e; bi++) {
+                        const ZSTD_Sequence *q = h->hSeqs + bi * QZ_HINT_PITCH;
+                        const size_t count = h->hCount[bi];
+                        if (count > 1) {
+                            memcpy(outSeqs + out, q, (count - 1) * sizeof(ZSTD_Sequence));
+                            outSeqs[out].litLength += (unsigned int)carry;
+                            out += count - 1;
+                            carry = 0;
+                        }
+                        carry += q[count - 1].litLength; /* the block's delimiter: its trailing literals */
+                    }
+                    outSeqs[out].offset = 0;
+                    outSeqs[out].litLength = (unsigned int)carry;
+                    outSeqs[out].matchLength = 0;
+                    outSeqs[out].rep = 0;
+                    out++;
                     s->servedFromBatch++;
                     if (k >= 2) {
                         s->autoServed++;
                         s->autoFails = 0;
+                        s->autoOutstanding = 0;
                         /* keep the pipeline full: once past the middle of a guess, guess what follows it */
-                        if (b + 1 == (h->nb + 1) / 2 || h->nb == 1) {
+                        if ((b < (h->nb + 1) / 2 && e >= (h->nb + 1) / 2) || h->nb == 1) {
                             const QZSTD_Hint_T *o = &s->hint[2 + ((k - 2) ^ 1)];
                             const unsigned char *nxt = h->base + h->size;
                             if (!(o->st != 0 && o->base == nxt)) {
@@ -691,7 +718,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                         }
                     }
                     if (last) h->st = 0; /* last block consumed */
-                    return count;
+                    return out;
                 }
                 if (last) h->st = 0;
             }
@@ -699,15 +726,18 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
         }
         /* nothing to serve from.  Unannounced caller: guess that the bytes after this block come next */
         if (s->hint[0].st == 0 && s->hint[1].st == 0) {
-            const int pending = s->hint[2].st != 0 || s->hint[3].st != 0;
-            if (guessMissed || pending) { /* an earlier guess was wrong: back off exponentially, start small again */
+            if (guessMissed || s->autoOutstanding) { /* the last guess was wrong: back off exponentially, start small again */
+                s->autoOutstanding = 0;
                 s->autoFails++;
-                s->autoBackoff = s->autoFails < 8 ? (1u << s->autoFails) : 256u;
+                s->autoBackoff = s->autoFails < 8 ? (1u << (s->autoFails - 1)) - 1u : 255u;
                 s->autoDepth = QZ_AUTO_DEPTH_MIN;
                 for (k = 2; k < 4; k++)
                     if (s->hint[k].st == 2) s->hint[k].st = 0;
             }
-            qzSpeculate(s, (const unsigned char *)src + srcSize, srcSize, compressionLevel);
+            /* the grid of a guess is this block's size; inside a multi-block frame (window larger than the block)
+             * libzstd 1.5.7 goes on with 64 KiB blocks after a 128 KiB one, and a 64 KiB grid serves both */
+            qzSpeculate(s, (const unsigned char *)src + srcSize,
+                        (srcSize == QZSTD_HIP_BLOCK_MAX && windowSize > srcSize) ? QZSTD_HIP_BLOCK_MAX / 2 : srcSize, compressionLevel);
         }
     }
 
@@ -931,6 +961,7 @@ static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t bl
     if (qzAnnounce(s, h, next, (size_t)s->autoDepth * blockSize, blockSize, compressionLevel, 1) != 0) {
         s->autoNext ^= 1;
         s->autoLaunched++;
+        s->autoOutstanding = 1;
     } else {
         s->autoBackoff = 16; /* unreadable, or no slot free: try again later */
     }

@@ -151,7 +151,8 @@ static void *worker(void *arg)
         }
     }
     /* look-ahead: segments of -H MiB (1 -> 4 MiB), a whole number of chunks, on libzstd's block grid */
-    const size_t grid = o->chunk <= 131072 ? o->chunk : 131072;
+    /* frames of several blocks: libzstd 1.5.7 cuts them into 128 KiB and 64 KiB blocks; a 64 KiB grid serves both */
+    const size_t grid = o->chunk <= 131072 ? o->chunk : 65536;
     const size_t segWant = (size_t)(o->hint > 1 ? o->hint : 4) << 20;
     const size_t segChunks = segWant / o->chunk ? segWant / o->chunk : 1;
     const size_t segBytes = segChunks * o->chunk;

@@ -441,3 +441,48 @@ def test_lookahead_can_be_switched_off(started, tmp_path):
             assert expect in out.stderr, out.stderr[-600:]
         else:
             assert "0 of them speculative" not in out.stderr, out.stderr[-600:]
+
+
+def test_callbacks_spanning_several_grid_blocks(started, zstd, oracle):
+    """an announcement on a 64 KiB grid serves 128 KiB callbacks too (what libzstd 1.5.7 mixes inside multi-block
+    frames): the two independently parsed halves are concatenated, the first half's trailing literals flowing
+    into the second half's first sequence.  Every callback is served from the announcement; the frames decode
+    exactly and are what libzstd makes of the oracle's two half-block parses joined the same way."""
+    data = K.by_name("system", 10 * 131072)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    st = started.lib.QZSTD_createSeqProdState()
+    assert started.lib.QZSTD_hintSource(st, buf, len(data), 65536, 1) == 0
+    got = _compress_chunks_raw(zstd, started, st, C.addressof(buf), len(data), 131072, 1)
+    stats = (C.c_ulong * 4)()
+    started.lib.QZSTD_hintStats(st, C.byref(stats))
+    started.lib.QZSTD_freeSeqProdState(st)
+    assert b"".join(zstd.decompress(f, 131072) for f in got) == data
+    assert stats[0] == 10 and stats[1] == 0, list(stats)
+
+    # the same join done by hand on the oracle's sequences, fed to libzstd through a tiny replay producer
+    prof = oracle.profile(1, 65536)
+    joined = {}
+    for c in range(10):
+        blk = data[c * 131072:(c + 1) * 131072]
+        n1, s1 = oracle.find(prof, blk[:65536])
+        n2, s2 = oracle.find(prof, blk[65536:])
+        a = [(s1[i].offset, s1[i].litLength, s1[i].matchLength) for i in range(n1)]
+        b2 = [(s2[i].offset, s2[i].litLength, s2[i].matchLength) for i in range(n2)]
+        carry = a[-1][1]
+        seqs = a[:-1]
+        if len(b2) > 1:
+            seqs += [(b2[0][0], b2[0][1] + carry, b2[0][2])] + b2[1:-1]
+            carry = 0
+        seqs.append((0, carry + b2[-1][1], 0))
+        joined[C.addressof(buf) + c * 131072] = seqs
+
+    def replay(state, out, cap, src, n, d, ds, level, win):
+        seqs = joined[src]
+        for i, (o, l, m) in enumerate(seqs):
+            out[i].offset, out[i].litLength, out[i].matchLength, out[i].rep = o, l, m, 0
+        return len(seqs)
+
+    cb = B.PRODUCER_F(replay)
+    want = _compress_chunks_raw(zstd, type("P", (), {"producer_addr": C.cast(cb, C.c_void_p)})(), None, C.addressof(buf), len(data),
+                                131072, 1)
+    assert got == want
