@@ -665,7 +665,10 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
             b = rel / h->block;
             if (rel % h->block != 0 || b >= h->nb) continue;
             for (e = b; e < h->nb && covered < srcSize; e++) covered += h->hDesc[e].srcLen;
-            if (covered != srcSize || e - b > 8) continue;
+            if (covered != srcSize || e - b > 8) {
+                QZ_LOG(3, "look-ahead %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
+                continue;
+            }
             if (k >= 2 && memcmp(h->hSrc + rel, src, srcSize) != 0) { /* the guess was read before these bytes were final */
                 guessMissed = 1;
                 continue;
@@ -724,6 +727,9 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
             }
             break; /* announced but unusable (too many sequences, failed launch): per-block path */
         }
+        QZ_LOG(3, "miss: %p + %zu (guesses: %d %p+%zu, %d %p+%zu) outstanding %d backoff %u depth %u\n", src, srcSize, s->hint[2].st,
+               (const void *)s->hint[2].base, s->hint[2].size, s->hint[3].st, (const void *)s->hint[3].base, s->hint[3].size,
+               s->autoOutstanding, s->autoBackoff, s->autoDepth);
         /* nothing to serve from.  Unannounced caller: guess that the bytes after this block come next */
         if (s->hint[0].st == 0 && s->hint[1].st == 0) {
             if (guessMissed || s->autoOutstanding) { /* the last guess was wrong: back off exponentially, start small again */
