@@ -651,8 +651,8 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     if (!qzDeviceUsable(s)) return ZSTD_SEQUENCE_PRODUCER_ERROR;
 
     /* look-ahead batch hit?  (src, srcSize) must start on an announced (k < 2) or guessed (k >= 2) block grid and
-     * cover one or more whole blocks of it: libzstd 1.5.7 cuts multi-block frames into 128 KiB and 64 KiB blocks, so a
-     * 64 KiB grid serves both — independently parsed neighbours are simply concatenated, the trailing literals of
+     * cover one or more whole blocks of it: libzstd 1.5.7 cuts multi-block frames into blocks of 32..128 KiB at 32 KiB
+     * steps, so a finer grid serves several sizes — independently parsed neighbours are simply concatenated, the trailing literals of
      * one block flowing into the first sequence of the next */
     {
         int k, guessMissed = 0;
@@ -741,7 +741,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                     if (s->hint[k].st == 2) s->hint[k].st = 0;
             }
             /* the grid of a guess is this block's size; inside a multi-block frame (window larger than the block)
-             * libzstd 1.5.7 goes on with 64 KiB blocks after a 128 KiB one, and a 64 KiB grid serves both */
+             * libzstd 1.5.7 goes on with smaller blocks after a 128 KiB one: a 64 KiB grid serves most of them */
             qzSpeculate(s, (const unsigned char *)src + srcSize,
                         (srcSize == QZSTD_HIP_BLOCK_MAX && windowSize > srcSize) ? QZSTD_HIP_BLOCK_MAX / 2 : srcSize, compressionLevel);
         }
