@@ -1,0 +1,68 @@
+/*
+ * mock_hip.c — TEST INFRASTRUCTURE ONLY.  A CPU stand-in for the device layer of include/qzstd_hip.h so that the
+ * host logic of qat-zstd-plugin_amd/host/qatseqprod.c (guards, slots, cross-thread coalescer, announced and guessed
+ * look-ahead, result checks) can be exercised by `pytest -m "not gpu"` in a container without a GPU.  "Device" memory
+ * is plain malloc, streams are synchronous, and the launch entry point runs the oracle (oracle/qzstd_oracle.c) per
+ * block.  It is linked ONLY into tests/mock/libqatseqprod_mock.so (built by tests/test_host_mock.py); the product
+ * library never contains it and keeps failing loudly without a GPU.
+ */
+#include "qzstd_hip.h"
+#include "qzstd_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static _Thread_local char gErr[128] = "";
+static int gLaunches;
+
+const char *qzstd_hip_last_error(void) { return gErr; }
+int qzstd_mock_launches(void) { return gLaunches; }
+int qzstd_hip_device_count(void) { return 1; }
+int qzstd_hip_device_name(int device, char *buf, size_t bufLen)
+{
+    (void)device;
+    if (buf && bufLen) snprintf(buf, bufLen, "mock device (CPU oracle)");
+    return 0;
+}
+void *qzstd_hip_malloc(int device, size_t bytes) { (void)device; return malloc(bytes ? bytes : 1); }
+void qzstd_hip_free(int device, void *p) { (void)device; free(p); }
+void *qzstd_hip_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void *qzstd_hip_host_device_ptr(void *h) { return h; }
+void qzstd_hip_host_free(void *h) { free(h); }
+void *qzstd_hip_stream_create(int device) { (void)device; return malloc(1); }
+void qzstd_hip_stream_destroy(int device, void *s) { (void)device; free(s); }
+int qzstd_hip_stream_sync(int device, void *s) { (void)device; (void)s; return 0; }
+int qzstd_hip_stream_query(int device, void *s) { (void)device; (void)s; return 0; }
+int qzstd_hip_memcpy_h2d(int device, void *s, void *dst, const void *src, size_t n) { (void)device; (void)s; memcpy(dst, src, n); return 0; }
+int qzstd_hip_memcpy_d2h(int device, void *s, void *dst, const void *src, size_t n) { (void)device; (void)s; memcpy(dst, src, n); return 0; }
+int qzstd_hip_memset(int device, void *s, void *dst, int v, size_t n) { (void)device; (void)s; memset(dst, v, n); return 0; }
+int qzstd_hip_memcpy2d_d2h(int device, void *s, void *dst, size_t dp, const void *src, size_t sp, size_t w, size_t h)
+{
+    size_t r;
+    (void)device; (void)s;
+    for (r = 0; r < h; r++) memcpy((char *)dst + r * dp, (const char *)src + r * sp, w);
+    return 0;
+}
+
+int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_src, const qzstd_hip_block_t *d_blocks,
+                             uint32_t nBlocks, uint32_t maxBlockLen, void *d_seqs, uint32_t *d_nseq, void *d_work,
+                             size_t workBytes)
+{
+    uint32_t b;
+    qzo_profile_t pf;
+    (void)device; (void)stream;
+    if (qzo_profile_for_level(level, maxBlockLen, &pf)) { snprintf(gErr, sizeof gErr, "mock: bad level"); return -1; }
+    if (qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen) > workBytes || (workBytes && !d_work)) {
+        snprintf(gErr, sizeof gErr, "mock: workspace missing or too small");
+        return -1;
+    }
+    __sync_fetch_and_add(&gLaunches, 1);
+    for (b = 0; b < nBlocks; b++) {
+        const qzstd_hip_block_t *k = &d_blocks[b];
+        const size_t n = qzo_find_sequences(&pf, (const uint8_t *)d_src + k->srcOff, k->srcLen,
+                                            (qzo_seq_t *)d_seqs + k->seqOff, k->seqCap);
+        d_nseq[b] = n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n;
+    }
+    return 0;
+}
