@@ -665,7 +665,9 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
             b = rel / h->block;
             if (rel % h->block != 0 || b >= h->nb) continue;
             for (e = b; e < h->nb && covered < srcSize; e++) covered += h->hDesc[e].srcLen;
-            if (covered != srcSize || e - b > 8) {
+            /* a GUESS must not change what the caller gets: it serves a callback only block for block (joining
+             * independently parsed grid blocks costs ratio; for announcements that is the announcer's choice) */
+            if (covered != srcSize || e - b > 8 || (k >= 2 && e - b != 1)) {
                 QZ_LOG(3, "look-ahead %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
                 continue;
             }
@@ -740,10 +742,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 for (k = 2; k < 4; k++)
                     if (s->hint[k].st == 2) s->hint[k].st = 0;
             }
-            /* the grid of a guess is this block's size; inside a multi-block frame (window larger than the block)
-             * libzstd 1.5.7 goes on with smaller blocks after a 128 KiB one: a 64 KiB grid serves most of them */
-            qzSpeculate(s, (const unsigned char *)src + srcSize,
-                        (srcSize == QZSTD_HIP_BLOCK_MAX && windowSize > srcSize) ? QZSTD_HIP_BLOCK_MAX / 2 : srcSize, compressionLevel);
+            qzSpeculate(s, (const unsigned char *)src + srcSize, srcSize, compressionLevel);
         }
     }
 
