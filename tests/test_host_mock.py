@@ -178,3 +178,29 @@ print("OK")
     for env in ({"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SLOTS": "3"}, {"QZSTD_HIP_LOOKAHEAD": "0"}, {"QZSTD_HIP_EXT_REPCODES": "1"}):
         out = subprocess.run(["python", "-c", script], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
         assert out.returncode == 0 and "OK" in out.stdout, (env, out.stderr[-800:])
+
+
+def test_lookahead_never_changes_the_output(mock, zstd):
+    """multi-block frames (libzstd 1.5.7 cuts them into irregular 32-128 KiB blocks): byte-identical frames with the
+    transparent look-ahead on and off"""
+    data = K.by_name("system", 3 * (1 << 20) + 4321)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+
+    def run(chunk):
+        st = mock.lib.QZSTD_createSeqProdState()
+        fr = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1)
+        mock.lib.QZSTD_freeSeqProdState(st)
+        return fr
+
+    on = {c: run(c) for c in (1 << 20, 393216)}
+    mock.lib.QZSTD_stopQatDevice()
+    os.environ["QZSTD_HIP_LOOKAHEAD"] = "0"
+    try:
+        assert mock.lib.QZSTD_startQatDevice() == 0
+        off = {c: run(c) for c in (1 << 20, 393216)}
+    finally:
+        del os.environ["QZSTD_HIP_LOOKAHEAD"]
+        mock.lib.QZSTD_stopQatDevice()
+        assert mock.lib.QZSTD_startQatDevice() == 0
+    assert on == off
+    assert b"".join(zstd.decompress(f, 1 << 20) for f in on[1 << 20]) == data
