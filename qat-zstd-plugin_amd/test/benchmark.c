@@ -25,7 +25,7 @@
 #define NBUCKETS 200
 
 typedef struct {
-    unsigned threads, loops, level, mode, extRep, hint;
+    unsigned threads, loops, level, mode, extRep, hint, split;
     size_t chunk;
     const unsigned char *src;
     size_t srcSize;
@@ -114,6 +114,7 @@ static void usage(const char *exe)
             "  -l#   loops [1-1000000] (default 1)\n"
             "  -c#   chunk size, K/M suffix allowed (default 32K)\n"
             "  -E#   searchForExternalRepcodes 0 auto, 1 enable, 2 disable (default auto)\n"
+            "  -S#   ZSTD_c_blockSplitterLevel (zstd >= 1.5.7): 0 auto, 1 = blocks of multi-block frames stay 128 KiB\n"
             "  -L#   compression level [1-12] (default 1)\n"
             "  -m#   0 software zstd, 1 GPU sequence producer (default 1)\n"
             "  -H#   look-ahead with QZSTD_hintSource: 1 = 4 MiB segments, n>1 = n MiB segments (default 0 = off)\n", exe);
@@ -149,10 +150,12 @@ static void *worker(void *arg)
             fprintf(stderr, "thread %u: cannot set parameters\n", w->id);
             ok = 0;
         }
+        if (ok && o->split) (void)ZSTD_CCtx_setParameter(zc, ZSTD_c_blockSplitterLevel, (int)o->split); /* older zstd: ignored */
     }
     /* look-ahead: segments of -H MiB (1 -> 4 MiB), a whole number of chunks, on libzstd's block grid */
-    /* frames of several blocks: libzstd 1.5.7 cuts them into 128 KiB and 64 KiB blocks; a 64 KiB grid serves both */
-    const size_t grid = o->chunk <= 131072 ? o->chunk : 65536;
+    /* frames of several blocks: libzstd 1.5.7 cuts them into 32..128 KiB blocks unless -S1 keeps them at 128 KiB;
+     * a 64 KiB grid serves the 64 and 128 KiB ones (two independently parsed halves joined) */
+    const size_t grid = o->chunk <= 131072 ? o->chunk : (o->split == 1 ? 131072 : 65536);
     const size_t segWant = (size_t)(o->hint > 1 ? o->hint : 4) << 20;
     const size_t segChunks = segWant / o->chunk ? segWant / o->chunk : 1;
     const size_t segBytes = segChunks * o->chunk;
@@ -231,7 +234,7 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-    Options o = { 1, 1, 1, 1, 0, 0, 32 * 1024, NULL, 0 };
+    Options o = { 1, 1, 1, 1, 0, 0, 0, 32 * 1024, NULL, 0 };
     const char *file = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -244,6 +247,7 @@ int main(int argc, char **argv)
         case 'L': o.level = (unsigned)atoi(a + 2); break;
         case 'm': o.mode = (unsigned)atoi(a + 2); break;
         case 'H': o.hint = (unsigned)atoi(a + 2); break;
+        case 'S': o.split = (unsigned)atoi(a + 2); break;
         default: usage(argv[0]); return a[1] == 'h' || a[1] == 'H' ? 0 : 1;
         }
     }
