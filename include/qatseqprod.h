@@ -102,7 +102,7 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
 
 /* Transparent look-ahead (no API): a state whose caller announces nothing guesses, after a callback that had
  * to wait for the GPU, that the bytes BEHIND that callback's block are the next blocks.  It reads them with a
- * fault-safe copy (process_vm_readv on itself; unreadable memory ends the copy), match-finds them ahead of time, and
+ * fault-safe copy (process_vm_readv on itself, or write/read through a pipe; unreadable memory ends the copy), match-finds them ahead of time, and
  * serves a later callback from the guess only if its address sits on the guessed grid and its bytes still equal the
  * copy.  It therefore READS (never writes) process memory behind the block a callback names; set the environment
  * variable QZSTD_HIP_LOOKAHEAD=0 before QZSTD_startQatDevice() to forbid that. */

@@ -35,6 +35,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/prctl.h>
 #include <sys/types.h>
 #include <sys/uio.h>
 #include <time.h>
@@ -134,7 +136,7 @@ typedef struct {
     QZSTD_Coalescer_T *coal; /* one per device */
     int coalesce;            /* QZSTD_HIP_COALESCE (default 1) */
     int levelFlags;          /* QZSTD_HIP_LEVEL_REPCODES when QZSTD_HIP_EXT_REPCODES=1 */
-    int lookahead;           /* QZSTD_HIP_LOOKAHEAD (default 1) and the fault-safe read works */
+    int lookahead;           /* transparent look-ahead: 0 off, 1 fault-safe read by process_vm_readv, 2 through a pipe */
     pthread_mutex_t mutex;
 } QZSTD_Process_T;
 
@@ -168,6 +170,7 @@ typedef struct {
     int hintNext, autoNext;
     unsigned autoDepth, autoBackoff, autoFails; /* blocks to speculate on, callbacks to sit out, misses in a row */
     int autoOutstanding;                        /* a guess was launched and nothing has been served from it yet */
+    int pipeFd[2];                              /* the fault-safe read's pipe (mode 2), -1 = not opened */
     unsigned long autoLaunched, autoServed;
     unsigned long servedFromBatch, servedSync;
     unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs; /* event log only */
@@ -477,10 +480,15 @@ int QZSTD_startQatDevice(void)
          * from level 10): repeat-offset aware sequences at every level */
         gProc.levelFlags = (rep && atoi(rep) > 0) ? QZSTD_HIP_LEVEL_REPCODES : 0;
         {
-            /* transparent look-ahead needs the fault-safe read: probe it once on ourselves */
+            /* transparent look-ahead needs a fault-safe read.  QZSTD_HIP_LOOKAHEAD: 0 off, 1 (default) on, 2 on and
+             * always through a pipe.  process_vm_readv is only tried where no seccomp filter could make an unusual
+             * system call fatal, and only kept if a probe on ourselves works */
             char probe[16] = "qzstd", back[16];
-            gProc.lookahead = qzEnvInt("QZSTD_HIP_LOOKAHEAD", 1, 0, 1) && qzSafeRead(back, probe, 16, 16) == 16 &&
-                              memcmp(back, probe, 16) == 0;
+            const int want = qzEnvInt("QZSTD_HIP_LOOKAHEAD", 1, 0, 2);
+            gProc.lookahead = want;
+            if (want == 1 && (prctl(PR_GET_SECCOMP, 0, 0, 0, 0) != 0 || qzSafeRead(back, probe, 16, 16) != 16 ||
+                              memcmp(back, probe, 16) != 0))
+                gProc.lookahead = 2;
         }
     }
     if (gProc.status == QZSTD_FAIL) {
@@ -522,6 +530,7 @@ void *QZSTD_createSeqProdState(void)
     QZSTD_Session_T *s = (QZSTD_Session_T *)calloc(1, sizeof(QZSTD_Session_T));
     if (!s) return NULL;
     s->slotHint = -1;
+    s->pipeFd[0] = s->pipeFd[1] = -1;
     return s;
 }
 
@@ -565,6 +574,8 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
         qzstd_hip_host_free(s->hint[k].hCount);
         qzstd_hip_host_free(s->hint[k].hDesc);
     }
+    if (s->pipeFd[0] >= 0) close(s->pipeFd[0]);
+    if (s->pipeFd[1] >= 0) close(s->pipeFd[1]);
     free(s);
 }
 
@@ -841,6 +852,32 @@ static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block)
     return done;
 }
 
+/* The same through a pipe, with nothing but pipe/write/read (for processes under a seccomp filter, where an unusual
+ * system call may be fatal): write() copies from user memory inside the kernel and stops with EFAULT at an
+ * unreadable page; what went in is read back out into dst. */
+static size_t qzSafeReadPipe(int fd[2], void *dst, const void *src, size_t len, size_t block)
+{
+    size_t done = 0;
+    if (fd[0] < 0) {
+        if (pipe(fd) != 0) { fd[0] = fd[1] = -1; return 0; }
+        (void)fcntl(fd[1], F_SETFL, O_NONBLOCK);
+    }
+    while (done < len) {
+        const size_t want = len - done < 65536 ? len - done : 65536; /* the default capacity of a pipe */
+        const ssize_t w = write(fd[1], (const char *)src + done, want);
+        size_t got = 0;
+        if (w <= 0) break;
+        while (got < (size_t)w) {
+            const ssize_t r = read(fd[0], (char *)dst + done + got, (size_t)w - got);
+            if (r <= 0) return (done / block) * block;
+            got += (size_t)r;
+        }
+        done += (size_t)w;
+        if ((size_t)w < want) break;
+    }
+    return (done / block) * block;
+}
+
 /* Stage a buffer, queue its match-finding on a slot's stream and remember it in *h (asynchronous, see
  * QZSTD_hintSource).  speculative: the buffer is a GUESS (what follows the block of the current callback): read it
  * fault-safely, take only whole readable blocks, never wait for a slot.  Returns the bytes announced, 0 if none. */
@@ -870,7 +907,8 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
 
     tq = qzNowNs();
     if (speculative) {
-        srcSize = qzSafeRead(h->hSrc, src, srcSize, blockSize);
+        srcSize = gProc.lookahead == 2 ? qzSafeReadPipe(s->pipeFd, h->hSrc, src, srcSize, blockSize)
+                                       : qzSafeRead(h->hSrc, src, srcSize, blockSize);
         if (srcSize == 0) return 0;
         nb = srcSize / blockSize;
         srcBytes = (srcSize + 63) & ~(size_t)63;

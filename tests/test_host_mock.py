@@ -30,6 +30,24 @@ def mock(oracle):
     plug.lib.QZSTD_stopQatDevice()
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def restarted(mock, **env):
+    """stop the (mock) device, restart it with environment variables set, and put everything back afterwards"""
+    mock.lib.QZSTD_stopQatDevice()
+    os.environ.update(env)
+    try:
+        assert mock.lib.QZSTD_startQatDevice() == 0
+        yield
+    finally:
+        for k in env:
+            del os.environ[k]
+        mock.lib.QZSTD_stopQatDevice()
+        assert mock.lib.QZSTD_startQatDevice() == 0
+
+
 def frames_of(zstd, producer_addr, state, addr, total, chunk, level, before=None, order=None, **params):
     zc = zstd.cctx(level, producer=producer_addr, state=state, fallback=False, validate=True, **params)
     cap = zstd.lib.ZSTD_compressBound(chunk)
@@ -69,7 +87,13 @@ def test_unchanged_caller_guessed_lookahead(mock, zstd, oracle, level, chunk):
     assert stats[2] == 0 and stats[0] >= 16, stats  # nothing announced; most blocks came from guesses
 
 
-def test_stale_guess_and_unreadable_page(mock, zstd, oracle):
+@pytest.mark.parametrize("mode", ["1", "2"])  # fault-safe read by process_vm_readv / through a pipe
+def test_stale_guess_and_unreadable_page(mock, zstd, oracle, mode):
+    with restarted(mock, QZSTD_HIP_LOOKAHEAD=mode):
+        _stale_guess_and_unreadable_page(mock, zstd, oracle)
+
+
+def _stale_guess_and_unreadable_page(mock, zstd, oracle):
     libc = C.CDLL(None, use_errno=True)
     page, nblk, chunk = mmap.PAGESIZE, 10, 65536
     total = nblk * chunk
@@ -86,7 +110,13 @@ def test_stale_guess_and_unreadable_page(mock, zstd, oracle):
     got = frames_of(zstd, mock.producer_addr, st, base, total, chunk, 1, before=rewrite)
     assert got == oracle_frames(zstd, oracle, final, chunk, 1)
     got = frames_of(zstd, mock.producer_addr, st, base, total, chunk, 1, order=[7, 2, 9, 0, 1, 3, 8, 4, 6, 5])
+    assert got == oracle_frames(zstd, oracle, final, chunk, 1)
     mock.lib.QZSTD_freeSeqProdState(st)
+    st = mock.lib.QZSTD_createSeqProdState()  # a fresh state (the old one has backed off): in order, stable content
+    got = frames_of(zstd, mock.producer_addr, st, base, total, chunk, 1)
+    served = stats_of(mock, st)[0]
+    mock.lib.QZSTD_freeSeqProdState(st)
+    assert served >= 5, served  # guesses are used right up to the unreadable page
     assert got == oracle_frames(zstd, oracle, final, chunk, 1)
     assert libc.mprotect(C.c_void_p(base + total), C.c_size_t(page), 3) == 0
     del got
@@ -175,7 +205,8 @@ plug.lib.QZSTD_stopQatDevice()
 assert ok == [True] * 6, ok
 print("OK")
 ''' % (os.path.join(ROOT, "tools"), MOCK_SO)
-    for env in ({"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SLOTS": "3"}, {"QZSTD_HIP_LOOKAHEAD": "0"}, {"QZSTD_HIP_EXT_REPCODES": "1"}):
+    for env in ({"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SLOTS": "3"}, {"QZSTD_HIP_LOOKAHEAD": "0"}, {"QZSTD_HIP_LOOKAHEAD": "2"},
+                {"QZSTD_HIP_EXT_REPCODES": "1"}):
         out = subprocess.run(["python", "-c", script], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
         assert out.returncode == 0 and "OK" in out.stdout, (env, out.stderr[-800:])
 
@@ -193,14 +224,9 @@ def test_lookahead_never_changes_the_output(mock, zstd):
         return fr
 
     on = {c: run(c) for c in (1 << 20, 393216)}
-    mock.lib.QZSTD_stopQatDevice()
-    os.environ["QZSTD_HIP_LOOKAHEAD"] = "0"
-    try:
-        assert mock.lib.QZSTD_startQatDevice() == 0
+    with restarted(mock, QZSTD_HIP_LOOKAHEAD="0"):
         off = {c: run(c) for c in (1 << 20, 393216)}
-    finally:
-        del os.environ["QZSTD_HIP_LOOKAHEAD"]
-        mock.lib.QZSTD_stopQatDevice()
-        assert mock.lib.QZSTD_startQatDevice() == 0
-    assert on == off
+    with restarted(mock, QZSTD_HIP_LOOKAHEAD="2"):
+        piped = {c: run(c) for c in (1 << 20, 393216)}
+    assert on == off == piped
     assert b"".join(zstd.decompress(f, 1 << 20) for f in on[1 << 20]) == data
