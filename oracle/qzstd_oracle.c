@@ -7,7 +7,12 @@
  * (qat-zstd-plugin_amd/csrc/qzstd_kernels.hip).  The definition is written so a
  * workgroup can evaluate it in parallel and still get the same bits:
  *
- *   1. CANDIDATES, tile by tile (tile = 1<<tileLog consecutive positions):
+ *   0. Levels >= 5 (profile.chainDepth != 0): EXACT hash chains, the sequential semantics of zstd's own
+ *      lazy levels — position p sees every earlier position with its 4-byte hash slot, newest first,
+ *      chainDepth links deep, and keeps the candidate with the highest gain (qzo_candidates_chain).
+ *      On the GPU the matcher waves take turns in position order and resolve same-slot positions inside
+ *      a wave with ballots, so the result does not depend on scheduling either.
+ *   1. CANDIDATES of levels 1-4, tile by tile (tile = 1<<tileLog consecutive positions):
  *      every position p of the tile reads the hash-table entry of its 4-byte
  *      hash as it was BEFORE the tile (=> newest earlier-tile position with that
  *      hash), then all positions of the tile are inserted; concurrent inserts to
@@ -56,28 +61,33 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
     (void)blockSize; /* the profile does not depend on the block size (the kernel's LDS footprint is fixed) */
-    /* levels 1-2: 6400 + no long table = 81.6 KB of LDS, two blocks per CU; levels >= 3: a bigger
-     * table plus a second table keyed by 8 bytes (the double-fast idea of zstd's levels 3-4), one block per CU */
-    out->tableSize = level >= 3 ? 16000u : 6400u;
-    out->longSize = level >= 3 ? 8192u : 0u;
+    /* levels 1-2: 6400 + no long table = 81.6 KB of LDS, two blocks per CU; levels 3-4: a bigger
+     * table plus a second table keyed by 8 bytes (the double-fast idea of zstd's levels 3-4), one block per CU;
+     * levels >= 5: exact hash chains (zstd: greedy / lazy / lazy2 / btlazy2 over a 4-byte hash), where the size
+     * of the head table hardly matters (a collision costs one chain step): 6400 again, two blocks per CU */
+    const int chains = level >= 5;
+    out->tableSize = chains ? 6400u : (level >= 3 ? 16000u : 6400u);
+    out->longSize = (!chains && level >= 3) ? 8192u : 0u;
     out->tileLog = 9;
-    out->capLen = 64;
+    out->capLen = level >= 9 ? 128u : 64u;
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;
-    out->lazy = 3;
+    out->lazy = chains ? 4u : 3u; /* 4 = the lazy rules compare gains (length and offset cost), not lengths */
     out->backExt = 4;
-    out->nearTab = 1;
+    out->nearTab = chains ? 0u : 1u;
     out->window = 0;
-    out->hashBytes = 5;
+    out->hashBytes = chains ? 4u : 5u;
     out->extLog = 11;
     /* libzstd turns repeat offsets of external sequences into repcodes only from level 10 (or when the
      * caller sets ZSTD_c_searchForExternalRepcodes); without that, short repeat matches cost a full offset */
-    out->repWin = (repcodes || level >= 10) ? 8u : 0u;
-    /* levels >= 5 (zstd: greedy, then lazy with 8 attempts, lazy2, btlazy2): walk the hash chain */
-    out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : (level >= 5 ? 4u : 0u));
-    /* per-wave turns where the waves have the time (chains) and at level 2, which buys its better ratio with them */
-    out->subTileLog = (level >= 5 || level == 2) ? 6u : 0u;
+    out->repWin = (repcodes || level >= 10) ? 16u : 0u;
+    /* levels >= 5: links walked per position (software zstd: 2^searchLog = 4..128 attempts plus repcodes; the
+     * producer API gives no repcodes below level 10, which deeper chains make up for) */
+    out->chainDepth = level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u)));
+    /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
+     * level 2, which buys its better ratio with them */
+    out->subTileLog = (chains || level == 2) ? 6u : 0u;
     return 0;
 }
 
@@ -126,13 +136,12 @@ static inline uint32_t qzo_mix8(const uint8_t *p)
 }
 
 static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t n,
-                           qzo_cand_t *cand, uint32_t *tbl, uint32_t *near, uint32_t *tblL, uint32_t *chain)
+                           qzo_cand_t *cand, uint32_t *tbl, uint32_t *near, uint32_t *tblL)
 {
     const uint32_t nl = pf->longSize && n >= 8u ? n - 7u : 0u; /* positions that have 8 bytes for the long table */
     const uint32_t nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0; /* hashable positions */
     const uint32_t T = 1u << pf->tileLog;
     const uint32_t S = pf->subTileLog ? 1u << pf->subTileLog : T;
-    uint32_t old0[1u << 10];
     uint32_t t0, s0, p;
 
     memset(tbl, 0, sizeof(uint32_t) * pf->tableSize);
@@ -151,10 +160,6 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
                 if (e < near[hn]) near[hn] = e;
             }
         }
-        /* levels with chains remember what every slot held before the tile: chain links never point into
-         * the tile that is being processed (on the GPU they live in device memory) */
-        if (pf->chainDepth)
-            for (p = t0; p < t1; p++) old0[p - t0] = tbl[qzo_slot(qzo_mix(src + p, pf->hashBytes), pf->tableSize)] >> QZO_TAG_BITS;
         /* look-up and insertion go sub-tile by sub-tile (= the whole tile when subTileLog is 0) */
         for (s0 = t0; s0 < t1; s0 += S) {
             const uint32_t s1 = s0 + S < t1 ? s0 + S : t1;
@@ -197,27 +202,6 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
                         }
                     }
                 }
-                /* probes 4.. (levels >= 6): the predecessor chain of the main-table slot.  chain[x] = what the
-                 * slot held before x's tile (position + 1, any tag; 0 = end).  The head itself was probe 1; a
-                 * chain candidate replaces the best so far only with a strictly higher gain (4 per matched
-                 * byte minus the bit length of the offset).  On the GPU chain[] lives in device memory. */
-                if (pf->chainDepth) {
-                    const uint32_t head = old0[p - t0]; /* position + 1, or 0: the slot BEFORE the whole tile */
-                    uint32_t link = head, d;
-                    int bg = bestLen ? (int)(4u * bestLen) - (int)(31u - (uint32_t)__builtin_clz(bestOff + 1u)) : -1000000;
-                    chain[p] = head;
-                    /* probe 1 looked at the slot's current head; if that still is `head`, start one link further */
-                    if (link == (e >> QZO_TAG_BITS)) link = link ? chain[link - 1u] : 0u;
-                    for (d = 1; d < pf->chainDepth && link != 0u; d++) {
-                        const uint32_t q = link - 1u;
-                        if ((pf->window == 0 || p - q <= pf->window) && qzo_rd32(src + q) == v) {
-                            const uint32_t l = qzo_prefix_len(src, q, p, cap);
-                            const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
-                            if (l >= 4u && g > bg) { bestLen = l; bestOff = p - q; bg = g; }
-                        }
-                        link = chain[q];
-                    }
-                }
                 cand[p].len = bestLen;
                 cand[p].off = bestOff;
             }
@@ -234,6 +218,50 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
     }
 }
 
+/* gain of a match in quarter bytes: 4 per matched byte minus the bit length of the offset */
+static inline int qzo_gain(uint32_t len, uint32_t off)
+{
+    return (int)(4u * len) - (int)(31u - (uint32_t)__builtin_clz(off + 1u));
+}
+
+/*
+ * Candidates of the chain levels (>= 5): exact hash chains.  tbl[slot] = newest position + 1 with that slot of
+ * the first hashBytes (4) bytes, chain[p] = what the slot held when p was inserted.  Position p walks
+ * chainDepth links from the slot's content (collisions count as links), measures every link whose first
+ * four bytes equal its own (length capped at capLen) and keeps the one with the highest gain; on equal gain
+ * the nearer (earlier visited) one stays.  Then p is inserted.  Same semantics as the hash-chain match-finder of
+ * zstd's lazy levels.  On the GPU the head table lives in LDS, chain[] in device memory; the matcher waves take
+ * turns in position order, and positions of one wave that share a slot are ordered with ballots.
+ */
+static void qzo_candidates_chain(const qzo_profile_t *pf, const uint8_t *src, uint32_t n,
+                                 qzo_cand_t *cand, uint32_t *tbl, uint32_t *chain)
+{
+    const uint32_t nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
+    uint32_t p;
+    memset(tbl, 0, sizeof(uint32_t) * pf->tableSize);
+    for (p = 0; p < n; p++) cand[p].len = 0, cand[p].off = 0;
+    for (p = 0; p < nh; p++) {
+        const uint32_t v = qzo_rd32(src + p);
+        const uint32_t sl = qzo_slot(qzo_mix(src + p, pf->hashBytes), pf->tableSize);
+        const uint32_t cap = pf->capLen < n - p ? pf->capLen : n - p;
+        uint32_t link = tbl[sl], d, bestLen = 0, bestOff = 0;
+        int bg = 0;
+        chain[p] = link;
+        tbl[sl] = p + 1u;
+        for (d = 0; d < pf->chainDepth && link != 0u; d++) {
+            const uint32_t q = link - 1u;
+            if ((pf->window == 0 || p - q <= pf->window) && qzo_rd32(src + q) == v) {
+                const uint32_t l = qzo_prefix_len(src, q, p, cap);
+                const int g = qzo_gain(l, p - q);
+                if (l >= 4u && (bestLen == 0u || g > bg)) { bestLen = l; bestOff = p - q; bg = g; }
+            }
+            link = chain[q];
+        }
+        cand[p].len = bestLen;
+        cand[p].off = bestOff;
+    }
+}
+
 /* ---- parse + emission ------------------------------------------------------- */
 
 static inline uint32_t qzo_min_len(const qzo_profile_t *pf, uint32_t off)
@@ -245,10 +273,21 @@ static inline int qzo_take(const qzo_profile_t *pf, const qzo_cand_t *c)
     return c->len != 0 && c->len >= qzo_min_len(pf, c->off);
 }
 
-/* start flag of the plain parse: a usable candidate that none of the lazy rules defers */
+/* start flag of the plain parse: a usable candidate that none of the lazy rules defers.  The rules never look
+ * across a 64-position window edge (one wave decides a window).  lazy 1..3: by length; lazy 4 (chain levels): by
+ * gain, the thresholds of zstd's lazy2 (a match one position on must gain more than 4 quarter bytes, two on more
+ * than 7) */
+#define QZO_LAZY_T1 4
+#define QZO_LAZY_T2 7
 static inline int qzo_is_start(const qzo_profile_t *pf, const qzo_cand_t *cand, uint32_t nh, uint32_t p)
 {
     if (!qzo_take(pf, &cand[p])) return 0;
+    if (pf->lazy >= 4) {
+        const int g = qzo_gain(cand[p].len, cand[p].off);
+        if (p + 1 < nh && (p & 63u) < 63u && qzo_take(pf, &cand[p + 1]) && qzo_gain(cand[p + 1].len, cand[p + 1].off) > g + QZO_LAZY_T1) return 0;
+        if (p + 2 < nh && (p & 63u) < 62u && qzo_take(pf, &cand[p + 2]) && qzo_gain(cand[p + 2].len, cand[p + 2].off) > g + QZO_LAZY_T2) return 0;
+        return 1;
+    }
     if (pf->lazy && p + 1 < nh && (p & 63u) < 63u && qzo_take(pf, &cand[p + 1]) && cand[p + 1].len > cand[p].len) return 0;
     if (pf->lazy >= 2 && p + 2 < nh && (p & 63u) < 62u && qzo_take(pf, &cand[p + 2]) && cand[p + 2].len > cand[p].len) return 0;
     if (pf->lazy >= 3 && p + 3 < nh && (p & 63u) < 61u && qzo_take(pf, &cand[p + 3]) && cand[p + 3].len > cand[p].len + 2u)
@@ -272,7 +311,7 @@ static inline uint32_t qzo_extend(const qzo_profile_t *pf, const uint8_t *src, u
 
 /* "price" of taking a match, in quarter bytes saved: 4 per matched byte minus the bits of the offset;
  * a repeated offset is nearly free.  0 = no match.  Always > 0 for a usable candidate. */
-#define QZO_REP_CAP 16u   /* repeat-offset probes compare this many bytes; a full hit always wins */
+#define QZO_REP_CAP 32u   /* repeat-offset probes compare this many bytes; a full hit always wins */
 #define QZO_REP_MIN 3u
 static inline uint32_t qzo_hash_gain(const qzo_profile_t *pf, const qzo_cand_t *c)
 {
@@ -286,69 +325,57 @@ static inline uint32_t qzo_rep_gain(uint32_t l, uint32_t r)
 }
 
 /*
- * Parse, repeat-offset aware variant (profile.repWin != 0).  Same candidates and the same start flags as
- * the plain parse; in addition, on arrival at the end of a match, the next repWin positions (inside the
- * current tile) are also tried with the last two distinct offsets; if any of those probes hits, the choice
- * among {candidate, repeat 1, repeat 2} at those positions, and the one/two-position deferral, go by
- * qzo_*_gain (otherwise the plain start flags decide, as if there were no repeats).
- * Shaped for the kernel's parse wave: one 16-byte vector probe per arrival, no other new state than the
- * two offsets.  libzstd encodes such offsets as repcodes when ZSTD_c_searchForExternalRepcodes is on.
+ * Parse, repeat-offset aware variant (profile.repWin != 0: levels >= 10, or any level | QZO_LEVEL_REPCODES).
+ * Same candidates; the parse walks window by window: the repWin positions from the cursor (never across a tile
+ * edge) are offered {candidate, repeat 1, repeat 2} — the repeats being the last two distinct offsets, probed over
+ * QZO_REP_CAP bytes — and the first position whose best option is not beaten by the next position (by more than
+ * 4 quarter bytes of gain) or the one after (by more than 11) is taken; a window without any option is skipped.
+ * The deferral looks at most two positions past the window.  libzstd encodes such offsets as repcodes when
+ * ZSTD_c_searchForExternalRepcodes is on.  Shaped for the kernel's parse wave: one lane per window position, the
+ * repeat probes as two byte-equality ballots.
  */
 static size_t qzo_parse_rep(const qzo_profile_t *pf, const uint8_t *src, uint32_t n, uint32_t nh,
                             const qzo_cand_t *cand, qzo_seq_t *out, size_t cap)
 {
     uint32_t cur = 0, anchor = 0, rep[2] = { 0u, 0u };
-    int arrival = 0;
     size_t ns = 0;
     while (cur < nh) {
-        uint32_t q = 0, off = 0, L = 0, b = 0;
+        const uint32_t tileEnd = ((cur >> pf->tileLog) + 1u) << pf->tileLog;
+        const uint32_t lim = tileEnd < nh ? tileEnd : nh;
+        const uint32_t W = pf->repWin < lim - cur ? pf->repWin : lim - cur; /* positions on offer */
+        const uint32_t V = W + 2u < lim - cur ? W + 2u : lim - cur;         /* ... + look-ahead for the deferral */
+        uint32_t G[34], opt[34], k, r, q = 0, off = 0, L = 0, b = 0;
         int found = 0;
-        if (arrival && rep[0] != 0u) {
-            const uint32_t tileEnd = ((cur >> pf->tileLog) + 1u) << pf->tileLog;
-            const uint32_t lim = tileEnd < nh ? tileEnd : nh;
-            const uint32_t W = pf->repWin < lim - cur ? pf->repWin : lim - cur;       /* positions probed with the repeats */
-            const uint32_t V = W + 2u < lim - cur ? W + 2u : lim - cur;               /* ... + look-ahead for the deferral */
-            uint32_t G[34], opt[34], k, r, hits = 0;
-            for (k = 0; k < V; k++) {
-                const uint32_t p = cur + k;
-                G[k] = qzo_hash_gain(pf, &cand[p]);
-                opt[k] = 0;
-                for (r = 0; r < 2u && k < W; r++) {
-                    if (rep[r] != 0u) {
-                        const uint32_t mx = n - p < QZO_REP_CAP ? n - p : QZO_REP_CAP;
-                        const uint32_t g = qzo_rep_gain(qzo_prefix_len(src, p - rep[r], p, mx), r);
-                        hits += g != 0u;
-                        if (g > G[k]) { G[k] = g; opt[k] = 1u + r; }
-                    }
+        for (k = 0; k < V; k++) {
+            const uint32_t p = cur + k;
+            G[k] = qzo_hash_gain(pf, &cand[p]);
+            opt[k] = 0;
+            for (r = 0; r < 2u; r++) {
+                if (rep[r] != 0u) {
+                    const uint32_t mx = n - p < QZO_REP_CAP ? n - p : QZO_REP_CAP;
+                    const uint32_t g = qzo_rep_gain(qzo_prefix_len(src, p - rep[r], p, mx), r);
+                    if (g > G[k]) { G[k] = g; opt[k] = 1u + r; }
                 }
             }
-            if (!hits) { arrival = 0; continue; } /* no repeat in reach: the plain start flags decide from here */
-            for (k = 0; k < W && !found; k++) {
-                if (G[k] == 0u) continue;
-                if (k + 1u < V && G[k + 1u] > G[k] + 4u) continue;
-                if (k + 2u < V && G[k + 2u] > G[k] + 11u) continue;
-                found = 1;
-                q = cur + k;
-                if (opt[k]) {
-                    const uint32_t mx = n - q < QZO_REP_CAP ? n - q : QZO_REP_CAP;
-                    off = rep[opt[k] - 1u];
-                    L = qzo_prefix_len(src, q - off, q, mx);
-                    if (L == QZO_REP_CAP) L = qzo_extend(pf, src, n, q, off, L);
-                } else {
-                    off = cand[q].off;
-                    L = cand[q].len;
-                    if (L == pf->capLen) L = qzo_extend(pf, src, n, q, off, L);
-                }
-            }
-            if (!found) { cur += W; arrival = 0; continue; }
-        } else {
-            while (cur < nh && !qzo_is_start(pf, cand, nh, cur)) cur++;
-            if (cur >= nh) break;
-            q = cur;
-            off = cand[q].off;
-            L = cand[q].len;
-            if (L == pf->capLen) L = qzo_extend(pf, src, n, q, off, L);
         }
+        for (k = 0; k < W && !found; k++) {
+            if (G[k] == 0u) continue;
+            if (k + 1u < V && G[k + 1u] > G[k] + 4u) continue;
+            if (k + 2u < V && G[k + 2u] > G[k] + 11u) continue;
+            found = 1;
+            q = cur + k;
+            if (opt[k]) {
+                const uint32_t mx = n - q < QZO_REP_CAP ? n - q : QZO_REP_CAP;
+                off = rep[opt[k] - 1u];
+                L = qzo_prefix_len(src, q - off, q, mx);
+                if (L == QZO_REP_CAP) L = qzo_extend(pf, src, n, q, off, L);
+            } else {
+                off = cand[q].off;
+                L = cand[q].len;
+                if (L == pf->capLen) L = qzo_extend(pf, src, n, q, off, L);
+            }
+        }
+        if (!found) { cur += W; continue; }
         while (b < pf->backExt && q - b > anchor && q - off - b > 0 && src[q - b - 1] == src[q - off - b - 1]) b++;
         if (ns + 1 >= cap - 1) return QZO_ERROR; /* src/qatseqprod.c:1073-1076 */
         out[ns].offset = off;
@@ -358,7 +385,6 @@ static size_t qzo_parse_rep(const qzo_profile_t *pf, const uint8_t *src, uint32_
         ns++;
         if (off != rep[0]) { rep[1] = rep[0]; rep[0] = off; }
         cur = anchor = q + L;
-        arrival = 1;
     }
     out[ns].offset = 0; /* trailing literals delimiter, src/qatseqprod.c:1037-1045 */
     out[ns].litLength = n - anchor;
@@ -381,7 +407,7 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
 
     if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
-        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->chainDepth > 64 || pf->subTileLog > pf->tileLog || (pf->subTileLog && pf->subTileLog < 4) || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
+        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->lazy > 4 || (pf->chainDepth && (pf->nearTab || pf->longSize)) || pf->chainDepth > 64 || pf->subTileLog > pf->tileLog || (pf->subTileLog && pf->subTileLog < 4) || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
         return QZO_ERROR;
     nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
 
@@ -392,7 +418,8 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
     chain = (uint32_t *)calloc((size_t)n + 1u, sizeof(uint32_t));
     if (!cand || !tbl || !near || !tblL || !chain) { free(cand); free(tbl); free(near); free(tblL); free(chain); return QZO_ERROR; }
 
-    qzo_candidates(pf, src, n, cand, tbl, near, tblL, chain);
+    if (pf->chainDepth) qzo_candidates_chain(pf, src, n, cand, tbl, chain);
+    else qzo_candidates(pf, src, n, cand, tbl, near, tblL);
 
     if (pf->repWin) {
         ns = qzo_parse_rep(pf, src, n, nh, cand, out, cap);
@@ -400,24 +427,7 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
     }
     while (p < nh) {
         uint32_t L, off, q, b = 0;
-        if (!qzo_take(pf, &cand[p])) { p++; continue; }
-        if (pf->lazy && p + 1 < nh && ((p + 1) & 63u) != 0 /* never across a 64-position window edge */ &&
-            qzo_take(pf, &cand[p + 1]) && cand[p + 1].len > cand[p].len) {
-            p++; /* one-step lazy: the next position has a strictly longer match */
-            continue;
-        }
-        /* deeper lazy steps: a match two positions on that is longer, or three on and longer by more
-         * than two bytes, is preferred (thresholds tuned on the bench corpus against software zstd) */
-        if (pf->lazy >= 2 && p + 2 < nh && (p & 63u) < 62u && qzo_take(pf, &cand[p + 2]) &&
-            cand[p + 2].len > cand[p].len) {
-            p++;
-            continue;
-        }
-        if (pf->lazy >= 3 && p + 3 < nh && (p & 63u) < 61u && qzo_take(pf, &cand[p + 3]) &&
-            cand[p + 3].len > cand[p].len + 2u) {
-            p++;
-            continue;
-        }
+        if (!qzo_is_start(pf, cand, nh, p)) { p++; continue; } /* no usable candidate, or deferred by a lazy rule */
         L = cand[p].len;
         off = cand[p].off;
         q = p - off;

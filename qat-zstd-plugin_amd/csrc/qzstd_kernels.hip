@@ -48,6 +48,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "qzstd_hip.h"
 
 namespace {
@@ -102,7 +104,6 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 below(uint32_t c) { return c >= 64u ? ~0ull : ((1ull << c) - 1ull); }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 /* where the block's bytes can be read from: the LDS ring (recent bytes) or HBM (anything) */
 /* explicit address spaces: through generic pointers the compiler falls back to FLAT loads for the ring */
@@ -351,22 +352,23 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
 }
 
 /*
- * Repeat-offset aware parse (profile.repWin != 0; oracle: qzo_parse_rep).  Same candidates and the same
- * start flags; in addition, on arrival at the end of a match the next repWin positions (inside the tile)
- * are probed with the last two offsets: lane k holds {candidate, repeat 1, repeat 2} of position cur+k,
- * 16 bytes compared per probe, everything in one LDS round trip; if any probe hits, the choice and
- * the one/two position deferral go by gain (4 per byte, minus the offset bits for a candidate, a full probe hit always
- * wins).  Per position the matchers leave   ns (7 bits) | capped length (7) | offset (17).
+ * Repeat-offset aware parse (profile.repWin != 0; oracle: qzo_parse_rep).  The parse wave walks window by
+ * window: lane k stands for position cursor+k (repWin = 16 positions on offer + 2 of look-ahead, never across the
+ * tile edge) and weighs {candidate, repeat 1, repeat 2}; the repeats (the last two distinct offsets) are probed
+ * byte-wise across the wave — lane b compares byte cursor+b with the byte one offset back, one ballot per offset =
+ * the equality bitmap of the next 64 bytes, and the match length at position cursor+k is the run of ones from bit k,
+ * capped at kRepCap = 32.  The first position whose best option is not beaten by the next one (by more than 4
+ * quarter bytes of gain) or the one after (by more than 11) is taken; a window without any option is skipped.
+ * Per position the matchers leave   capped length (8 bits, << 7) | offset (17 bits, << 15).
  * Every chosen match is written back over the parse words of its first three positions (behind the
  * cursor: dead) as {offset, length, index, literal anchor} for the emitting wave: no masks, no ranks.
  */
 struct RepState {
     uint32_t cur, anchor, nseq;
     uint32_t rep1, rep2; /* the last two distinct offsets */
-    uint32_t arrival;    /* standing at the end of a match */
     uint32_t tileSeq;    /* nseq when the parse entered the tile being parsed */
 };
-constexpr uint32_t kRepCap = 16u, kRepMin = 3u;
+constexpr uint32_t kRepCap = 32u, kRepMin = 3u;
 constexpr uint32_t kChosenBit = 0x80000000u; /* marks a parse-word slot rewritten into a chosen-match record */
 
 /* one byte of the block at position x: from the ring, or from HBM when `far` */
@@ -377,95 +379,63 @@ __device__ __forceinline__ uint32_t ring_byte(const Src &s, uint32_t x, bool far
     return reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(s.ring)[umin(m, m - kRing)];
 }
 
-/* parse from the cursor up to `limit` (a window boundary inside the tile that starts at `base`).  A plain
- * loop, one sequence per iteration: [probe the repeats on arrival] -> [else chase the start flags] ->
- * record.  The parse words are read from LDS (a window at a time for the chase, the probe window
- * directly), which keeps the code small and the state in SGPRs. */
-__device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, const Src &src, uint32_t *pvT, uint32_t *srecT,
+/* equality bitmap of the 64 bytes from `cur` against the bytes `rp` back (0 when rp == 0): bit b = byte cur+b matches */
+__device__ __forceinline__ u64 rep_bitmap(const Src &src, uint32_t cur, uint32_t rp, uint32_t n, uint32_t lane)
+{
+    if (rp == 0u) return 0ull; /* uniform */
+    const uint32_t bpos = cur + lane;
+    bool eq = false;
+    if (bpos < n) eq = ring_byte(src, bpos, false) == ring_byte(src, bpos - rp, rp > kNear);
+    return __ballot(eq);
+}
+
+/* parse from the cursor up to `limit` (a window boundary inside the tile that starts at `base`): one window
+ * evaluation per iteration, state in SGPRs */
+__device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, const Src &src, uint32_t *pvT,
                                                uint32_t base, uint32_t limit, uint32_t n, uint32_t nh, uint32_t lane,
-                                               RepState &st, uint32_t dbg = 0u)
+                                               RepState &st)
 {
     const uint32_t tileLim = umin(base + kTile, nh), stop = umin(limit, nh);
-    uint32_t wv = 0, cw0 = kNone; /* parse words of the window the chase is in */
     while (st.cur < stop) {
-        uint32_t q = 0, off = 0, L = 0;
-        uint32_t from = pf.capLen; /* a length equal to this is a capped one: extend */
-        bool have = false;
-        if (st.arrival && st.rep1 != 0u && !(dbg & 64u)) {
-            st.arrival = 0u;
-            const uint32_t W = umin(pf.repWin, tileLim - st.cur), V = umin(W + 2u, tileLim - st.cur);
-            /* the probe, byte-wise across the wave: lane b (< 32) compares byte cursor+b with the byte one
-             * repeat-1 offset back, lane 32+b with repeat 2; the ballot is the equality bitmap of the next 32
-             * bytes for both offsets, and the match length at position cursor+k is the run of ones from
-             * bit k (8 positions x 16 bytes fit in 32).  One LDS round trip, a handful of instructions. */
-            const uint32_t bpos = st.cur + (lane & 31u);
-            const uint32_t rp = lane < 32u ? st.rep1 : st.rep2;
-            uint32_t wd = 0;
-            if (lane < V) wd = pvT[st.cur + lane - base]; /* parse word of the window position (same round trip) */
-            bool eq = false;
-            if (rp != 0u && bpos < n) {
-                const uint32_t A = ring_byte(src, bpos, false);
-                uint32_t Bv;
-                if (umax(st.rep1, st.rep2) <= kNear) Bv = ring_byte(src, bpos - rp, false); /* uniform: the usual case */
-                else Bv = ring_byte(src, bpos - rp, rp > kNear);
-                eq = A == Bv;
-            }
-            const u64 M = __ballot(eq);
-            const uint32_t M1 = (uint32_t)M, M2 = (uint32_t)(M >> 32);
-            uint32_t rl1 = 0, rl2 = 0;
-            if (lane < W) {
-                rl1 = umin((uint32_t)__builtin_ctz(~(M1 >> lane) | 0x10000u), kRepCap);
-                rl2 = umin((uint32_t)__builtin_ctz(~(M2 >> lane) | 0x10000u), kRepCap);
-            }
-            const uint32_t rg1 = rl1 < kRepMin ? 0u : (rl1 >= kRepCap ? 1000u : 4u * rl1 + 36u);
-            const uint32_t rg2 = rl2 < kRepMin ? 0u : (rl2 >= kRepCap ? 999u : 4u * rl2 + 35u);
-            if (__ballot((rg1 | rg2) != 0u) && !(dbg & 128u)) { /* else: no repeat in reach, the start flags decide */
-                const uint32_t cl = (wd >> 7) & 0x7Fu, co = wd >> 14;
-                uint32_t G = 0, opt = 0;
-                if (cl != 0u && cl >= min_len(pf, co)) G = 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(co + 1u));
-                if (rg1 > G) { G = rg1; opt = 1u; }
-                if (rg2 > G) { G = rg2; opt = 2u; }
-                /* the gains one and two positions on: DPP row shifts (the window lives in lanes 0-15 = one row) */
-                const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x101, 0xF, 0xF, true);
-                const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x102, 0xF, 0xF, true);
-                const bool ok = lane < W && G != 0u && !(G1 > G + 4u) && !(G2 > G + 11u);
-                const u64 m = __ballot(ok);
-                if (m) {
-                    const uint32_t ks = (uint32_t)__builtin_ctzll(m);
-                    const uint32_t o = rdlane(opt, ks);
-                    q = st.cur + ks;
-                    if (o == 0u) {
-                        off = rdlane(co, ks);
-                        L = rdlane(cl, ks);
-                    } else {
-                        off = o == 1u ? st.rep1 : st.rep2;
-                        L = rdlane(o == 1u ? rl1 : rl2, ks);
-                        from = kRepCap;
-                    }
-                    have = true;
-                } else {
-                    st.cur += W;
-                }
-            }
+        const uint32_t W = umin(pf.repWin, tileLim - st.cur), V = umin(W + 2u, tileLim - st.cur);
+        uint32_t wd = 0;
+        if (lane < V) wd = pvT[st.cur + lane - base]; /* the candidate of the window position */
+        const u64 M1 = rep_bitmap(src, st.cur, st.rep1, n, lane);
+        const u64 M2 = rep_bitmap(src, st.cur, st.rep2, n, lane);
+        uint32_t rl1 = 0, rl2 = 0;
+        if (lane < V) {
+            const u64 z1 = ~(M1 >> lane), z2 = ~(M2 >> lane); /* lane < 18: 32 bits of look-ahead are always there; the shift feeds zeros */
+            rl1 = umin((uint32_t)__builtin_ctzll(z1), kRepCap);
+            rl2 = umin((uint32_t)__builtin_ctzll(z2), kRepCap);
         }
-        if (!have) { /* chase the start flags from the cursor */
-            for (;;) {
-                if (st.cur >= stop) return;
-                const uint32_t w0 = st.cur & ~63u;
-                if (w0 != cw0) {
-                    wv = pvT[w0 - base + lane];
-                    cw0 = w0;
-                }
-                const uint32_t j = rdlane(wv, st.cur & 63u) & 0x7Fu; /* next start flag at/after the cursor */
-                if (j < 64u) {
-                    const uint32_t wd = rdlane(wv, j);
-                    q = w0 + j;
-                    L = (wd >> 7) & 0x7Fu;
-                    off = wd >> 14;
-                    break;
-                }
-                st.cur = w0 + 64u;
-            }
+        const uint32_t rg1 = rl1 < kRepMin ? 0u : (rl1 >= kRepCap ? 1000u : 4u * rl1 + 36u);
+        const uint32_t rg2 = rl2 < kRepMin ? 0u : (rl2 >= kRepCap ? 999u : 4u * rl2 + 35u);
+        const uint32_t cl = (wd >> 7) & 0xFFu, co = wd >> 15;
+        uint32_t G = 0, opt = 0;
+        if (cl != 0u && cl >= min_len(pf, co)) G = 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(co + 1u));
+        if (rg1 > G) { G = rg1; opt = 1u; }
+        if (rg2 > G) { G = rg2; opt = 2u; }
+        /* the gains one and two positions on: whole-wave DPP shifts (lane i reads lane i+1); lanes >= V hold 0 */
+        const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x130, 0xF, 0xF, true);
+        const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G1, 0x130, 0xF, 0xF, true);
+        const bool ok = lane < W && G != 0u && !(G1 > G + 4u) && !(G2 > G + 11u);
+        const u64 m = __ballot(ok);
+        if (!m) { /* nothing on offer in this window */
+            st.cur += W;
+            continue;
+        }
+        const uint32_t ks = (uint32_t)__builtin_ctzll(m);
+        const uint32_t o = rdlane(opt, ks);
+        const uint32_t q = st.cur + ks;
+        uint32_t off, L, from;
+        if (o == 0u) {
+            off = rdlane(co, ks);
+            L = rdlane(cl, ks);
+            from = pf.capLen;
+        } else {
+            off = o == 1u ? st.rep1 : st.rep2;
+            L = rdlane(o == 1u ? rl1 : rl2, ks);
+            from = kRepCap;
         }
         if (L == from) L = extend_match(src, q, off, from, umin(n, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
         /* record, branch-free: the three parse-word slots at the start of the match (all behind the new cursor,
@@ -482,7 +452,6 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
             st.rep1 = off;
         }
         st.cur = st.anchor = q + L;
-        st.arrival = 1u;
     }
 }
 
@@ -612,7 +581,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #endif
         uint32_t nseqEnd, anchorEnd;
         if (REP) {
-            RepState st = { 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+            RepState st = { 0u, 0u, 0u, 0u, 0u, 0u };
             for (uint32_t it = 0; it < nTiles + 2u; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u, base = k << kTileLog;
@@ -620,12 +589,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 if (work) {
                     st.tileSeq = st.nseq;
                     if (lane == 0u) srecT[0] = st.nseq; /* the records carry indices relative to this */
-                    parse_rep_span(pf, src, pvT, srecT, base, base + 64u * kSplit, n, nh, lane, st, QZ_DBG);
+                    parse_rep_span(pf, src, pvT, base, base + 64u * kSplit, n, nh, lane, st);
                 }
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
                 QZ_PLAP(pW1)
-                if (work) parse_rep_span(pf, src, pvT, srecT, base, base + kTile, n, nh, lane, st, QZ_DBG);
+                if (work) parse_rep_span(pf, src, pvT, base, base + kTile, n, nh, lane, st);
                 QZ_PLAP(pI2)
                 __syncthreads(); /* B2 */
                 QZ_PLAP(pW2)
@@ -717,7 +686,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             mix = (v * kPrime1) ^ (hi * kPrime2);
             slot = __umulhi(mix, pf.tableSize);
             nslot = mix >> nearShift;
-            if (!TURNS || CHAIN) old = tbl[slot]; /* with turns only the chain needs the pre-tile content */
+            if (!TURNS) old = tbl[slot]; /* with turns the slot is read when the wave's turn comes */
             if (pf.nearTab) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
             if (validL) { /* second table, keyed by the first 8 bytes */
                 const uint32_t m8 = (v * kPrime1) ^ (oa[1] * kPrime2);
@@ -738,7 +707,70 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         }
         offB = offA; lenB = lenA;
         uint32_t cl = 0, off = 0; /* capped candidate length, offset */
-        const uint32_t old0 = old; /* the main-table slot before the tile: head of the chain (CHAIN) */
+        if (CHAIN) {
+            /* Levels >= 5: exact hash chains (oracle: qzo_candidates_chain).  The waves take turns in position order;
+             * at its turn a wave reads its slots (newest earlier position + 1, with that position's tag), inserts
+             * its own positions (ds_max: the newest wins), and orders the positions that share a slot INSIDE the
+             * wave with ballots, so every position gets its exact predecessor.  The links of the current tile
+             * stay in LDS (chainT: later waves of this tile may walk them at once); all links also go to device
+             * memory (chainB), where later tiles find them (ordered by the barriers in between). */
+            uint32_t *chainB = args.chain + (size_t)blockIdx.x * args.chainStride;
+            uint32_t *chainT = nearTab; /* [kTile] links of the tile in progress */
+            const uint32_t tag = (mix >> 3) & kTagMask;
+            const uint32_t mine = ((p + 1u) << kTagBits) | tag;
+            const uint32_t turn = it * (uint32_t)kMatchWaves + wave;
+            uint32_t spins = 0, predE = 0;
+            while (__hip_atomic_load(turnCtr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != turn && ++spins < (1u << 22))
+                __builtin_amdgcn_s_sleep(1);
+            if (valid) {
+                predE = tbl[slot];
+                atomicMax(&tbl[slot], mine);
+            }
+            {
+                /* lanes that are not the newest of their slot in this window have a same-slot lane above them */
+                const uint32_t fin = valid ? __hip_atomic_load(&tbl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : mine;
+                u64 rem = __ballot(fin != mine);
+                while (rem) {
+                    const uint32_t s0 = rdlane(slot, (uint32_t)__builtin_ctzll(rem));
+                    const bool in = valid && slot == s0;
+                    const u64 grp = __ballot(in);
+                    const u64 lower = grp & below(lane);
+                    const uint32_t e = (uint32_t)__shfl((int)mine, lower ? 63 - __builtin_clzll(lower) : (int)lane);
+                    if (in && lower) predE = e; /* the nearest lower lane of the group */
+                    rem &= ~grp;
+                }
+            }
+            chainT[tid] = valid ? predE : 0u;
+            if (lane == 0u) __hip_atomic_store(turnCtr, turn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (valid) chainB[p] = predE;
+            /* the walk: chainDepth links, newest first; a link whose tag differs is a slot collision (skipped without
+             * touching its bytes); the candidate with the highest gain stays, the nearer one on a tie */
+            const uint32_t cap = valid ? umin(pf.capLen, n - p) : 0u;
+            uint32_t linkE = valid ? predE : 0u;
+            int bg = 0;
+            for (uint32_t d = 0; d < pf.chainDepth; d++) {
+                if (!__ballot(linkE != 0u)) break;
+                if (linkE != 0u) {
+                    const uint32_t q = (linkE >> kTagBits) - 1u;
+                    const bool hit = (linkE & kTagMask) == tag && (pf.window == 0u || p - q <= pf.window);
+                    linkE = q >= t0 ? chainT[q - t0] : chainB[q]; /* next link: in flight during the compare */
+                    if (hit && !QZ_ABLATED(2u)) {
+                        const bool far = p - q > kNear;
+                        uint32_t l = head_len(src, oa, q, ring_back(rp, p - q), far);
+                        if (l == 16u && cap > 16u) {
+                            for (;;) {
+                                const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q, far);
+                                l += c;
+                                if (c < 32u || l >= cap) break;
+                            }
+                        }
+                        l = umin(l, cap);
+                        const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
+                        if (l >= 4u && (cl == 0u || g > bg)) { cl = l; off = p - q; bg = g; }
+                    }
+                }
+            }
+        } else {
         if (TURNS) {
             /* level 2 and levels >= 5 update the tables per 64 positions, in position order: the matcher waves take turns
              * (LDS counter, acquire/release at workgroup scope), each reading its slots before inserting its own
@@ -802,58 +834,30 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             if (l3 >= 4u && l3 > cl) { cl = l3; off = p - q3; }   /* 8-byte table: only if strictly longer */
             if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }  /* same tile: ties go to the nearer source */
         }
-        if (CHAIN && it < nTiles) {
-            /* candidates 4..: the predecessor chain of the main-table slot, in device memory (L2/MALL resident:
-             * 4 B per position).  chain[x] = what the slot held before x's tile (position + 1, any tag); every
-             * link points into an earlier tile, i.e. was stored at least two barriers ago.  A chain candidate
-             * replaces the best so far only with a strictly higher gain.  Dependent loads, ~1 us each: the
-             * matcher waves have that time at these levels (oracle: qzo_candidates, probes 4..). */
-            uint32_t *chainB = args.chain + (size_t)blockIdx.x * args.chainStride;
-            uint32_t link = 0;
-            int bg = cl ? (int)(4u * cl) - (int)(31u - (uint32_t)__builtin_clz(off + 1u)) : -1000000;
-            const uint32_t cap = valid ? umin(pf.capLen, n - p) : 0u;
-            if (valid) {
-                const uint32_t head = old0 >> kTagBits; /* what the slot held before the tile */
-                chainB[p] = head;
-                link = head;
-                /* candidate 1 looked at the slot's current head; if that still is `head`, start one link further */
-                if (head == (old >> kTagBits) && head)
-                    link = __hip_atomic_load(chainB + (head - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            for (uint32_t d = 1; d < pf.chainDepth; d++) {
-                if (!__ballot(link != 0u)) break;
-                if (link != 0u) {
-                    const uint32_t q = link - 1u;
-                    const bool far = p - q > kNear;
-                    link = __hip_atomic_load(chainB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* next link: in flight during the compare */
-                    if (pf.window == 0u || p - q <= pf.window) {
-                        uint32_t l = head_len(src, oa, q, ring_back(rp, p - q), far);
-                        if (l == 16u && cap > 16u) {
-                            for (;;) {
-                                const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q, far);
-                                l += c;
-                                if (c < 32u || l >= cap) break;
-                            }
-                        }
-                        l = umin(l, cap);
-                        const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
-                        if (l >= 4u && g > bg) { cl = l; off = p - q; bg = g; }
-                    }
-                }
-            }
         }
         if (it < nTiles && !QZ_ABLATED(4u)) {
             /* start flags: the lazy rules compare capped lengths and never look across the window edge */
             const bool take = cl != 0u && cl >= min_len(pf, off);
-            const uint32_t tl = take ? cl : 0u; /* length if this position could start a match, else 0 */
-            /* the next three positions' values: whole-wave DPP shifts (wave_shl:1 = lane i reads lane i+1), three
-             * VALU moves instead of three LDS permutes; what lane 63/62/61 read is masked by the edge rule below */
-            const uint32_t tl1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x130, 0xF, 0xF, true);
-            const uint32_t tl2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl1, 0x130, 0xF, 0xF, true);
-            const uint32_t tl3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl2, 0x130, 0xF, 0xF, true);
-            const bool defer1 = pf.lazy >= 1u && lane < 63u && tl1 > cl;      /* next position: strictly longer */
-            const bool defer2 = pf.lazy >= 2u && lane < 62u && tl2 > cl;      /* two on: strictly longer */
-            const bool defer3 = pf.lazy >= 3u && lane < 61u && tl3 > cl + 2u; /* three on: longer by more than two */
+            bool defer1, defer2, defer3 = false;
+            if (pf.lazy >= 4u) {
+                /* chain levels: by gain (4 per matched byte minus the offset's bit length, biased to stay positive);
+                 * one position on must gain more than 4, two on more than 7 (oracle: qzo_is_start) */
+                const uint32_t G = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
+                const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x130, 0xF, 0xF, true);
+                const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G1, 0x130, 0xF, 0xF, true);
+                defer1 = lane < 63u && G1 > G + 4u;
+                defer2 = lane < 62u && G2 > G + 7u;
+            } else {
+                const uint32_t tl = take ? cl : 0u; /* length if this position could start a match, else 0 */
+                /* the next three positions' values: whole-wave DPP shifts (wave_shl:1 = lane i reads lane i+1), three
+                 * VALU moves instead of three LDS permutes; what lane 63/62/61 read is masked by the edge rule below */
+                const uint32_t tl1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x130, 0xF, 0xF, true);
+                const uint32_t tl2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl1, 0x130, 0xF, 0xF, true);
+                const uint32_t tl3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl2, 0x130, 0xF, 0xF, true);
+                defer1 = pf.lazy >= 1u && lane < 63u && tl1 > cl;      /* next position: strictly longer */
+                defer2 = pf.lazy >= 2u && lane < 62u && tl2 > cl;      /* two on: strictly longer */
+                defer3 = pf.lazy >= 3u && lane < 61u && tl3 > cl + 2u; /* three on: longer by more than two */
+            }
             const bool start = take && !defer1 && !defer2 && !defer3;
             const u64 startMask = __ballot(start);
             /* what the parse wave needs, one word per position (see parse_tile) */
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             const u64 rest = endj < 64u ? startMask >> endj : 0ull;
             uint32_t nx = endj >= 64u ? endj : (rest ? endj + (uint32_t)__builtin_ctzll(rest) : 64u);
             nx = capped ? kNxCapped : nx;
-            pv[(it & 1u) * kPvStride + tid] = REP ? (ns | (cl << 7) | (off << 14)) : pack_pos(nx, ns, capped ? off : cl);
+            pv[(it & 1u) * kPvStride + tid] = REP ? ((cl << 7) | (off << 15)) : pack_pos(nx, ns, capped ? off : cl);
         }
         offA = off;
         lenA = cl;
@@ -1021,8 +1025,6 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
                              const qzstd_hip_block_t *d_blocks, uint32_t nBlocks, uint32_t maxBlockLen,
                              void *d_seqs, uint32_t *d_nseq, void *d_work, size_t workBytes)
 {
-    static thread_local int attrDevice = -1;
-    static thread_local size_t attrBytes = 0;
     LaunchArgs a;
     if (nBlocks == 0) return 0;
     if (!d_src || !d_blocks || !d_seqs || !d_nseq) return fail_msg("qzstd_hip_find_sequences: null pointer");
@@ -1030,36 +1032,48 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (qzstd_hip_profile_for_level(level, maxBlockLen, &a.prof))
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12 (optionally | QZSTD_HIP_LEVEL_REPCODES)");
     if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
-        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 8 || a.prof.chainDepth > 64 ||
-        (a.prof.subTileLog != 0u && a.prof.subTileLog != 6u) || (a.prof.chainDepth && a.prof.subTileLog != 6u))
+        a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 16 || a.prof.chainDepth > 64 ||
+        a.prof.lazy > 4 || (a.prof.subTileLog != 0u && a.prof.subTileLog != 6u) ||
+        (a.prof.chainDepth && (a.prof.subTileLog != 6u || a.prof.longSize || a.prof.nearTab)) || (a.prof.longSize && a.prof.subTileLog))
         return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");
     QZ_CHECK(hipSetDevice(device), "hipSetDevice");
     /* [long][rep][chain/turns: 0 none, 1 turns, 2 chain + turns] */
-    const void *variants[2][2][3] = {
+    static const void *const variants[2][2][3] = {
         { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, false>),
-            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, true>), nullptr },
+            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, true>),
+            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, true, true>) },
           { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, false>),
-            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, true>), nullptr } },
-        { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, false, false>), nullptr,
-            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, true, true>) },
-          { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, false, false>), nullptr,
-            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, true, true>) } } };
-    if (attrDevice != device || attrBytes < lds) {
-        for (int v = 0; v < 12; v++) {
-            const void *f = variants[v / 6][(v / 3) % 2][v % 3];
-            if (f) QZ_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, true>),
+            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, true, true>) } },
+        { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, false, false>), nullptr, nullptr },
+          { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, false, false>), nullptr, nullptr } } };
+    /* the LDS a variant may ask for is a per-function, per-device attribute (process-wide, not per thread): raise it
+     * once per device to the most any level needs and never lower it */
+    {
+        static std::mutex attrMu;
+        static bool attrDone[64];
+        std::lock_guard<std::mutex> g(attrMu);
+        if (device < 0 || device >= 64) return fail_msg("qzstd_hip_find_sequences: device index out of range");
+        if (!attrDone[device]) {
+            size_t most = 0;
+            for (int l = 1; l <= 12; l++) {
+                const size_t b = qzstd_hip_lds_bytes(l, QZSTD_HIP_BLOCK_MAX);
+                if (b > most) most = b;
+            }
+            for (int v = 0; v < 12; v++) {
+                const void *f = variants[v / 6][(v / 3) % 2][v % 3];
+                if (f) QZ_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most),
+                                "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            }
+            attrDone[device] = true;
         }
-        attrDevice = device;
-        attrBytes = lds;
     }
     a.chain = nullptr;
     a.chainStride = 0;
     if (a.prof.chainDepth) {
         const size_t need = qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen);
-        if (!a.prof.longSize) return fail_msg("qzstd_hip_find_sequences: unsupported profile (chains without the long table)");
         if (!d_work || workBytes < need) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
         a.chain = static_cast<uint32_t *>(d_work);
         a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint32_t));

@@ -27,28 +27,35 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     memset(out, 0, sizeof(*out));
     (void)blockSize; /* the profile does not depend on the block size: the LDS footprint is fixed (ring + tables) */
     /* levels 1-2: 6400 entries, no long table = 81.6 KB of LDS -> two blocks per CU;
-     * levels >= 3: 16000 entries + a second table keyed by 8 bytes (the double-fast idea of zstd's
-     * levels 3-4) = 152.8 KB -> one block per CU */
-    out->tableSize = level >= 3 ? 16000u : 6400u;
-    out->longSize = level >= 3 ? 8192u : 0u;
-    out->tileLog = 9;
-    out->capLen = 64;
-    out->minMatch = 4;
-    out->farLog1 = 12;
-    out->farLog2 = 16;
-    out->lazy = 3;
-    out->backExt = 4;
-    out->nearTab = 1;
-    out->window = 0;
-    out->hashBytes = 5;
-    out->extLog = 11;
-    /* libzstd turns repeat offsets of external sequences into repcodes only from level 10 (or when the
-     * caller sets ZSTD_c_searchForExternalRepcodes); without that, short repeat matches cost a full offset */
-    out->repWin = (repcodes || level >= 10) ? 8u : 0u;
-    /* levels >= 5 (zstd: greedy, then lazy with 8 attempts, lazy2, btlazy2): walk the hash chain */
-    out->chainDepth = level >= 9 ? 16u : (level >= 6 ? 8u : (level >= 5 ? 4u : 0u));
-    /* per-wave turns where the waves have the time (chains) and at level 2, which buys its better ratio with them */
-    out->subTileLog = (level >= 5 || level == 2) ? 6u : 0u;
+     * levels 3-4: 16000 entries + a second table keyed by 8 bytes (the double-fast idea of zstd's
+     * levels 3-4) = 152.8 KB -> one block per CU;
+     * levels >= 5: exact hash chains over a 4-byte hash (zstd: greedy / lazy / lazy2 / btlazy2); the size of the
+     * head table hardly matters there (a collision costs one chain step): 6400 again -> two blocks per CU */
+    {
+        const int chains = level >= 5;
+        out->tableSize = chains ? 6400u : (level >= 3 ? 16000u : 6400u);
+        out->longSize = (!chains && level >= 3) ? 8192u : 0u;
+        out->tileLog = 9;
+        out->capLen = level >= 9 ? 128u : 64u;
+        out->minMatch = 4;
+        out->farLog1 = 12;
+        out->farLog2 = 16;
+        out->lazy = chains ? 4u : 3u; /* 4 = the lazy rules compare gains (length and offset cost), not lengths */
+        out->backExt = 4;
+        out->nearTab = chains ? 0u : 1u;
+        out->window = 0;
+        out->hashBytes = chains ? 4u : 5u;
+        out->extLog = 11;
+        /* libzstd turns repeat offsets of external sequences into repcodes only from level 10 (or when the
+         * caller sets ZSTD_c_searchForExternalRepcodes); without that, short repeat matches cost a full offset */
+        out->repWin = (repcodes || level >= 10) ? 16u : 0u;
+        /* levels >= 5: links walked per position (software zstd: 2^searchLog = 4..128 attempts plus repcodes; the
+         * producer API gives no repcodes below level 10, which deeper chains make up for) */
+        out->chainDepth = level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u)));
+        /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
+         * level 2, which buys its better ratio with them */
+        out->subTileLog = (chains || level == 2) ? 6u : 0u;
+    }
     return 0;
 }
 
@@ -76,7 +83,7 @@ size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
     need = (size_t)QZ_RING_BYTES
            + 4u * p.tableSize        /* hash table                                    */
            + 4u * p.longSize         /* 8-byte-key table (levels >= 3)                */
-           + (4u << p.tileLog)     /* tile-local near table                         */
+           + (4u << p.tileLog)     /* tile-local near table / the current tile's chain links (levels >= 5) */
            + 2u * ((4u << p.tileLog) + 32u) /* per-position parse words (+ override spill), 2 tiles in flight */
            + 2u * ((1u << p.tileLog) >> 6) * 32u /* per-window emission records, x2 */
            + QZ_LDS_CTRL;

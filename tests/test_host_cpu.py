@@ -84,7 +84,7 @@ def test_workspace_only_for_chain_levels(plugin):
         assert W(level, 100, 131072) == 0 and plugin.profile(level, 131072).chainDepth == 0
         assert plugin.profile(level, 131072).subTileLog == (6 if level == 2 else 0)
     for level in range(5, 13):
-        assert plugin.profile(level, 131072).chainDepth in (4, 8, 16) and plugin.profile(level, 131072).subTileLog == 6
+        assert plugin.profile(level, 131072).chainDepth in (8, 16, 32, 64) and plugin.profile(level, 131072).subTileLog == 6
         assert W(level, 100, 131072) == 100 * 131072 * 4
         assert W(level, 3, 1000) == 3 * 1024 * 4
     assert W(6, 1, 131073) == 0 and W(0, 1, 1000) == 0
@@ -95,7 +95,7 @@ def test_repcode_aware_parse_follows_libzstd_default(plugin):
     caller has to ask for it (level | QZSTD_HIP_LEVEL_REPCODES, env QZSTD_HIP_EXT_REPCODES=1)"""
     for level in range(1, 13):
         assert (plugin.profile(level, 131072).repWin != 0) == (level >= 10)
-        assert plugin.profile(level | 0x100, 131072).repWin == 8
+        assert plugin.profile(level | 0x100, 131072).repWin == 16
 
 
 def test_profile_rejects_bad_levels(plugin, oracle):

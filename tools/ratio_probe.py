@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--ext-rep", type=int, default=None)
     a = ap.parse_args()
     z = B.Zstd()
-    orc = B.Oracle()
+    orc = B.Oracle(os.environ.get("QZ_ORACLE_SO", B.ORACLE_SO))
     per = int(a.mb * K.MiB)
     corp = {}
     for label, part in K.system_corpus_parts():
