@@ -359,7 +359,7 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
  * the equality bitmap of the next 64 bytes, and the match length at position cursor+k is the run of ones from bit k,
  * capped at kRepCap = 32.  The first position whose best option is not beaten by the next one (by more than 4
  * quarter bytes of gain) or the one after (by more than 11) is taken; a window without any option is skipped.
- * Per position the matchers leave   capped length (8 bits, << 7) | offset (17 bits, << 15).
+ * Per position the matchers leave   capped length (bits 0-7) | offset (bits 8-24); bit 31 stays clear (kChosenBit).
  * Every chosen match is written back over the parse words of its first three positions (behind the
  * cursor: dead) as {offset, length, index, literal anchor} for the emitting wave: no masks, no ranks.
  */
@@ -382,10 +382,9 @@ __device__ __forceinline__ uint32_t ring_byte(const Src &s, uint32_t x, bool far
 /* equality bitmap of the 64 bytes from `cur` against the bytes `rp` back (0 when rp == 0): bit b = byte cur+b matches */
 __device__ __forceinline__ u64 rep_bitmap(const Src &src, uint32_t cur, uint32_t rp, uint32_t n, uint32_t lane)
 {
-    if (rp == 0u) return 0ull; /* uniform */
     const uint32_t bpos = cur + lane;
     bool eq = false;
-    if (bpos < n) eq = ring_byte(src, bpos, false) == ring_byte(src, bpos - rp, rp > kNear);
+    if (rp != 0u && bpos < n) eq = ring_byte(src, bpos, false) == ring_byte(src, bpos - rp, rp > kNear);
     return __ballot(eq);
 }
 
@@ -404,13 +403,14 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
         const u64 M2 = rep_bitmap(src, st.cur, st.rep2, n, lane);
         uint32_t rl1 = 0, rl2 = 0;
         if (lane < V) {
-            const u64 z1 = ~(M1 >> lane), z2 = ~(M2 >> lane); /* lane < 18: 32 bits of look-ahead are always there; the shift feeds zeros */
-            rl1 = umin((uint32_t)__builtin_ctzll(z1), kRepCap);
-            rl2 = umin((uint32_t)__builtin_ctzll(z2), kRepCap);
+            /* bit kRepCap set: the run is counted up to the cap only (and ctz never sees 0) */
+            const u64 z1 = ~(M1 >> lane) | (1ull << kRepCap), z2 = ~(M2 >> lane) | (1ull << kRepCap);
+            rl1 = (uint32_t)__builtin_ctzll(z1);
+            rl2 = (uint32_t)__builtin_ctzll(z2);
         }
         const uint32_t rg1 = rl1 < kRepMin ? 0u : (rl1 >= kRepCap ? 1000u : 4u * rl1 + 36u);
         const uint32_t rg2 = rl2 < kRepMin ? 0u : (rl2 >= kRepCap ? 999u : 4u * rl2 + 35u);
-        const uint32_t cl = (wd >> 7) & 0xFFu, co = wd >> 15;
+        const uint32_t cl = wd & 0xFFu, co = wd >> 8;
         uint32_t G = 0, opt = 0;
         if (cl != 0u && cl >= min_len(pf, co)) G = 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(co + 1u));
         if (rg1 > G) { G = rg1; opt = 1u; }
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             const u64 rest = endj < 64u ? startMask >> endj : 0ull;
             uint32_t nx = endj >= 64u ? endj : (rest ? endj + (uint32_t)__builtin_ctzll(rest) : 64u);
             nx = capped ? kNxCapped : nx;
-            pv[(it & 1u) * kPvStride + tid] = REP ? ((cl << 7) | (off << 15)) : pack_pos(nx, ns, capped ? off : cl);
+            pv[(it & 1u) * kPvStride + tid] = REP ? (cl | (off << 8)) : pack_pos(nx, ns, capped ? off : cl);
         }
         offA = off;
         lenA = cl;

@@ -6,10 +6,15 @@ import numpy as np
 import qz_bind as B, qz_corpus as K
 
 def main():
-    plug, orc = B.Plugin(), B.Oracle()
+    plug, orc = B.Plugin(os.environ.get("QZ_PLUGIN_SO", B.PLUGIN_SO)), B.Oracle()
     level = int(os.environ.get("QZ_LEVEL", "1"), 0)  # e.g. 0x106 = level 6 | QZSTD_HIP_LEVEL_REPCODES
     sizes = [int(a) for a in sys.argv[1:]] or [600, 1500, 3000, 9000, 131072]
-    base = K.by_name(os.environ.get("QZ_CORPUS", "text"), 140000)
+    corpus = os.environ.get("QZ_CORPUS", "text")
+    off0 = int(os.environ.get("QZ_OFFSET", "0"))
+    if corpus == "records":
+        base = b"".join(b"record%05d;" % (i % 97) + bytes(53) for i in range(2000))
+    else:
+        base = K.by_name(corpus, off0 + 140000)[off0:]
     for n in sizes:
         blk = base[:n]
         counts, seqs, stride = plug.find_batch([blk], level)
@@ -18,7 +23,7 @@ def main():
         w = np.frombuffer(want, dtype=np.uint32).reshape(-1, 4)[:want_n, :3]
         m = min(len(g), len(w))
         diff = np.nonzero((g[:m] != w[:m]).any(axis=1))[0]
-        print("n=%d gpu_count=%d oracle_count=%d first_diff=%s" % (n, counts[0], want_n, diff[:1]))
+        print("n=%d gpu_count=%d oracle_count=%d first_diff=%s" % (n, counts[0], want_n, diff[:1]), flush=True)
         if len(diff):
             i = int(diff[0])
             pos_g = int(g[:i, 1].sum() + g[:i, 2].sum())
