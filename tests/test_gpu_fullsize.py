@@ -1,8 +1,8 @@
 """BASELINE config #2 at full size on the GPU (8192 x 128 KiB = 1 GiB resident in HBM, level 1): the sizes the
 oracle cannot walk in seconds are covered by size-independent properties, checked on the device with torch —
 every block's sequences add up to the block, every offset is in range, every match is a true copy (first and
-last 4 bytes of each of the ~53 M matches), the run is deterministic — plus exact parity with the oracle on a
-random sample of the blocks."""
+last 4 bytes of each of the ~53 M matches), the run is deterministic — plus parity with the oracle on ALL 8192 blocks
+(count + position-weighted checksum of every block's sequences; sequence for sequence on a random sample)."""
 import ctypes as C
 import random
 
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 NB, BLOCK = 8192, 131072
 
 
-def test_config2_full_size_properties_and_sampled_parity(gpu_plugin, oracle):
+def test_config2_full_size_properties_and_full_parity(gpu_plugin, oracle):
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
     L = gpu_plugin.lib
@@ -83,11 +83,38 @@ def test_config2_full_size_properties_and_sampled_parity(gpu_plugin, oracle):
     for i, want in zip((0, NB // 2, NB - 1), keep):
         assert np.array_equal(d_seqs[i, :len(want), :3].cpu().numpy(), want)
 
-    # exact parity with the oracle on a random sample of blocks
+    # exact parity with the oracle on ALL 8192 blocks: the oracle walks the whole GiB on the host cores (a thread
+    # pool over the .so: ctypes releases the GIL; ~20 core-seconds), the comparison is a position-weighted checksum
+    # per block, computed on the device for the GPU's sequences and with numpy for the oracle's, plus the counts ...
+    import concurrent.futures as cf
+    w3 = torch.tensor([1, 3, 7], device=dev, dtype=torch.int64)
+    gchk = torch.empty(NB, dtype=torch.int64, device=dev)
+    for b0 in range(0, NB, 256):
+        s = d_seqs[b0:b0 + 256, :, :3].to(torch.int64)
+        c = cnt[b0:b0 + 256]
+        idx = torch.arange(stride, device=dev, dtype=torch.int64).unsqueeze(0)
+        used = (idx < c.unsqueeze(1)).to(torch.int64)
+        gchk[b0:b0 + 256] = (((s * w3).sum(dim=2)) * (idx + 1) * used).sum(dim=1)
+    gchk = gchk.cpu().numpy()
+    gcnt = cnt.cpu().numpy()
+    prof = oracle.profile(1, BLOCK)
+
+    def walk(i):
+        n, want = oracle.find(prof, data[i * BLOCK:(i + 1) * BLOCK], cap=stride)
+        w = np.frombuffer(want, dtype=np.uint32).reshape(-1, 4)[:n, :3].astype(np.int64)
+        return i, n, int(((w * np.array([1, 3, 7])).sum(axis=1) * np.arange(1, n + 1)).sum())
+
+    import os
+    with cf.ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 8)) as ex:
+        for i, n, chk in ex.map(walk, range(NB)):
+            assert int(gcnt[i]) == n, "block %d: %d sequences, oracle %d" % (i, int(gcnt[i]), n)
+            assert int(gchk[i]) == chk, "block %d: checksum of the sequences differs from the oracle's" % i
+
+    # ... and sequence for sequence on a random sample
     rng = random.Random(20250928)
     for i in rng.sample(range(NB), 24):
         blk = data[i * BLOCK:(i + 1) * BLOCK]
-        n, want = oracle.find(oracle.profile(1, BLOCK), blk, cap=stride)
+        n, want = oracle.find(prof, blk, cap=stride)
         assert int(cnt[i]) == n, i
         w = np.frombuffer(want, dtype=np.uint32).reshape(-1, 4)[:n, :3].astype(np.int64)
         g = d_seqs[i, :n, :3].cpu().numpy().astype(np.int64)

@@ -126,17 +126,24 @@ def test_one_shot_multiblock_frame(started, zstd):
     assert zstd.decompress(frame, len(data)) == data
 
 
-@pytest.mark.parametrize("level", [1, 3])
-def test_ratio_within_2pct_of_software(started, zstd, level):
-    data = K.by_name("system", 64 * 131072)
+@pytest.mark.parametrize("level,chunk,corpus,size", [(1, 131072, "system", 64 * 131072), (3, 131072, "system", 64 * 131072),
+                                                     (6, 131072, "system", 48 * 131072), (6, 131072, "text", 32 * 131072),
+                                                     (9, 131072, "system", 24 * 131072),
+                                                     (12, 32768, "weblog", 96 * 32768), (12, 32768, "system", 96 * 32768)])
+def test_ratio_within_2pct_of_software(started, zstd, level, chunk, corpus, size):
+    """north star: compressed size within 2 % of libzstd's own match-finder at the same level, same framing (one frame
+    per chunk, reference test/benchmark.c:300-321), through the real callback path with libzstd's default parameters.
+    Level 6 on 128 KiB text blocks = BASELINE config 3, level 12 on 32 KiB web-log blocks = config 4."""
+    data = K.by_name(corpus, size, seed={"text": 3, "weblog": 4}.get(corpus, 1))
     st = started.lib.QZSTD_createSeqProdState()
-    got = compress_with(zstd, started.producer_addr, st, data, 131072, level, hint_lib=started.lib)
+    got = compress_with(zstd, started.producer_addr, st, data, chunk, level, hint_lib=started.lib)
     started.lib.QZSTD_freeSeqProdState(st)
+    assert b"".join(zstd.decompress(f, chunk) for f in got) == data
     zc = zstd.cctx(level)
-    sw, _ = zstd.compress_chunks(zc, data, 131072)
+    sw, _ = zstd.compress_chunks(zc, data, chunk)
     zstd.free(zc)
     ours = sum(len(f) for f in got)
-    assert ours <= sw * 1.02, "compressed %d vs software %d (%.2f %% worse)" % (ours, sw, 100.0 * (ours / sw - 1))
+    assert ours <= sw * 1.02, "level %d: compressed %d vs software %d (%.2f %% worse)" % (level, ours, sw, 100.0 * (ours / sw - 1))
 
 
 def test_guards_match_reference(started):
