@@ -94,18 +94,34 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState);
  * frame).  Returns 0 when the hint was accepted.
  *
  * The call is asynchronous: it copies at most 16 MiB into pinned memory, queues the
- * transfers and the launch, and returns.  A state holds two announcements, so a caller
- * announces segment k+1 and then compresses segment k.
+ * transfers and the launches, and returns.  A state holds two announcements, so a caller
+ * announces segment k+1 and then compresses segment k.  On a node with several GPUs the
+ * blocks of one announcement are split into contiguous ranges, one per GPU, each on its own
+ * stream; every kernel writes its results into the announcement's pinned host buffers
+ * (QZSTD_HIP_SPLIT=n limits the split to n GPUs, 1 keeps it on the state's own GPU).
+ *
+ * Contract: the announced bytes should not change until their callbacks have come.  The
+ * plugin does not rely on it — every callback served from an announcement is compared with
+ * the staged copy first (memcmp); if the buffer was rewritten the announcement is dropped
+ * and the block is match-found afresh — so breaking the contract costs time, never
+ * correctness.  An announcement the caller walks away from is dropped after 16 misses.
  * ------------------------------------------------------------------------------------ */
 int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize,
                      size_t blockSize, int compressionLevel);
 
-/* Transparent look-ahead (no API): a state whose caller announces nothing guesses, after a callback that had
+/* Transparent look-ahead (no API, OPT-IN): with the environment variable QZSTD_HIP_LOOKAHEAD=1 (or 2: always through a
+ * pipe) set before QZSTD_startQatDevice(), a state whose caller announces nothing guesses, after a callback that had
  * to wait for the GPU, that the bytes BEHIND that callback's block are the next blocks.  It reads them with a
- * fault-safe copy (process_vm_readv on itself, or write/read through a pipe; unreadable memory ends the copy), match-finds them ahead of time, and
- * serves a later callback from the guess only if its address sits on the guessed grid and its bytes still equal the
- * copy.  It therefore READS (never writes) process memory behind the block a callback names; set the environment
- * variable QZSTD_HIP_LOOKAHEAD=0 before QZSTD_startQatDevice() to forbid that. */
+ * fault-safe copy (process_vm_readv on itself, or write/read through a close-on-exec pipe; unreadable memory ends the
+ * copy) — never past the end of the memory mapping that holds the block the callback named — match-finds them ahead of
+ * time, and serves a later callback from the guess only if its address sits on the guessed grid and its bytes still
+ * equal the copy.  It therefore READS (never writes) process memory the caller did not hand over, which is why it is
+ * off unless asked for; the first guess is logged at debug level 1, and staged copies are zeroed before their pinned
+ * pages are released.  Default (unset or 0): the library touches nothing but [src, src + srcSize) of each callback. */
+
+/* Time-out (reference: 2 s of polling, src/qatseqprod.c:1099-1104): a request that is still running after
+ * QZSTD_HIP_TIMEOUT_MS (default 2000) returns ZSTD_SEQUENCE_PRODUCER_ERROR, so that ZSTD_c_enableSeqProducerFallback
+ * takes over; the stream involved is not used again before it has drained. */
 
 /* Diagnostics for the above: stats[0] = blocks served from an announcement, [1] = blocks that took
  * the per-block path, [2] = announcements accepted, [3] = microseconds spent waiting for the GPU. */

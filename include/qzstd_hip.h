@@ -84,7 +84,8 @@ size_t qzstd_hip_sequence_bound(size_t srcSize);
 size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen);
 
 /* ---- device / memory / stream plumbing ---- */
-int qzstd_hip_device_count(void); /* number of usable gfx950-class devices, <0 on error */
+int qzstd_hip_device_count(void); /* number of usable devices (gfx950: the only code object in the library), <0 on error;
+                                   * devices are indexed 0..count-1 in that filtered order */
 int qzstd_hip_device_name(int device, char *buf, size_t bufLen);
 void *qzstd_hip_malloc(int device, size_t bytes);
 void qzstd_hip_free(int device, void *dptr);
@@ -97,6 +98,9 @@ void *qzstd_hip_stream_create(int device);
 void qzstd_hip_stream_destroy(int device, void *stream);
 int qzstd_hip_stream_sync(int device, void *stream);
 int qzstd_hip_stream_query(int device, void *stream); /* 0 done, 1 still running, <0 error */
+/* bounded wait (the reference polls icp_sal_DcPollInstance for at most 2 s, src/qatseqprod.c:1099-1104,:1261-1272):
+ * 0 = everything queued on the stream is done, 1 = still running after timeoutMs, <0 error */
+int qzstd_hip_stream_wait(int device, void *stream, unsigned timeoutMs);
 int qzstd_hip_memcpy_h2d(int device, void *stream, void *dst, const void *src, size_t bytes);
 int qzstd_hip_memcpy_d2h(int device, void *stream, void *dst, const void *src, size_t bytes);
 int qzstd_hip_memset(int device, void *stream, void *dst, int value, size_t bytes);

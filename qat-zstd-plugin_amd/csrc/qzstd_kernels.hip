@@ -49,6 +49,8 @@
 #include <string.h>
 
 #include <mutex>
+#include <sched.h>
+#include <time.h>
 
 #include "qzstd_hip.h"
 
@@ -907,18 +909,52 @@ extern "C" {
 
 const char *qzstd_hip_last_error(void) { return g_err; }
 
-int qzstd_hip_device_count(void)
+/* The library carries one code object (gfx950).  Only devices that can run it are counted, and the `device` argument
+ * of every entry point indexes that filtered list (reference: instance discovery keeps only usable DC instances,
+ * /root/reference/src/qatseqprod.c:529-600). */
+static std::once_flag g_devOnce;
+static int g_devCount = -1;
+static int g_devMap[64];
+
+static void probe_devices()
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) { fail("hipGetDeviceCount", e); (void)hipGetLastError(); return -1; }
-    return n;
+    if (e != hipSuccess) { fail("hipGetDeviceCount", e); (void)hipGetLastError(); g_devCount = -1; return; }
+    g_devCount = 0;
+    for (int d = 0; d < n && g_devCount < 64; d++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) continue; /* no code object for it */
+        g_devMap[g_devCount++] = d;
+    }
+    if (g_devCount == 0) fail_msg("no gfx950 device among the visible HIP devices");
+}
+
+static inline int phys(int device)
+{
+    std::call_once(g_devOnce, probe_devices);
+    return device >= 0 && device < g_devCount ? g_devMap[device] : -1;
+}
+
+#define QZ_SET_DEVICE(device)                                            \
+    do {                                                                 \
+        const int pd_ = phys(device);                                    \
+        if (pd_ < 0) return fail_msg("device index out of range");       \
+        QZ_CHECK(hipSetDevice(pd_), "hipSetDevice");                     \
+    } while (0)
+
+int qzstd_hip_device_count(void)
+{
+    std::call_once(g_devOnce, probe_devices);
+    return g_devCount;
 }
 
 int qzstd_hip_device_name(int device, char *buf, size_t bufLen)
 {
     hipDeviceProp_t prop;
-    QZ_CHECK(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (phys(device) < 0) return fail_msg("device index out of range");
+    QZ_CHECK(hipGetDeviceProperties(&prop, phys(device)), "hipGetDeviceProperties");
     if (buf && bufLen) snprintf(buf, bufLen, "%s (%s, %d CUs, %zu KiB LDS/WG)", prop.name, prop.gcnArchName,
                                 prop.multiProcessorCount, prop.sharedMemPerBlock >> 10);
     return 0;
@@ -927,7 +963,7 @@ int qzstd_hip_device_name(int device, char *buf, size_t bufLen)
 void *qzstd_hip_malloc(int device, size_t bytes)
 {
     void *p = nullptr;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    if (phys(device) < 0 || hipSetDevice(phys(device)) != hipSuccess) return nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) { fail("hipMalloc", e); return nullptr; }
     return p;
@@ -936,7 +972,7 @@ void *qzstd_hip_malloc(int device, size_t bytes)
 void qzstd_hip_free(int device, void *dptr)
 {
     if (!dptr) return;
-    if (hipSetDevice(device) == hipSuccess) (void)hipFree(dptr);
+    if (phys(device) >= 0 && hipSetDevice(phys(device)) == hipSuccess) (void)hipFree(dptr);
 }
 
 void *qzstd_hip_host_alloc(size_t bytes)
@@ -964,7 +1000,7 @@ void qzstd_hip_host_free(void *hptr)
 void *qzstd_hip_stream_create(int device)
 {
     hipStream_t s = nullptr;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    if (phys(device) < 0 || hipSetDevice(phys(device)) != hipSuccess) return nullptr;
     hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     if (e != hipSuccess) { fail("hipStreamCreate", e); return nullptr; }
     return (void *)s;
@@ -972,42 +1008,65 @@ void *qzstd_hip_stream_create(int device)
 
 void qzstd_hip_stream_destroy(int device, void *stream)
 {
-    if (stream && hipSetDevice(device) == hipSuccess) (void)hipStreamDestroy((hipStream_t)stream);
+    if (stream && phys(device) >= 0 && hipSetDevice(phys(device)) == hipSuccess) (void)hipStreamDestroy((hipStream_t)stream);
 }
 
 int qzstd_hip_stream_sync(int device, void *stream)
 {
-    QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    QZ_SET_DEVICE(device);
     QZ_CHECK(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
     return 0;
 }
 
 int qzstd_hip_stream_query(int device, void *stream)
 {
-    QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    QZ_SET_DEVICE(device);
     hipError_t e = hipStreamQuery((hipStream_t)stream);
     if (e == hipSuccess) return 0;
     if (e == hipErrorNotReady) return 1;
     return fail("hipStreamQuery", e);
 }
 
+int qzstd_hip_stream_wait(int device, void *stream, unsigned timeoutMs)
+{
+    QZ_SET_DEVICE(device);
+    /* poll instead of hipStreamSynchronize: a wedged kernel must not take the calling thread with it.  Busy polls for
+     * the first 200 us (the latency of a small request), then yields, then naps */
+    struct timespec t0, t;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        const hipError_t e = hipStreamQuery((hipStream_t)stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail("hipStreamQuery", e);
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        const long long us = (long long)(t.tv_sec - t0.tv_sec) * 1000000ll + (t.tv_nsec - t0.tv_nsec) / 1000;
+        if (us >= (long long)timeoutMs * 1000ll) {
+            snprintf(g_err, sizeof(g_err), "stream still busy after %u ms", timeoutMs);
+            return 1;
+        }
+        if (us < 200) continue;
+        if (us < 5000) sched_yield();
+        else { const struct timespec nap = { 0, 100000 }; nanosleep(&nap, nullptr); }
+    }
+}
+
 int qzstd_hip_memcpy_h2d(int device, void *stream, void *dst, const void *src, size_t bytes)
 {
-    QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    QZ_SET_DEVICE(device);
     QZ_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync H2D");
     return 0;
 }
 
 int qzstd_hip_memcpy_d2h(int device, void *stream, void *dst, const void *src, size_t bytes)
 {
-    QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    QZ_SET_DEVICE(device);
     QZ_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync D2H");
     return 0;
 }
 
 int qzstd_hip_memset(int device, void *stream, void *dst, int value, size_t bytes)
 {
-    QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    QZ_SET_DEVICE(device);
     QZ_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream), "hipMemsetAsync");
     return 0;
 }
@@ -1015,7 +1074,7 @@ int qzstd_hip_memset(int device, void *stream, void *dst, int value, size_t byte
 int qzstd_hip_memcpy2d_d2h(int device, void *stream, void *dst, size_t dpitch, const void *src, size_t spitch,
                            size_t width, size_t height)
 {
-    QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    QZ_SET_DEVICE(device);
     QZ_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, (hipStream_t)stream),
              "hipMemcpy2DAsync D2H");
     return 0;
@@ -1038,7 +1097,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");
-    QZ_CHECK(hipSetDevice(device), "hipSetDevice");
+    QZ_SET_DEVICE(device);
     /* [long][rep][chain/turns: 0 none, 1 turns, 2 chain + turns] */
     static const void *const variants[2][2][3] = {
         { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, false>),
@@ -1055,7 +1114,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         static std::mutex attrMu;
         static bool attrDone[64];
         std::lock_guard<std::mutex> g(attrMu);
-        if (device < 0 || device >= 64) return fail_msg("qzstd_hip_find_sequences: device index out of range");
+        if (phys(device) < 0) return fail_msg("qzstd_hip_find_sequences: device index out of range");
         if (!attrDone[device]) {
             size_t most = 0;
             for (int l = 1; l <= 12; l++) {

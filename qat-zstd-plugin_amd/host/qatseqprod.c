@@ -9,14 +9,16 @@
  *   ---------------------------------------------  -----------------------------------------
  *   QZSTD_startQatDevice   :948-964                runtime probe + slot table, under a mutex
  *   instance discovery + round-robin shuffle       slots interleaved across GPUs so that
- *     :529-663                                       consecutive slots sit on different devices
+ *     :529-663                                       consecutive slots sit on different devices;
+ *                                                    an announced buffer is split across the GPUs
  *   QZSTD_grabInstance / releaseInstance :905-933  test-and-set sweep starting at the hint (hint path,
  *                                                    QZSTD_HIP_COALESCE=0); by default callers are
- *                                                    merged into one launch per tick per GPU (coalescer)
+ *                                                    merged into batches, several in flight per GPU
  *   QZSTD_allocInstMem (lazy)  :685-822            pinned + device buffers, created on first use
  *   input staging memcpy       :1222-1227          memcpy into the pinned staging buffer
- *   cpaDcCompressData2 + poll  :1243-1272          H2D, kernel launch, D2H on the slot's stream,
- *                                                    stream sync
+ *   cpaDcCompressData2 + poll  :1243-1272          H2D, kernel launch on a stream, bounded wait
+ *   poll time-out              :1099-1104,:1261-72 QZSTD_HIP_TIMEOUT_MS (default 2000): error -> libzstd's
+ *                                                    fallback; the stream is quarantined until it drains
  *   QZSTD_decLz4s              :1013-1091          (none: the kernel emits ZSTD_Sequence)
  *   result / capacity checks   :1293-1322          count == NSEQ_ERROR or >= cap-1 -> ERROR
  *   device-down counter, retry every 1000 blocks   same (failOffloadCnt)
@@ -25,17 +27,18 @@
  * No QAT / icp_sal / cpa symbol is used or emulated.
  */
 #ifndef _GNU_SOURCE
-#define _GNU_SOURCE /* process_vm_readv: the fault-safe read behind the transparent look-ahead */
+#define _GNU_SOURCE /* process_vm_readv, pipe2, F_GETPIPE_SZ: the fault-safe read behind the opt-in transparent look-ahead */
 #endif
 #include "qatseqprod.h"
 #include "qzstd_hip.h"
 
+#include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <fcntl.h>
 #include <sys/prctl.h>
 #include <sys/types.h>
 #include <sys/uio.h>
@@ -54,6 +57,7 @@
 #define QZ_MAX_SLOTS 1024
 #define QZ_DEFAULT_SLOTS_PER_DEVICE 128
 #define QZ_FIRST_COPY_SEQS 16384u /* sequences fetched together with the count */
+#define QZ_DEFAULT_TIMEOUT_MS 2000 /* reference: 2 s of polling, src/qatseqprod.c:1099-1104 */
 
 static int qzLogLevel = DEBUGLEVEL; /* 0 silent, 1 errors, 2 events, 3 every sequence */
 #define QZ_LOG(l, ...)                                       \
@@ -63,11 +67,12 @@ static int qzLogLevel = DEBUGLEVEL; /* 0 silent, 1 errors, 2 events, 3 every seq
         }                                                    \
     } while (0)
 
-/* One slot = one in-flight block on one GPU (the analogue of a QAT DC instance). */
+/* One slot = one stream with its staging and device buffers on one GPU (the analogue of a QAT DC instance). */
 typedef struct {
     int device;
     volatile int lock;
     int ready; /* buffers + stream exist */
+    int stuck; /* a wait on the stream timed out: not reusable until the stream drains */
     void *stream;
     unsigned char *hSrc; /* pinned staging, QZSTD_HIP_BLOCK_MAX + pad */
     unsigned char *dSrc;
@@ -78,53 +83,58 @@ typedef struct {
     unsigned int *hCount; /* pinned */
     unsigned int *dCount;
     size_t seqCap;
-    /* grow-only buffers of the batched (hinted) path */
+    /* grow-only buffers of the batched (announced) path */
     unsigned char *dBatchSrc; size_t dBatchSrcCap;
-    /* launch scratch (hash chains of levels >= 6), grow-only: one block / a hinted batch */
+    /* launch scratch (hash chains of levels >= 5), grow-only: one block / an announced batch */
     void *dWork; size_t dWorkCap;
     void *dBatchWork; size_t dBatchWorkCap;
 } QZSTD_Slot_T;
 
 /*
- * Cross-thread request coalescing (one per GPU).  The producer API hands over ONE block per
- * call and waits, and a single block keeps one of 256 CUs busy for ~0.7 ms; many callers
- * (one CCtx per thread, the reference's own scaling model: README.md:138) are therefore merged
- * into one launch per tick: the first caller to find the device idle becomes the leader of the
- * open batch and runs it; callers arriving while it runs pile up in the other batch, whose first
- * member leads it when the device frees up ("group commit": no timers, no added latency for a
- * lone caller).  Every caller copies its own block into the batch's pinned staging area and its
- * own result out of it, so those copies run in parallel on the callers' threads.
+ * Cross-thread request coalescing (one per GPU).  The producer API hands over ONE block per call and waits, and a
+ * single block keeps one of 256 CUs busy; many callers (one CCtx per thread, the reference's own scaling model:
+ * README.md:138, many DC instances per device: src/qatseqprod.c:905-928) are therefore merged into batches.  A GPU has
+ * QZ_BATCHES batches, each with its own stream and staging, so several launches are in flight at once: a caller that
+ * finds no batch collecting opens an idle one and leads it — it stages its block, closes the batch and launches, so a
+ * lone caller never waits for anybody; callers that arrive while a leader is staging join its batch; when every batch
+ * is busy, newcomers wait for the first one to come back and then pile into it together ("group commit": no timers).
+ * Every caller copies its own block into the batch's pinned staging area and its own result out of it, so those
+ * copies run in parallel on the callers' threads.  Levels may be mixed: one launch per level present in a batch.
  */
-#define QZ_BATCH_MAX 64
+#define QZ_BATCH_MAX 128
+#define QZ_BATCHES 4
+#define QZ_BATCH_PITCH ((size_t)16384) /* sequences per block in the batch's result area; denser blocks are redone alone */
 typedef struct {
     const void *src;
     size_t srcSize, cap, rc;
+    int level;
 } QZSTD_Req_T;
 
 typedef struct {
-    int state; /* 0 open (collecting), 1 running, 2 done (results being copied out) */
-    int n, copied, consumed, level;
+    int state; /* 0 idle or collecting, 1 closed (running), 2 done (results being copied out) */
+    int n, copied, consumed;
+    int ready, stuck;
     QZSTD_Req_T req[QZ_BATCH_MAX];
     unsigned char *hSrc;      /* pinned, QZ_BATCH_MAX x QZ_SRC_STRIDE */
-    ZSTD_Sequence *hSeqs;     /* pinned, QZ_BATCH_MAX x seqStride */
+    unsigned char *dSrc;      /* device, same size */
+    ZSTD_Sequence *hSeqs;     /* pinned, QZ_BATCH_MAX x QZ_BATCH_PITCH */
     qzstd_hip_block_t *hDesc; /* pinned */
     unsigned int *hCount;     /* pinned */
     void *dvSeqs, *dvDesc, *dvCount; /* device-side addresses of hSeqs / hDesc / hCount */
-    pthread_cond_t cvLead;    /* the batch's leader (its first member) waits here: device idle / members staged */
+    void *stream;
+    void *dWork; /* launch scratch, grow-only */
+    size_t dWorkCap;
+    pthread_cond_t cvLead;    /* the batch's leader (its first member) waits here for the members to finish staging */
     pthread_cond_t cvDone;    /* the other members wait here for the results */
 } QZSTD_Batch_T;
 
 typedef struct {
-    int device, ready, running, open; /* open = index of the batch that accepts requests */
+    int device;
+    int open; /* index of the batch that is collecting, -1 = none */
     pthread_mutex_t mu;
-    pthread_cond_t cvOpen; /* callers that found no batch to join wait here */
-    QZSTD_Batch_T batch[2];
-    void *stream;
-    unsigned char *dSrc;
-    void *dWork; /* launch scratch, grow-only */
-    size_t dWorkCap;
-    size_t seqStride;
-    unsigned long launches, blocks;
+    pthread_cond_t cvOpen; /* callers that found every batch busy wait here */
+    QZSTD_Batch_T batch[QZ_BATCHES];
+    unsigned long launches, blocks, batches;
 } QZSTD_Coalescer_T;
 #define QZ_SRC_STRIDE ((size_t)QZSTD_HIP_BLOCK_MAX + 64)
 
@@ -136,19 +146,33 @@ typedef struct {
     QZSTD_Coalescer_T *coal; /* one per device */
     int coalesce;            /* QZSTD_HIP_COALESCE (default 1) */
     int levelFlags;          /* QZSTD_HIP_LEVEL_REPCODES when QZSTD_HIP_EXT_REPCODES=1 */
-    int lookahead;           /* transparent look-ahead: 0 off, 1 fault-safe read by process_vm_readv, 2 through a pipe */
+    int lookahead;           /* transparent look-ahead (opt-in): 0 off, 1 fault-safe read by process_vm_readv, 2 through a pipe */
+    int lookaheadLogged;
+    int timeoutMs;           /* QZSTD_HIP_TIMEOUT_MS */
+    int split;               /* QZSTD_HIP_SPLIT: announced buffers are split across this many GPUs (default: all) */
     pthread_mutex_t mutex;
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, PTHREAD_MUTEX_INITIALIZER };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, PTHREAD_MUTEX_INITIALIZER };
 
-/* One announced buffer: staged in pinned memory, match-found asynchronously on a slot's stream,
- * results (count + the first QZ_HINT_PITCH sequences of every block) copied back asynchronously. */
+/* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
+ * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
+ * the kernels straight into the announcement's pinned host buffers. */
 #define QZ_HINT_MAX_BYTES ((size_t)16 << 20)
 #define QZ_HINT_PITCH ((size_t)16384) /* blocks with more sequences take the per-block path */
+#define QZ_HINT_PARTS 8
 typedef struct {
-    int st;   /* 0 empty, 1 in flight on the GPU (slot held), 2 ready */
+    int st;   /* 0 none, 1 in flight on the GPU (slot held), 2 ready, 3 failed */
     int slot; /* index of the slot held while in flight */
+    size_t b0, b1; /* block range [b0, b1) of the announcement */
+} QZSTD_Part_T;
+
+typedef struct {
+    int st;   /* 0 empty, 1 announced (parts in flight or ready) */
+    int touched; /* a callback was served from it */
+    unsigned misses; /* callbacks that found nothing to serve since the announcement was last used */
+    int nParts;
+    QZSTD_Part_T part[QZ_HINT_PARTS];
     const unsigned char *base;
     size_t size, block, nb;
     int level;
@@ -156,7 +180,7 @@ typedef struct {
     ZSTD_Sequence *hSeqs;     /* pinned, nb x QZ_HINT_PITCH */
     unsigned int *hCount;     /* pinned */
     qzstd_hip_block_t *hDesc; /* pinned */
-    void *dvSeqs, *dvCount, *dvDesc; /* device-side addresses of the three: the kernel uses them directly */
+    void *dvSeqs, *dvCount, *dvDesc; /* device-side addresses of the three: the kernels use them directly */
     size_t hSrcCap, hSeqsCap, hCountCap, hDescCap; /* bytes */
 } QZSTD_Hint_T;
 
@@ -166,11 +190,13 @@ typedef struct {
     unsigned int failOffloadCnt;
     /* look-ahead batches served to later callbacks (QZSTD_hintSource): two, so that the GPU can
      * work on the next buffer while libzstd entropy-codes the current one on this thread */
-    QZSTD_Hint_T hint[4]; /* [0..1] announced by the caller, [2..3] speculative (transparent look-ahead) */
+    QZSTD_Hint_T hint[4]; /* [0..1] announced by the caller, [2..3] speculative (transparent look-ahead, opt-in) */
     int hintNext, autoNext;
     unsigned autoDepth, autoBackoff, autoFails; /* blocks to speculate on, callbacks to sit out, misses in a row */
     int autoOutstanding;                        /* a guess was launched and nothing has been served from it yet */
     int pipeFd[2];                              /* the fault-safe read's pipe (mode 2), -1 = not opened */
+    size_t pipeChunk;
+    uintptr_t mapLo, mapHi;                     /* the caller's mapping the last guess was confined to */
     unsigned long autoLaunched, autoServed;
     unsigned long servedFromBatch, servedSync;
     unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs; /* event log only */
@@ -178,20 +204,51 @@ typedef struct {
 
 #define QZ_AUTO_DEPTH_MIN 2u  /* transparent look-ahead: blocks guessed ahead, doubling while guesses are consumed */
 #define QZ_AUTO_DEPTH_MAX 32u
+#define QZ_HINT_STALE_MISSES 16u /* an announcement that was used and then missed this often is dropped */
 static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block);
 static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t blockSize, int compressionLevel);
-
+static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need);
 
 const char *QZSTD_version(void)
 {
     return QZSTD_VERSION;
 }
 
+static unsigned long qzNowNs(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (unsigned long)ts.tv_sec * 1000000000ul + (unsigned long)ts.tv_nsec;
+}
+
+/* Bounded wait for a stream (reference: the polling loop with its 2 s limit, src/qatseqprod.c:1261-1285).
+ * 0 = everything queued on the stream is done, 1 = timed out (the work is still running: the caller must not touch
+ * the buffers involved and marks their owner as stuck), -1 = the runtime reported an error. */
+static int qzWait(int dev, void *stream)
+{
+    const int r = qzstd_hip_stream_wait(dev, stream, (unsigned)gProc.timeoutMs);
+    if (r == 1) QZ_LOG(1, "device %d: request timed out after %d ms\n", dev, gProc.timeoutMs);
+    if (r < 0) QZ_LOG(1, "device %d: %s\n", dev, qzstd_hip_last_error());
+    return r;
+}
+
+/* A stream that timed out is quarantined; it becomes usable again once a non-blocking query finds it drained. */
+static int qzStillStuck(int dev, void *stream, int *stuck)
+{
+    if (!*stuck) return 0;
+    if (qzstd_hip_stream_query(dev, stream) == 0) {
+        *stuck = 0;
+        QZ_LOG(1, "device %d: a timed-out stream has drained, back in service\n", dev);
+        return 0;
+    }
+    return 1;
+}
+
 /* ---------------------------------------------------------------- slots ---------- */
 
 static void qzFreeSlot(QZSTD_Slot_T *s)
 {
-    if (s->stream) (void)qzstd_hip_stream_sync(s->device, s->stream);
+    if (s->stream) (void)qzstd_hip_stream_wait(s->device, s->stream, (unsigned)gProc.timeoutMs);
     qzstd_hip_host_free(s->hSrc);
     qzstd_hip_host_free(s->hSeqs);
     qzstd_hip_host_free(s->hDesc);
@@ -211,12 +268,19 @@ static void qzFreeSlot(QZSTD_Slot_T *s)
     }
 }
 
-/* lazy per-slot setup, first use only (reference: QZSTD_allocInstMem, :685-822) */
-static int qzSetupSlot(QZSTD_Slot_T *s)
+/* lazy per-slot setup, first use only (reference: QZSTD_allocInstMem, :685-822); `full` also creates the buffers of the
+ * one-block path (an announced batch only needs the stream and the grow-only batch buffers) */
+static int qzSetupSlot(QZSTD_Slot_T *s, int full)
 {
-    if (s->ready) return QZSTD_OK;
+    if (!s->stream) {
+        s->stream = qzstd_hip_stream_create(s->device);
+        if (!s->stream) {
+            QZ_LOG(1, "slot setup failed on device %d: %s\n", s->device, qzstd_hip_last_error());
+            return QZSTD_FAIL;
+        }
+    }
+    if (!full || s->ready) return QZSTD_OK;
     s->seqCap = qzstd_hip_sequence_bound(QZSTD_HIP_BLOCK_MAX);
-    s->stream = qzstd_hip_stream_create(s->device);
     s->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZSTD_HIP_BLOCK_MAX + 64);
     s->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(s->seqCap * sizeof(ZSTD_Sequence));
     s->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(sizeof(qzstd_hip_block_t));
@@ -225,8 +289,7 @@ static int qzSetupSlot(QZSTD_Slot_T *s)
     s->dSeqs = (ZSTD_Sequence *)qzstd_hip_malloc(s->device, s->seqCap * sizeof(ZSTD_Sequence));
     s->dDesc = (qzstd_hip_block_t *)qzstd_hip_malloc(s->device, sizeof(qzstd_hip_block_t));
     s->dCount = (unsigned int *)qzstd_hip_malloc(s->device, 64);
-    if (!s->stream || !s->hSrc || !s->hSeqs || !s->hDesc || !s->hCount || !s->dSrc || !s->dSeqs ||
-        !s->dDesc || !s->dCount) {
+    if (!s->hSrc || !s->hSeqs || !s->hDesc || !s->hCount || !s->dSrc || !s->dSeqs || !s->dDesc || !s->dCount) {
         QZ_LOG(1, "slot setup failed on device %d: %s\n", s->device, qzstd_hip_last_error());
         qzFreeSlot(s);
         return QZSTD_FAIL;
@@ -235,22 +298,33 @@ static int qzSetupSlot(QZSTD_Slot_T *s)
     return QZSTD_OK;
 }
 
-/* test-and-set sweep over the slots, starting at the caller's sticky hint
- * (reference: QZSTD_grabInstance, :905-928) */
-static int qzGrabSlot(int hint)
+/* one quick sweep over the slots (no waiting), starting at the caller's sticky hint; dev >= 0 confines it to the slots of
+ * that GPU (slot i sits on device i % numDevices) */
+static int qzTryGrabSlot(int hint, int dev)
 {
-    int sweep, k;
-    const int n = gProc.numSlots;
+    int k;
+    const int n = gProc.numSlots, nd = gProc.numDevices;
     if (n <= 0) return -1;
     if (hint < 0 || hint >= n) hint = 0;
+    if (dev >= 0) hint = hint - hint % nd + dev; /* same row, that device's column */
+    for (k = 0; k < n; k += dev >= 0 ? nd : 1) {
+        const int i = (hint + k) % n;
+        if (__sync_lock_test_and_set(&gProc.slots[i].lock, 1) == 0) return i;
+    }
+    return -1;
+}
+
+/* test-and-set sweep over the slots, starting at the caller's sticky hint
+ * (reference: QZSTD_grabInstance, :905-928) */
+static int qzGrabSlot(int hint, int dev)
+{
+    int sweep;
     /* The reference sweeps its instances 10 times and then fails the block (src/qatseqprod.c:905-928, :915);
      * here a caller WAITS for a slot: short spins first, then 50 us naps, giving up only after about two seconds
      * (the reference's own time-out for a stuck request, :1261-1285) */
     for (sweep = 0; sweep < QZ_GRAB_SWEEPS; sweep++) {
-        for (k = 0; k < n; k++) {
-            const int i = (hint + k) % n;
-            if (__sync_lock_test_and_set(&gProc.slots[i].lock, 1) == 0) return i;
-        }
+        const int i = qzTryGrabSlot(hint, dev);
+        if (i >= 0 || gProc.numSlots <= 0) return i;
         if (sweep < 64) {
             sched_yield(); /* every slot busy: more threads than slots; let the holders finish */
         } else {
@@ -268,119 +342,156 @@ static void qzReleaseSlot(int i)
 
 /* ---------------------------------------------------------------- coalescer ------ */
 
+static void qzFreeBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
+{
+    if (bt->stream) (void)qzstd_hip_stream_wait(c->device, bt->stream, (unsigned)gProc.timeoutMs);
+    qzstd_hip_host_free(bt->hSrc);
+    qzstd_hip_host_free(bt->hSeqs);
+    qzstd_hip_host_free(bt->hDesc);
+    qzstd_hip_host_free(bt->hCount);
+    qzstd_hip_free(c->device, bt->dSrc);
+    qzstd_hip_free(c->device, bt->dWork);
+    if (bt->stream) qzstd_hip_stream_destroy(c->device, bt->stream);
+    bt->hSrc = NULL; bt->hSeqs = NULL; bt->hDesc = NULL; bt->hCount = NULL; bt->dSrc = NULL; bt->dWork = NULL;
+    bt->dWorkCap = 0; bt->stream = NULL; bt->dvSeqs = bt->dvDesc = bt->dvCount = NULL;
+    bt->ready = 0;
+}
+
 static void qzFreeCoalescer(QZSTD_Coalescer_T *c)
 {
     int b;
-    if (c->stream) (void)qzstd_hip_stream_sync(c->device, c->stream);
-    for (b = 0; b < 2; b++) {
-        qzstd_hip_host_free(c->batch[b].hSrc);
-        qzstd_hip_host_free(c->batch[b].hSeqs);
-        qzstd_hip_host_free(c->batch[b].hDesc);
-        qzstd_hip_host_free(c->batch[b].hCount);
-    }
-    qzstd_hip_free(c->device, c->dSrc);
-    qzstd_hip_free(c->device, c->dWork);
-    if (c->stream) qzstd_hip_stream_destroy(c->device, c->stream);
-    QZ_LOG(2, "device %d: %lu block(s) in %lu coalesced launch(es)\n", c->device, c->blocks, c->launches);
+    for (b = 0; b < QZ_BATCHES; b++) qzFreeBatch(c, &c->batch[b]);
+    QZ_LOG(2, "device %d: %lu block(s) in %lu batch(es), %lu launch(es)\n", c->device, c->blocks, c->batches, c->launches);
     pthread_mutex_destroy(&c->mu);
     pthread_cond_destroy(&c->cvOpen);
-    for (b = 0; b < 2; b++) {
+    for (b = 0; b < QZ_BATCHES; b++) {
         pthread_cond_destroy(&c->batch[b].cvLead);
         pthread_cond_destroy(&c->batch[b].cvDone);
     }
 }
 
-/* lazy, under c->mu */
-static int qzSetupCoalescer(QZSTD_Coalescer_T *c)
+/* lazy, per batch, under c->mu; a failure frees what was created (nothing leaks when pinned memory is short) */
+static int qzSetupBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
 {
-    int b, ok = 1;
-    if (c->ready) return QZSTD_OK;
-    c->seqStride = qzstd_hip_sequence_bound(QZSTD_HIP_BLOCK_MAX);
-    c->stream = qzstd_hip_stream_create(c->device);
-    c->dSrc = (unsigned char *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * QZ_SRC_STRIDE);
-    ok = c->stream && c->dSrc;
-    for (b = 0; b < 2 && ok; b++) {
-        QZSTD_Batch_T *bt = &c->batch[b];
-        bt->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SRC_STRIDE);
-        bt->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(QZ_BATCH_MAX * c->seqStride * sizeof(ZSTD_Sequence));
-        bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(qzstd_hip_block_t));
-        bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(unsigned int));
-        bt->dvSeqs = qzstd_hip_host_device_ptr(bt->hSeqs);
-        bt->dvDesc = qzstd_hip_host_device_ptr(bt->hDesc);
-        bt->dvCount = qzstd_hip_host_device_ptr(bt->hCount);
-        ok = bt->hSrc && bt->hSeqs && bt->hDesc && bt->hCount && bt->dvSeqs && bt->dvDesc && bt->dvCount;
-    }
-    if (!ok) {
-        QZ_LOG(1, "coalescer setup failed on device %d: %s\n", c->device, qzstd_hip_last_error());
+    if (bt->ready) return QZSTD_OK;
+    bt->stream = qzstd_hip_stream_create(c->device);
+    bt->dSrc = (unsigned char *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * QZ_SRC_STRIDE);
+    bt->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SRC_STRIDE);
+    bt->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_BATCH_PITCH * sizeof(ZSTD_Sequence));
+    bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(qzstd_hip_block_t));
+    bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(unsigned int));
+    bt->dvSeqs = qzstd_hip_host_device_ptr(bt->hSeqs);
+    bt->dvDesc = qzstd_hip_host_device_ptr(bt->hDesc);
+    bt->dvCount = qzstd_hip_host_device_ptr(bt->hCount);
+    if (!(bt->stream && bt->dSrc && bt->hSrc && bt->hSeqs && bt->hDesc && bt->hCount && bt->dvSeqs && bt->dvDesc && bt->dvCount)) {
+        QZ_LOG(1, "batch setup failed on device %d: %s\n", c->device, qzstd_hip_last_error());
+        qzFreeBatch(c, bt);
         return QZSTD_FAIL;
     }
-    c->ready = 1;
+    bt->ready = 1;
     return QZSTD_OK;
 }
 
-static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need);
-
-/* the leader's job: one launch for the whole batch (called WITHOUT c->mu held) */
+/* the leader's job: one launch per level present in the batch (called WITHOUT c->mu held) */
 static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
 {
     const int n = bt->n, dev = c->device;
-    unsigned int maxLen = 0;
-    int i, failed = 0;
+    int order[QZ_BATCH_MAX];
+    int i, j, g0, failed = 0, launches = 0;
+    /* requests grouped by level (insertion sort, stable: the usual batch has one level) */
     for (i = 0; i < n; i++) {
-        bt->hDesc[i].srcOff = (size_t)i * QZ_SRC_STRIDE;
-        bt->hDesc[i].seqOff = (size_t)i * c->seqStride;
-        bt->hDesc[i].srcLen = (unsigned int)bt->req[i].srcSize;
-        bt->hDesc[i].seqCap = (unsigned int)(bt->req[i].cap < c->seqStride ? bt->req[i].cap : c->seqStride);
-        if (bt->hDesc[i].srcLen > maxLen) maxLen = bt->hDesc[i].srcLen;
+        for (j = i; j > 0 && bt->req[order[j - 1]].level > bt->req[i].level; j--) order[j] = order[j - 1];
+        order[j] = i;
     }
-    {
-        const size_t work = qzstd_hip_workspace_bytes(bt->level, (unsigned int)n, maxLen);
-        if (work) c->dWork = qzGrowDev(dev, c->dWork, &c->dWorkCap, work);
-        failed = work && !c->dWork;
+    for (j = 0; j < n; j++) {
+        const QZSTD_Req_T *r = &bt->req[order[j]];
+        bt->hDesc[j].srcOff = (size_t)order[j] * QZ_SRC_STRIDE;
+        bt->hDesc[j].seqOff = (size_t)order[j] * QZ_BATCH_PITCH;
+        bt->hDesc[j].srcLen = (unsigned int)r->srcSize;
+        bt->hDesc[j].seqCap = (unsigned int)(r->cap < QZ_BATCH_PITCH ? r->cap : QZ_BATCH_PITCH);
     }
-    /* one copy in, one launch, one wait: the kernel reads the descriptors from and writes the sequences and
+    /* one copy in, one launch per level, one wait: the kernel reads the descriptors from and writes the sequences and
      * counts to this batch's pinned host buffers directly (posted PCIe writes while it runs), which takes two
      * copies and one synchronisation off the latency of a request */
-    failed = failed || qzstd_hip_memcpy_h2d(dev, c->stream, c->dSrc, bt->hSrc, (size_t)n * QZ_SRC_STRIDE) ||
-             qzstd_hip_find_sequences(dev, c->stream, bt->level, c->dSrc, (const qzstd_hip_block_t *)bt->dvDesc,
-                                      (unsigned int)n, maxLen, bt->dvSeqs, (unsigned int *)bt->dvCount, c->dWork,
-                                      c->dWorkCap) ||
-             qzstd_hip_stream_sync(dev, c->stream);
-    for (i = 0; i < n; i++) {
-        const size_t cnt = failed ? QZSTD_HIP_NSEQ_ERROR : bt->hCount[i];
+    failed = qzstd_hip_memcpy_h2d(dev, bt->stream, bt->dSrc, bt->hSrc, (size_t)n * QZ_SRC_STRIDE);
+    for (g0 = 0; g0 < n && !failed; ) {
+        const int level = bt->req[order[g0]].level;
+        unsigned int maxLen = 0;
+        int g1 = g0;
+        size_t work;
+        while (g1 < n && bt->req[order[g1]].level == level) {
+            if (bt->hDesc[g1].srcLen > maxLen) maxLen = bt->hDesc[g1].srcLen;
+            g1++;
+        }
+        work = qzstd_hip_workspace_bytes(level, (unsigned int)(g1 - g0), maxLen);
+        if (work > bt->dWorkCap && launches) failed = qzWait(dev, bt->stream) != 0; /* the scratch is about to be replaced */
+        if (work && !failed) bt->dWork = qzGrowDev(dev, bt->dWork, &bt->dWorkCap, work);
+        failed = failed || (work && !bt->dWork) ||
+                 qzstd_hip_find_sequences(dev, bt->stream, level, bt->dSrc, (const qzstd_hip_block_t *)bt->dvDesc + g0,
+                                          (unsigned int)(g1 - g0), maxLen, bt->dvSeqs, (unsigned int *)bt->dvCount + g0,
+                                          bt->dWork, bt->dWorkCap);
+        launches++;
+        g0 = g1;
+    }
+    if (!failed) {
+        const int w = qzWait(dev, bt->stream);
+        if (w == 1) bt->stuck = 1; /* the kernel may still write into this batch's buffers: quarantined */
+        failed = w != 0;
+    }
+    for (j = 0; j < n; j++) {
+        QZSTD_Req_T *r = &bt->req[order[j]];
+        const size_t cnt = failed ? QZSTD_HIP_NSEQ_ERROR : bt->hCount[j];
         /* capacity rule, reference :1318-1322 */
-        bt->req[i].rc = (cnt == QZSTD_HIP_NSEQ_ERROR || cnt == 0 || cnt >= bt->req[i].cap - 1) ? ZSTD_SEQUENCE_PRODUCER_ERROR : cnt;
+        r->rc = (cnt == QZSTD_HIP_NSEQ_ERROR || cnt == 0 || cnt >= r->cap - 1) ? ZSTD_SEQUENCE_PRODUCER_ERROR : cnt;
     }
     if (failed) QZ_LOG(1, "device request failed: %s\n", qzstd_hip_last_error());
-    c->launches++;
+    c->launches += (unsigned long)launches;
+    c->batches++;
     c->blocks += (unsigned long)n;
 }
 
+static size_t qzSlotBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
+                          size_t srcSize, int level);
+
 /* one block through the coalescer of device `dev`; returns the sequence count or the error code */
-static size_t qzCoalescedBlock(int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
+static size_t qzCoalescedBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
                                size_t srcSize, int level)
 {
     QZSTD_Coalescer_T *c = &gProc.coal[dev];
-    QZSTD_Batch_T *bt;
+    QZSTD_Batch_T *bt = NULL;
     size_t rc;
-    int i;
+    int i, b, dense;
 
     pthread_mutex_lock(&c->mu);
-    if (qzSetupCoalescer(c) != QZSTD_OK) {
-        pthread_mutex_unlock(&c->mu);
-        return ZSTD_SEQUENCE_PRODUCER_ERROR;
-    }
-    for (;;) { /* join the open batch (same level only) */
-        bt = &c->batch[c->open];
-        if (bt->state == 0 && bt->n < QZ_BATCH_MAX && (bt->n == 0 || bt->level == level)) break;
+    for (;;) {
+        int usable = 0;
+        if (c->open >= 0 && c->batch[c->open].state == 0 && c->batch[c->open].n < QZ_BATCH_MAX) { /* join the collecting batch */
+            bt = &c->batch[c->open];
+            break;
+        }
+        if (c->open < 0) { /* nobody is collecting: open an idle batch and lead it */
+            for (b = 0; b < QZ_BATCHES && !bt; b++) {
+                QZSTD_Batch_T *cand = &c->batch[b];
+                if (cand->state != 0 || cand->n != 0) { usable++; continue; } /* busy, but it will come back */
+                if (qzStillStuck(dev, cand->stream, &cand->stuck)) continue;
+                if (qzSetupBatch(c, cand) != QZSTD_OK) continue;
+                bt = cand;
+                c->open = b;
+            }
+            if (bt) break;
+            if (!usable) { /* every batch is stuck or cannot be set up: fail the block (libzstd's fallback takes over) */
+                pthread_mutex_unlock(&c->mu);
+                return ZSTD_SEQUENCE_PRODUCER_ERROR;
+            }
+        }
         pthread_cond_wait(&c->cvOpen, &c->mu);
     }
     i = bt->n++;
-    bt->level = level;
     bt->req[i].src = src;
     bt->req[i].srcSize = srcSize;
     bt->req[i].cap = outSeqsCapacity;
     bt->req[i].rc = ZSTD_SEQUENCE_PRODUCER_ERROR;
+    bt->req[i].level = level;
     pthread_mutex_unlock(&c->mu);
 
     memcpy(bt->hSrc + (size_t)i * QZ_SRC_STRIDE, src, srcSize); /* staging copy (reference :1223), on the caller's thread */
@@ -388,22 +499,17 @@ static size_t qzCoalescedBlock(int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCa
     pthread_mutex_lock(&c->mu);
     bt->copied++;
     if (i == 0) {
-        /* the first member leads its batch: it keeps collecting while the device works on the other batch,
-         * then closes it and launches.  Every waiter has its own condition variable (no thundering herd
-         * when more threads than cores wait here). */
-        while (c->running) pthread_cond_wait(&bt->cvLead, &c->mu);
-        c->running = 1;
+        /* the first member leads its batch: whoever arrived while it was staging has joined; close and launch.
+         * Every waiter has its own condition variable (no thundering herd when more threads than cores wait here). */
         bt->state = 1;
-        c->open ^= 1; /* newcomers now collect in the other batch (once its results are handed out) */
+        c->open = -1; /* newcomers open another batch, or wait for one to come back */
         pthread_cond_broadcast(&c->cvOpen);
         while (bt->copied < bt->n) pthread_cond_wait(&bt->cvLead, &c->mu); /* members still staging */
         pthread_mutex_unlock(&c->mu);
         qzRunBatch(c, bt);
         pthread_mutex_lock(&c->mu);
         bt->state = 2;
-        c->running = 0;
         pthread_cond_broadcast(&bt->cvDone);
-        pthread_cond_signal(&c->batch[c->open].cvLead); /* the other batch's leader may go now */
     } else {
         if (bt->state == 1 && bt->copied == bt->n) pthread_cond_signal(&bt->cvLead);
         while (bt->state != 2) pthread_cond_wait(&bt->cvDone, &c->mu);
@@ -412,15 +518,19 @@ static size_t qzCoalescedBlock(int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCa
 
     rc = bt->req[i].rc;
     if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR)
-        memcpy(outSeqs, bt->hSeqs + (size_t)i * c->seqStride, rc * sizeof(ZSTD_Sequence));
+        memcpy(outSeqs, bt->hSeqs + (size_t)i * QZ_BATCH_PITCH, rc * sizeof(ZSTD_Sequence));
+    dense = rc == ZSTD_SEQUENCE_PRODUCER_ERROR && outSeqsCapacity > QZ_BATCH_PITCH && !bt->stuck;
 
     pthread_mutex_lock(&c->mu);
-    if (++bt->consumed == bt->n) { /* last one out re-opens the batch */
+    if (++bt->consumed == bt->n) { /* last one out hands the batch back */
         bt->n = bt->copied = bt->consumed = 0;
         bt->state = 0;
         pthread_cond_broadcast(&c->cvOpen);
     }
     pthread_mutex_unlock(&c->mu);
+    /* a block with more sequences than the batch's result pitch holds (incompressible-looking data with many
+     * short matches) is redone alone with the caller's full capacity */
+    if (dense) rc = qzSlotBlock(s, dev, outSeqs, outSeqsCapacity, src, srcSize, level);
     return rc;
 }
 
@@ -443,7 +553,7 @@ static int qzEnvInt(const char *name, int dflt, int lo, int hi)
 static int qzBuildSlots(void)
 {
     int nDev = qzstd_hip_device_count();
-    int perDev, i, maxDev;
+    int perDev, i, b, maxDev;
     if (nDev <= 0) return QZSTD_FAIL;
     maxDev = qzEnvInt("QZSTD_HIP_MAX_DEVICES", QZ_MAX_DEVICES, 1, QZ_MAX_DEVICES);
     if (nDev > maxDev) nDev = maxDev;
@@ -454,16 +564,18 @@ static int qzBuildSlots(void)
     gProc.numSlots = nDev * perDev;
     for (i = 0; i < gProc.numSlots; i++) gProc.slots[i].device = i % nDev;
     gProc.coalesce = qzEnvInt("QZSTD_HIP_COALESCE", 1, 0, 1);
+    gProc.split = qzEnvInt("QZSTD_HIP_SPLIT", nDev < QZ_HINT_PARTS ? nDev : QZ_HINT_PARTS, 1, nDev < QZ_HINT_PARTS ? nDev : QZ_HINT_PARTS);
     gProc.coal = (QZSTD_Coalescer_T *)calloc((size_t)nDev, sizeof(QZSTD_Coalescer_T));
     if (!gProc.coal) return QZSTD_FAIL;
     for (i = 0; i < nDev; i++) {
         gProc.coal[i].device = i;
+        gProc.coal[i].open = -1;
         pthread_mutex_init(&gProc.coal[i].mu, NULL);
         pthread_cond_init(&gProc.coal[i].cvOpen, NULL);
-        pthread_cond_init(&gProc.coal[i].batch[0].cvLead, NULL);
-        pthread_cond_init(&gProc.coal[i].batch[0].cvDone, NULL);
-        pthread_cond_init(&gProc.coal[i].batch[1].cvLead, NULL);
-        pthread_cond_init(&gProc.coal[i].batch[1].cvDone, NULL);
+        for (b = 0; b < QZ_BATCHES; b++) {
+            pthread_cond_init(&gProc.coal[i].batch[b].cvLead, NULL);
+            pthread_cond_init(&gProc.coal[i].batch[b].cvDone, NULL);
+        }
     }
     return QZSTD_OK;
 }
@@ -479,12 +591,14 @@ int QZSTD_startQatDevice(void)
         /* the caller promises ZSTD_c_searchForExternalRepcodes = enable on its CCtx (libzstd's default only
          * from level 10): repeat-offset aware sequences at every level */
         gProc.levelFlags = (rep && atoi(rep) > 0) ? QZSTD_HIP_LEVEL_REPCODES : 0;
+        gProc.timeoutMs = qzEnvInt("QZSTD_HIP_TIMEOUT_MS", QZ_DEFAULT_TIMEOUT_MS, 1, 600000);
         {
-            /* transparent look-ahead needs a fault-safe read.  QZSTD_HIP_LOOKAHEAD: 0 off, 1 (default) on, 2 on and
-             * always through a pipe.  process_vm_readv is only tried where no seccomp filter could make an unusual
-             * system call fatal, and only kept if a probe on ourselves works */
+            /* The transparent look-ahead READS memory behind the block a callback names, so it is strictly opt-in:
+             * QZSTD_HIP_LOOKAHEAD = 0 / unset: off; 1: on; 2: on and always through a pipe.  It needs a fault-safe read:
+             * process_vm_readv is only tried where no seccomp filter could make an unusual system call fatal, and only
+             * kept if a probe on ourselves works; otherwise the pipe. */
             char probe[16] = "qzstd", back[16];
-            const int want = qzEnvInt("QZSTD_HIP_LOOKAHEAD", 1, 0, 2);
+            const int want = qzEnvInt("QZSTD_HIP_LOOKAHEAD", 0, 0, 2);
             gProc.lookahead = want;
             if (want == 1 && (prctl(PR_GET_SECCOMP, 0, 0, 0, 0) != 0 || qzSafeRead(back, probe, 16, 16) != 16 ||
                               memcmp(back, probe, 16) != 0))
@@ -494,7 +608,7 @@ int QZSTD_startQatDevice(void)
     if (gProc.status == QZSTD_FAIL) {
         /* runtime up? (reference: QZSTD_salUserStart, :498-527) */
         gProc.status = qzstd_hip_device_count() > 0 ? QZSTD_STARTED : QZSTD_FAIL;
-        if (gProc.status == QZSTD_FAIL) QZ_LOG(2, "no HIP device: %s\n", qzstd_hip_last_error());
+        if (gProc.status == QZSTD_FAIL) QZ_LOG(2, "no usable HIP device: %s\n", qzstd_hip_last_error());
     }
     if (gProc.status == QZSTD_STARTED) {
         gProc.status = qzBuildSlots() == QZSTD_OK ? QZSTD_OK : QZSTD_STARTED;
@@ -534,28 +648,31 @@ void *QZSTD_createSeqProdState(void)
     return s;
 }
 
-static void qzReleaseSlot(int i);
-
-static unsigned long qzNowNs(void)
+/* wait for one part of an announcement and give its slot back; the part becomes ready (2) or failed (3) */
+static void qzPartFinish(QZSTD_Part_T *pt)
 {
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (unsigned long)ts.tv_sec * 1000000000ul + (unsigned long)ts.tv_nsec;
+    if (pt->st != 1) return;
+    if (gProc.slots && pt->slot >= 0 && pt->slot < gProc.numSlots) {
+        QZSTD_Slot_T *sl = &gProc.slots[pt->slot];
+        const int w = qzWait(sl->device, sl->stream);
+        if (w == 1) sl->stuck = 1; /* the slot is given back, but nobody uses it before its stream has drained */
+        qzReleaseSlot(pt->slot);
+        pt->st = w == 0 ? 2 : 3;
+        if (w != 0) QZ_LOG(1, "look-ahead batch failed: %s\n", qzstd_hip_last_error());
+    } else {
+        pt->st = 3;
+    }
 }
 
-/* wait for an in-flight hint and give its slot back; the hint becomes ready (or empty on failure) */
-static void qzHintFinish(QZSTD_Hint_T *h)
+/* drop an announcement: wait for what is still in flight (its buffers are about to be reused or freed) */
+static void qzHintDrop(QZSTD_Hint_T *h)
 {
-    if (h->st != 1) return;
-    if (gProc.slots && h->slot >= 0 && h->slot < gProc.numSlots) {
-        QZSTD_Slot_T *sl = &gProc.slots[h->slot];
-        const int bad = qzstd_hip_stream_sync(sl->device, sl->stream);
-        qzReleaseSlot(h->slot);
-        h->st = bad ? 0 : 2;
-        if (bad) QZ_LOG(1, "look-ahead batch failed: %s\n", qzstd_hip_last_error());
-    } else {
-        h->st = 0;
-    }
+    int k;
+    for (k = 0; k < h->nParts; k++) qzPartFinish(&h->part[k]);
+    h->nParts = 0;
+    h->st = 0;
+    h->touched = 0;
+    h->misses = 0;
 }
 
 void QZSTD_freeSeqProdState(void *sequenceProducerState)
@@ -568,7 +685,10 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
            s->servedFromBatch, s->autoServed, s->autoLaunched, s->servedSync, s->hintCalls, s->hintStageNs / 1e6,
            s->hintQueueNs / 1e6, s->hintWaitNs / 1e6);
     for (k = 0; k < 4; k++) {
-        qzHintFinish(&s->hint[k]);
+        qzHintDrop(&s->hint[k]);
+        /* the staged copies are the caller's data (for a guess: bytes it never handed over): scrubbed before the
+         * pinned pages go back to the allocator */
+        if (s->hint[k].hSrc) memset(s->hint[k].hSrc, 0, s->hint[k].hSrcCap);
         qzstd_hip_host_free(s->hint[k].hSrc);
         qzstd_hip_host_free(s->hint[k].hSeqs);
         qzstd_hip_host_free(s->hint[k].hCount);
@@ -597,12 +717,13 @@ static int qzDeviceUsable(QZSTD_Session_T *s)
     return 0;
 }
 
-/* one block, synchronously, on slot i */
+/* one block, synchronously, on a slot */
 static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
                          size_t srcSize, int level)
 {
     const size_t cap = outSeqsCapacity < sl->seqCap ? outSeqsCapacity : sl->seqCap;
     size_t first, count;
+    int w;
     memcpy(sl->hSrc, src, srcSize); /* staging copy, reference :1223 */
     sl->hDesc->srcOff = 0;
     sl->hDesc->seqOff = 0;
@@ -620,9 +741,11 @@ static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeq
         goto fail;
     first = cap < QZ_FIRST_COPY_SEQS ? cap : QZ_FIRST_COPY_SEQS;
     if (qzstd_hip_memcpy_d2h(sl->device, sl->stream, sl->hCount, sl->dCount, sizeof(unsigned int)) ||
-        qzstd_hip_memcpy_d2h(sl->device, sl->stream, sl->hSeqs, sl->dSeqs, first * sizeof(ZSTD_Sequence)) ||
-        qzstd_hip_stream_sync(sl->device, sl->stream))
+        qzstd_hip_memcpy_d2h(sl->device, sl->stream, sl->hSeqs, sl->dSeqs, first * sizeof(ZSTD_Sequence)))
         goto fail;
+    w = qzWait(sl->device, sl->stream);
+    if (w == 1) sl->stuck = 1;
+    if (w != 0) goto fail;
     count = *sl->hCount;
     if (count == QZSTD_HIP_NSEQ_ERROR || count == 0 || count >= outSeqsCapacity - 1) {
         QZ_LOG(1, "sequence count %zu does not fit capacity %zu\n", count, outSeqsCapacity);
@@ -630,9 +753,11 @@ static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeq
     }
     if (count > first) {
         if (qzstd_hip_memcpy_d2h(sl->device, sl->stream, sl->hSeqs + first, sl->dSeqs + first,
-                                 (count - first) * sizeof(ZSTD_Sequence)) ||
-            qzstd_hip_stream_sync(sl->device, sl->stream))
+                                 (count - first) * sizeof(ZSTD_Sequence)))
             goto fail;
+        w = qzWait(sl->device, sl->stream);
+        if (w == 1) sl->stuck = 1;
+        if (w != 0) goto fail;
     }
     memcpy(outSeqs, sl->hSeqs, count * sizeof(ZSTD_Sequence));
     return count;
@@ -641,13 +766,39 @@ fail:
     return ZSTD_SEQUENCE_PRODUCER_ERROR;
 }
 
+/* one block on a slot of its own (QZSTD_HIP_COALESCE=0, and blocks too dense for a batch) */
+static size_t qzSlotBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
+                          size_t srcSize, int level)
+{
+    size_t rc = ZSTD_SEQUENCE_PRODUCER_ERROR;
+    int tries;
+    for (tries = 0; tries < 4; tries++) {
+        const int i = qzGrabSlot(s->slotHint + tries * gProc.numDevices, dev);
+        QZSTD_Slot_T *sl;
+        if (i < 0) {
+            QZ_LOG(1, "failed to grab a slot\n");
+            return ZSTD_SEQUENCE_PRODUCER_ERROR;
+        }
+        sl = &gProc.slots[i];
+        if (sl->stream && qzStillStuck(sl->device, sl->stream, &sl->stuck)) { /* quarantined: try the next one */
+            qzReleaseSlot(i);
+            continue;
+        }
+        if (dev < 0) s->slotHint = i;
+        if (qzSetupSlot(sl, 1) == QZSTD_OK) rc = qzRunBlock(sl, outSeqs, outSeqsCapacity, src, srcSize, level);
+        QZ_LOG(2, "block %zu B level %d -> %zu sequences (slot %d, device %d)\n", srcSize, level & 0xFF, rc, i, sl->device);
+        qzReleaseSlot(i);
+        return rc;
+    }
+    return rc;
+}
+
 size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity,
                            const void *src, size_t srcSize, const void *dict, size_t dictSize,
                            int compressionLevel, size_t windowSize)
 {
     QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
     size_t rc = ZSTD_SEQUENCE_PRODUCER_ERROR;
-    int i;
 
     /* guards, reference :1123-1137 */
     if (windowSize < (srcSize < 32 * 1024 ? srcSize : 32 * 1024) || dictSize > 0 || dict) {
@@ -664,14 +815,19 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     /* look-ahead batch hit?  (src, srcSize) must start on an announced (k < 2) or guessed (k >= 2) block grid and
      * cover one or more whole blocks of it: libzstd 1.5.7 cuts multi-block frames into blocks of 32..128 KiB at 32 KiB
      * steps, so a finer grid serves several sizes — independently parsed neighbours are simply concatenated, the trailing literals of
-     * one block flowing into the first sequence of the next */
+     * one block flowing into the first sequence of the next.  In every case the bytes of the callback must still
+     * equal the staged copy the sequences were computed from (the caller may have reused or changed the buffer
+     * since the announcement): one memcmp per callback, a mismatch drops the announcement. */
     {
-        int k, guessMissed = 0;
+        int k, guessMissed = 0, announced = 0;
         for (k = 0; k < 4; k++) {
             QZSTD_Hint_T *h = &s->hint[k];
             const unsigned char *p = (const unsigned char *)src;
             size_t rel, b, e, covered = 0;
-            if (h->st == 0 || h->level != compressionLevel || p < h->base || p + srcSize > h->base + h->size) continue;
+            int pi, ok = 1;
+            if (h->st == 0) continue;
+            if (k < 2) announced = 1;
+            if (h->level != compressionLevel || p < h->base || p + srcSize > h->base + h->size) continue;
             rel = (size_t)(p - h->base);
             b = rel / h->block;
             if (rel % h->block != 0 || b >= h->nb) continue;
@@ -682,22 +838,33 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 QZ_LOG(3, "look-ahead %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
                 continue;
             }
-            if (k >= 2 && memcmp(h->hSrc + rel, src, srcSize) != 0) { /* the guess was read before these bytes were final */
-                guessMissed = 1;
+            if (memcmp(h->hSrc + rel, src, srcSize) != 0) {
+                /* a guess that was read before these bytes were final, or an announced buffer that was rewritten */
+                if (k >= 2) guessMissed = 1;
+                else {
+                    QZ_LOG(2, "announcement %d: the buffer changed after it was announced; dropped\n", k);
+                    qzHintDrop(h);
+                }
                 continue;
             }
-            if (h->st == 1) { /* first use: wait for the GPU (usually long done) */
-                const unsigned long w0 = qzNowNs();
-                qzHintFinish(h);
-                s->hintWaitNs += qzNowNs() - w0;
+            /* the parts that hold these blocks: wait for them (usually long done) */
+            for (pi = 0; pi < h->nParts; pi++) {
+                QZSTD_Part_T *pt = &h->part[pi];
+                if (pt->b1 <= b || pt->b0 >= e) continue;
+                if (pt->st == 1) {
+                    const unsigned long w0 = qzNowNs();
+                    qzPartFinish(pt);
+                    s->hintWaitNs += qzNowNs() - w0;
+                }
+                if (pt->st != 2) ok = 0;
             }
-            if (h->st == 2) {
+            if (ok) {
                 const int last = rel + srcSize >= h->size;
                 size_t total = 1, carry = 0, out = 0, bi;
                 int usable = 1;
                 for (bi = b; bi < e; bi++) {
                     const size_t count = h->hCount[bi];
-                    if (count == QZSTD_HIP_NSEQ_ERROR || count == 0 || count > QZ_HINT_PITCH) usable = 0;
+                    if (count == QZSTD_HIP_NSEQ_ERROR || count == 0 || count > QZ_HINT_PITCH) { usable = 0; break; }
                     total += count - 1;
                 }
                 if (usable && total < outSeqsCapacity - 1) {
@@ -718,6 +885,8 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                     outSeqs[out].rep = 0;
                     out++;
                     s->servedFromBatch++;
+                    h->touched = 1;
+                    h->misses = 0;
                     if (k >= 2) {
                         s->autoServed++;
                         s->autoFails = 0;
@@ -733,54 +902,53 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                             }
                         }
                     }
-                    if (last) h->st = 0; /* last block consumed */
+                    if (last) qzHintDrop(h); /* last block consumed */
                     return out;
                 }
-                if (last) h->st = 0;
+                if (last) qzHintDrop(h);
             }
             break; /* announced but unusable (too many sequences, failed launch): per-block path */
         }
+        /* nothing to serve from.  Announcements the caller has walked away from (used, then missed again and again)
+         * are dropped, so that they neither serve stale positions nor keep the state from guessing */
+        for (k = 0; k < 2; k++) {
+            QZSTD_Hint_T *h = &s->hint[k];
+            if (h->st != 0 && h->touched && ++h->misses > QZ_HINT_STALE_MISSES) {
+                QZ_LOG(2, "announcement %d: abandoned by the caller; dropped\n", k);
+                qzHintDrop(h);
+            }
+        }
+        announced = s->hint[0].st != 0 || s->hint[1].st != 0;
         QZ_LOG(3, "miss: %p + %zu (guesses: %d %p+%zu, %d %p+%zu) outstanding %d backoff %u depth %u\n", src, srcSize, s->hint[2].st,
                (const void *)s->hint[2].base, s->hint[2].size, s->hint[3].st, (const void *)s->hint[3].base, s->hint[3].size,
                s->autoOutstanding, s->autoBackoff, s->autoDepth);
-        /* nothing to serve from.  Unannounced caller: guess that the bytes after this block come next */
-        if (s->hint[0].st == 0 && s->hint[1].st == 0) {
+        /* Unannounced caller with the transparent look-ahead switched on: guess that the bytes after this block come next */
+        if (!announced && gProc.lookahead) {
             if (guessMissed || s->autoOutstanding) { /* the last guess was wrong: back off exponentially, start small again */
                 s->autoOutstanding = 0;
                 s->autoFails++;
                 s->autoBackoff = s->autoFails < 8 ? (1u << (s->autoFails - 1)) - 1u : 255u;
                 s->autoDepth = QZ_AUTO_DEPTH_MIN;
-                for (k = 2; k < 4; k++)
-                    if (s->hint[k].st == 2) s->hint[k].st = 0;
+                for (k = 2; k < 4; k++) qzHintDrop(&s->hint[k]);
             }
             qzSpeculate(s, (const unsigned char *)src + srcSize, srcSize, compressionLevel);
         }
     }
 
-    if (gProc.coalesce) {
+    {
         /* sticky device per state, states spread round-robin over the GPUs */
         static volatile unsigned int nextDev = 0;
         if (s->slotHint < 0) s->slotHint = (int)(__sync_fetch_and_add(&nextDev, 1u) & 0x3FFFFFFFu);
-        rc = qzCoalescedBlock(s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize,
+    }
+    if (gProc.coalesce) {
+        rc = qzCoalescedBlock(s, s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize,
                               compressionLevel | gProc.levelFlags);
-        if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
         QZ_LOG(2, "block %zu B level %d -> %zu sequences (coalesced, device %d)\n", srcSize, compressionLevel, rc,
                s->slotHint % gProc.numDevices);
-        return rc;
+    } else {
+        rc = qzSlotBlock(s, -1, outSeqs, outSeqsCapacity, src, srcSize, compressionLevel | gProc.levelFlags);
     }
-    i = qzGrabSlot(s->slotHint);
-    if (i < 0) {
-        QZ_LOG(1, "failed to grab a slot\n");
-        return ZSTD_SEQUENCE_PRODUCER_ERROR;
-    }
-    s->slotHint = i;
-    if (qzSetupSlot(&gProc.slots[i]) == QZSTD_OK) {
-        rc = qzRunBlock(&gProc.slots[i], outSeqs, outSeqsCapacity, src, srcSize, compressionLevel | gProc.levelFlags);
-        if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
-    }
-    QZ_LOG(2, "block %zu B level %d -> %zu sequences (slot %d, device %d)\n", srcSize, compressionLevel, rc, i,
-           gProc.slots[i].device);
-    qzReleaseSlot(i);
+    if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
     return rc;
 }
 
@@ -791,6 +959,7 @@ static void *qzGrowHost(void *old, size_t *cap, size_t need)
 {
     void *p;
     if (old && *cap >= need) return old;
+    if (old) memset(old, 0, *cap); /* staged caller data: scrubbed before the pages go back */
     qzstd_hip_host_free(old);
     p = qzstd_hip_host_alloc(need);
     *cap = p ? need : 0;
@@ -805,20 +974,6 @@ static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need)
     p = qzstd_hip_malloc(dev, need);
     *cap = p ? need : 0;
     return p;
-}
-
-/* one quick sweep over the slots (no waiting) */
-static int qzTryGrabSlot(int hint)
-{
-    int k;
-    const int n = gProc.numSlots;
-    if (n <= 0) return -1;
-    if (hint < 0 || hint >= n) hint = 0;
-    for (k = 0; k < n; k++) {
-        const int i = (hint + k) % n;
-        if (__sync_lock_test_and_set(&gProc.slots[i].lock, 1) == 0) return i;
-    }
-    return -1;
 }
 
 void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4])
@@ -852,18 +1007,24 @@ static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block)
     return done;
 }
 
-/* The same through a pipe, with nothing but pipe/write/read (for processes under a seccomp filter, where an unusual
+/* The same through a pipe, with nothing but pipe2/write/read (for processes under a seccomp filter, where an unusual
  * system call may be fatal): write() copies from user memory inside the kernel and stops with EFAULT at an
- * unreadable page; what went in is read back out into dst. */
-static size_t qzSafeReadPipe(int fd[2], void *dst, const void *src, size_t len, size_t block)
+ * unreadable page; what went in is read back out into dst.  The pipe is close-on-exec and non-blocking on the write side;
+ * chunks never exceed its capacity, so a short write means an unreadable page, not a full pipe. */
+static size_t qzSafeReadPipe(QZSTD_Session_T *s, void *dst, const void *src, size_t len, size_t block)
 {
+    int *fd = s->pipeFd;
     size_t done = 0;
     if (fd[0] < 0) {
-        if (pipe(fd) != 0) { fd[0] = fd[1] = -1; return 0; }
+        int cap;
+        if (pipe2(fd, O_CLOEXEC) != 0) { fd[0] = fd[1] = -1; return 0; }
         (void)fcntl(fd[1], F_SETFL, O_NONBLOCK);
+        cap = fcntl(fd[1], F_GETPIPE_SZ);
+        s->pipeChunk = cap >= 4096 ? (size_t)cap : 4096;
+        if (s->pipeChunk > 65536) s->pipeChunk = 65536;
     }
     while (done < len) {
-        const size_t want = len - done < 65536 ? len - done : 65536; /* the default capacity of a pipe */
+        const size_t want = len - done < s->pipeChunk ? len - done : s->pipeChunk;
         const ssize_t w = write(fd[1], (const char *)src + done, want);
         size_t got = 0;
         if (w <= 0) break;
@@ -878,21 +1039,107 @@ static size_t qzSafeReadPipe(int fd[2], void *dst, const void *src, size_t len, 
     return (done / block) * block;
 }
 
-/* Stage a buffer, queue its match-finding on a slot's stream and remember it in *h (asynchronous, see
- * QZSTD_hintSource).  speculative: the buffer is a GUESS (what follows the block of the current callback): read it
- * fault-safely, take only whole readable blocks, never wait for a slot.  Returns the bytes announced, 0 if none. */
+/* The end of the caller's own mapping around p (the VMA that holds the block it just named): a guess never reads
+ * past it, so it cannot wander into unrelated mappings (device BARs, other libraries' regions).  Cached per state;
+ * /proc/self/maps is read again only when a block lies outside the cached range.  0 = unknown (no guess). */
+static uintptr_t qzMappingEnd(QZSTD_Session_T *s, const void *p)
+{
+    const uintptr_t a = (uintptr_t)p;
+    FILE *f;
+    char line[512];
+    if (a >= s->mapLo && a < s->mapHi) return s->mapHi;
+    s->mapLo = s->mapHi = 0;
+    f = fopen("/proc/self/maps", "re");
+    if (!f) return 0;
+    while (fgets(line, sizeof line, f)) {
+        unsigned long lo = 0, hi = 0;
+        char perm[8] = "";
+        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perm) == 3 && a >= lo && a < hi) {
+            if (perm[0] == 'r') { s->mapLo = lo; s->mapHi = hi; }
+            break;
+        }
+    }
+    fclose(f);
+    return s->mapHi;
+}
+
+/* queue blocks [b0, b1) of announcement h on a slot of device `dev` (any device when dev < 0); 0 on success */
+static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, size_t b0, size_t b1, int dev, int level,
+                        int mayWait)
+{
+    QZSTD_Slot_T *sl;
+    const size_t o0 = b0 * h->block;
+    const size_t bytes = ((b1 * h->block < h->size ? b1 * h->block : h->size) - o0 + 63) & ~(size_t)63;
+    size_t b;
+    int i, tries;
+    pt->st = 0;
+    for (tries = 0; ; tries++) {
+        i = qzTryGrabSlot(s->slotHint + tries * gProc.numDevices, dev);
+        if (i < 0 && mayWait) {
+            /* every slot is busy: give back what this state still holds, then wait for one */
+            int k, j;
+            for (k = 0; k < 4; k++)
+                for (j = 0; j < s->hint[k].nParts; j++)
+                    if (&s->hint[k] != h) qzPartFinish(&s->hint[k].part[j]);
+            i = qzGrabSlot(s->slotHint, dev);
+        }
+        if (i < 0) return -1;
+        sl = &gProc.slots[i];
+        if (!(sl->stream && qzStillStuck(sl->device, sl->stream, &sl->stuck))) break;
+        qzReleaseSlot(i); /* quarantined after a time-out: try another one */
+        if (tries >= 8) return -1;
+    }
+    if (dev < 0) s->slotHint = i;
+    if (qzSetupSlot(sl, 0) != QZSTD_OK) goto fail;
+    sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, bytes);
+    if (!sl->dBatchSrc) goto fail;
+    {
+        const size_t work = qzstd_hip_workspace_bytes(level, (unsigned int)(b1 - b0), (unsigned int)h->block);
+        if (work) sl->dBatchWork = qzGrowDev(sl->device, sl->dBatchWork, &sl->dBatchWorkCap, work);
+        if (work && !sl->dBatchWork) goto fail;
+    }
+    for (b = b0; b < b1; b++) {
+        const size_t o = b * h->block;
+        h->hDesc[b].srcOff = o - o0; /* relative to this part's device buffer */
+        /* results go straight into the pinned buffer, QZ_HINT_PITCH entries per block: a block with more
+         * sequences reports an error and is redone by the per-block path when its callback comes */
+        h->hDesc[b].seqOff = b * QZ_HINT_PITCH;
+        h->hDesc[b].srcLen = (unsigned int)(h->size - o < h->block ? h->size - o : h->block);
+        h->hDesc[b].seqCap = (unsigned int)(qzstd_hip_sequence_bound(h->block) < QZ_HINT_PITCH ? qzstd_hip_sequence_bound(h->block) : QZ_HINT_PITCH);
+    }
+    /* everything below is queued on the slot's stream and returns immediately */
+    if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc + o0, bytes) ||
+        qzstd_hip_find_sequences(sl->device, sl->stream, level, sl->dBatchSrc, (const qzstd_hip_block_t *)h->dvDesc + b0,
+                                 (unsigned int)(b1 - b0), (unsigned int)h->block, h->dvSeqs, (unsigned int *)h->dvCount + b0,
+                                 sl->dBatchWork, sl->dBatchWorkCap)) {
+        if (qzWait(sl->device, sl->stream) == 1) sl->stuck = 1;
+        goto fail;
+    }
+    pt->st = 1; /* in flight; the slot stays ours until qzPartFinish() */
+    pt->slot = i;
+    pt->b0 = b0;
+    pt->b1 = b1;
+    return 0;
+fail:
+    QZ_LOG(1, "look-ahead not taken: %s\n", qzstd_hip_last_error());
+    qzReleaseSlot(i);
+    return -1;
+}
+
+/* Stage a buffer, queue its match-finding and remember it in *h (asynchronous, see QZSTD_hintSource).  The blocks
+ * are split into contiguous ranges, one per GPU (reference analogue: instances interleaved across devices,
+ * src/qatseqprod.c:601-630), each on its own slot and stream; the results land in the announcement's pinned buffers.
+ * speculative: the buffer is a GUESS (what follows the block of the current callback): read it fault-safely, take only
+ * whole readable blocks, never wait for a slot, one GPU.  Returns the bytes announced, 0 if none. */
 static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, size_t srcSize, size_t blockSize,
                          int compressionLevel, int speculative)
 {
-    QZSTD_Slot_T *sl;
-    size_t nb, b, stride, blocksBytes, srcBytes;
+    size_t nb, blocksBytes, srcBytes;
     unsigned long tq;
-    int i;
+    int parts, k, firstDev;
 
-    qzHintFinish(h); /* an old announcement that was never consumed */
-    h->st = 0;
+    qzHintDrop(h); /* an old announcement that was never consumed */
     nb = (srcSize + blockSize - 1) / blockSize;
-    stride = qzstd_hip_sequence_bound(blockSize);
     blocksBytes = nb * sizeof(qzstd_hip_block_t);
     srcBytes = (srcSize + 63) & ~(size_t)63;
 
@@ -907,63 +1154,46 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
 
     tq = qzNowNs();
     if (speculative) {
-        srcSize = gProc.lookahead == 2 ? qzSafeReadPipe(s->pipeFd, h->hSrc, src, srcSize, blockSize)
+        srcSize = gProc.lookahead == 2 ? qzSafeReadPipe(s, h->hSrc, src, srcSize, blockSize)
                                        : qzSafeRead(h->hSrc, src, srcSize, blockSize);
         if (srcSize == 0) return 0;
         nb = srcSize / blockSize;
-        srcBytes = (srcSize + 63) & ~(size_t)63;
-    }
-    i = qzTryGrabSlot(s->slotHint);
-    if (i < 0) {
-        if (speculative) return 0;
-        /* every slot is busy: give back what this state still holds, then wait for one */
-        for (b = 0; b < 4; b++) qzHintFinish(&s->hint[b]);
-        i = qzGrabSlot(s->slotHint);
-        if (i < 0) return 0;
-    }
-    s->slotHint = i;
-    sl = &gProc.slots[i];
-    if (qzSetupSlot(sl) != QZSTD_OK) goto fail;
-    sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, srcBytes);
-    if (!sl->dBatchSrc) goto fail;
-    {
-        const size_t work = qzstd_hip_workspace_bytes(compressionLevel | gProc.levelFlags, (unsigned int)nb, (unsigned int)blockSize);
-        if (work) sl->dBatchWork = qzGrowDev(sl->device, sl->dBatchWork, &sl->dBatchWorkCap, work);
-        if (work && !sl->dBatchWork) goto fail;
-    }
-    if (!speculative) memcpy(h->hSrc, src, srcSize); /* pinned staging: the H2D below is then truly asynchronous */
-    for (b = 0; b < nb; b++) {
-        const size_t o = b * blockSize;
-        h->hDesc[b].srcOff = o;
-        /* results go straight into the pinned buffer, QZ_HINT_PITCH entries per block: a block with more
-         * sequences reports an error and is redone by the per-block path when its callback comes */
-        h->hDesc[b].seqOff = b * QZ_HINT_PITCH;
-        h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
-        h->hDesc[b].seqCap = (unsigned int)(stride < QZ_HINT_PITCH ? stride : QZ_HINT_PITCH);
+    } else {
+        memcpy(h->hSrc, src, srcSize); /* pinned staging: the H2D copies are then truly asynchronous */
     }
     s->hintStageNs += qzNowNs() - tq;
     tq = qzNowNs();
-    /* everything below is queued on the slot's stream and returns immediately */
-    if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc, srcBytes) ||
-        qzstd_hip_find_sequences(sl->device, sl->stream, compressionLevel | gProc.levelFlags, sl->dBatchSrc,
-                                 (const qzstd_hip_block_t *)h->dvDesc, (unsigned int)nb, (unsigned int)blockSize, h->dvSeqs,
-                                 (unsigned int *)h->dvCount, sl->dBatchWork, sl->dBatchWorkCap)) {
-        (void)qzstd_hip_stream_sync(sl->device, sl->stream);
-        goto fail;
-    }
     h->base = (const unsigned char *)src;
     h->size = srcSize;
     h->block = blockSize;
     h->level = compressionLevel;
     h->nb = nb;
-    h->slot = i;
-    h->st = 1; /* in flight; the slot stays ours until qzHintFinish() */
+    /* contiguous block ranges, one per GPU, starting at this state's own GPU; a range is worth a launch from 4 blocks */
+    parts = speculative ? 1 : gProc.split;
+    if ((size_t)parts > nb / 4) parts = nb / 4 ? (int)(nb / 4) : 1;
+    if (s->slotHint < 0) {
+        static volatile unsigned int nextHintDev = 0;
+        s->slotHint = (int)(__sync_fetch_and_add(&nextHintDev, 1u) & 0x3FFFFFFFu);
+    }
+    firstDev = s->slotHint % gProc.numDevices;
+    h->nParts = 0;
+    for (k = 0; k < parts; k++) {
+        const size_t b0 = nb * (size_t)k / (size_t)parts, b1 = nb * (size_t)(k + 1) / (size_t)parts;
+        const int dev = parts > 1 ? (firstDev + k) % gProc.numDevices : (speculative ? -1 : firstDev);
+        if (qzLaunchPart(s, h, &h->part[h->nParts], b0, b1, dev, compressionLevel | gProc.levelFlags, !speculative) != 0) {
+            /* that range could not be queued: its callbacks take the per-block path; a guess is simply not made */
+            if (speculative) { qzHintDrop(h); return 0; }
+            h->part[h->nParts].st = 3;
+            h->part[h->nParts].b0 = b0;
+            h->part[h->nParts].b1 = b1;
+        }
+        h->nParts++;
+    }
+    h->st = 1;
+    h->touched = 0;
+    h->misses = 0;
     s->hintQueueNs += qzNowNs() - tq;
     return srcSize;
-fail:
-    QZ_LOG(1, "look-ahead not taken: %s\n", qzstd_hip_last_error());
-    qzReleaseSlot(i);
-    return 0;
 }
 
 int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
@@ -971,6 +1201,7 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
 {
     QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
     QZSTD_Hint_T *h;
+    int k, inflight = 0;
 
     if (!s || !src || srcSize == 0 || srcSize > QZ_HINT_MAX_BYTES || blockSize == 0 || blockSize > QZSTD_HIP_BLOCK_MAX ||
         (blockSize & 15))
@@ -980,28 +1211,49 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     h = &s->hint[s->hintNext];
     s->hintNext ^= 1;
     if (qzAnnounce(s, h, src, srcSize, blockSize, compressionLevel, 0) == 0) return -1;
+    for (k = 0; k < h->nParts; k++) inflight += h->part[k].st == 1;
+    if (!inflight) { /* nothing could be queued */
+        qzHintDrop(h);
+        return -1;
+    }
     s->hintCalls++;
     return 0;
 }
 
-/* Transparent look-ahead for callers that announce nothing.  libzstd hands over one block per callback and waits,
- * but most callers walk a contiguous buffer (a file in chunks, a multi-block frame), so the bytes that FOLLOW the
- * current block are very likely the next blocks.  On a callback that had to take the per-block path, guess: read
- * the following blocks fault-safely, and let the GPU match-find them while this block is being served and its
- * frame entropy-coded.  A later callback is served from a guess only if its (src, srcSize) sits on the guessed
- * grid AND its bytes still equal the staged copy (memcmp), so a wrong guess costs GPU time, never correctness.
- * The depth doubles while guesses are consumed (2 .. 32 blocks); misses back off exponentially. */
+/* Transparent look-ahead for callers that announce nothing — OPT-IN (QZSTD_HIP_LOOKAHEAD=1|2), because it reads memory
+ * the caller did not hand over.  libzstd passes one block per callback and waits, but most callers walk a contiguous
+ * buffer (a file in chunks, a multi-block frame), so the bytes that FOLLOW the current block are very likely the
+ * next blocks.  On a callback that had to take the per-block path, guess: read the following blocks fault-safely —
+ * never past the end of the mapping that holds the current block — and let the GPU match-find them while this block is
+ * being served and its frame entropy-coded.  A later callback is served from a guess only if its (src, srcSize) sits
+ * on the guessed grid AND its bytes still equal the staged copy (memcmp), so a wrong guess costs GPU time, never
+ * correctness.  The depth doubles while guesses are consumed (2 .. 32 blocks); misses back off exponentially. */
 static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t blockSize, int compressionLevel)
 {
     QZSTD_Hint_T *h;
+    size_t want;
+    uintptr_t end;
+    int k;
     /* only with the coalescer: there the per-block path needs no slot, so guesses that hold slots cannot starve it */
     if (!gProc.lookahead || !gProc.coalesce || (blockSize & 15) || blockSize < 4096) return;
     if (s->autoBackoff) { s->autoBackoff--; return; }
     if (s->autoDepth < QZ_AUTO_DEPTH_MIN) s->autoDepth = QZ_AUTO_DEPTH_MIN;
     h = &s->hint[2 + s->autoNext];
-    if (h->st == 1 && qzstd_hip_stream_query(gProc.slots[h->slot].device, gProc.slots[h->slot].stream) == 1)
-        return; /* the buffer we would reuse is still on the GPU: do not wait for a guess */
-    if (qzAnnounce(s, h, next, (size_t)s->autoDepth * blockSize, blockSize, compressionLevel, 1) != 0) {
+    for (k = 0; k < h->nParts; k++)
+        if (h->part[k].st == 1 && qzstd_hip_stream_query(gProc.slots[h->part[k].slot].device, gProc.slots[h->part[k].slot].stream) == 1)
+            return; /* the buffer we would reuse is still on the GPU: do not wait for a guess */
+    /* confined to the caller's own mapping: the one that holds the last byte of the block it just named */
+    end = qzMappingEnd(s, next - 1);
+    if (end == 0 || (uintptr_t)next >= end) { s->autoBackoff = 16; return; }
+    want = (size_t)s->autoDepth * blockSize;
+    if (want > end - (uintptr_t)next) want = ((end - (uintptr_t)next) / blockSize) * blockSize;
+    if (want == 0) { s->autoBackoff = 16; return; }
+    if (!gProc.lookaheadLogged) {
+        gProc.lookaheadLogged = 1;
+        QZ_LOG(1, "transparent look-ahead is ON (QZSTD_HIP_LOOKAHEAD=%d): reading up to %u blocks behind the block of a "
+                  "callback, inside the caller's mapping only\n", gProc.lookahead, QZ_AUTO_DEPTH_MAX);
+    }
+    if (qzAnnounce(s, h, next, want, blockSize, compressionLevel, 1) != 0) {
         s->autoNext ^= 1;
         s->autoLaunched++;
         s->autoOutstanding = 1;

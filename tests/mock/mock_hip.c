@@ -13,12 +13,31 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
 static _Thread_local char gErr[128] = "";
 static int gLaunches;
+static int gLaunchDev[64];
+static volatile long long gStallUntilNs; /* test hook: every stream looks busy until then (a wedged device) */
+
+static long long nowNs(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+/* test hooks */
+void qzstd_mock_stall_ms(int ms) { gStallUntilNs = ms > 0 ? nowNs() + (long long)ms * 1000000ll : 0; }
+int qzstd_mock_launches_on(int device) { return device >= 0 && device < 64 ? gLaunchDev[device] : -1; }
 
 const char *qzstd_hip_last_error(void) { return gErr; }
 int qzstd_mock_launches(void) { return gLaunches; }
-int qzstd_hip_device_count(void) { return 1; }
+int qzstd_hip_device_count(void)
+{
+    const char *v = getenv("QZSTD_MOCK_DEVICES"); /* several "GPUs": the split of announcements and the device round-robin */
+    const int n = v ? atoi(v) : 1;
+    return n < 1 ? 1 : (n > 8 ? 8 : n);
+}
 int qzstd_hip_device_name(int device, char *buf, size_t bufLen)
 {
     (void)device;
@@ -33,7 +52,18 @@ void qzstd_hip_host_free(void *h) { free(h); }
 void *qzstd_hip_stream_create(int device) { (void)device; return malloc(1); }
 void qzstd_hip_stream_destroy(int device, void *s) { (void)device; free(s); }
 int qzstd_hip_stream_sync(int device, void *s) { (void)device; (void)s; return 0; }
-int qzstd_hip_stream_query(int device, void *s) { (void)device; (void)s; return 0; }
+int qzstd_hip_stream_query(int device, void *s) { (void)device; (void)s; return nowNs() < gStallUntilNs ? 1 : 0; }
+int qzstd_hip_stream_wait(int device, void *s, unsigned timeoutMs)
+{
+    const long long deadline = nowNs() + (long long)timeoutMs * 1000000ll;
+    (void)device; (void)s;
+    while (nowNs() < gStallUntilNs) {
+        const struct timespec nap = { 0, 200000 };
+        if (nowNs() >= deadline) { snprintf(gErr, sizeof gErr, "mock: stream still busy after %u ms", timeoutMs); return 1; }
+        nanosleep(&nap, NULL);
+    }
+    return 0;
+}
 int qzstd_hip_memcpy_h2d(int device, void *s, void *dst, const void *src, size_t n) { (void)device; (void)s; memcpy(dst, src, n); return 0; }
 int qzstd_hip_memcpy_d2h(int device, void *s, void *dst, const void *src, size_t n) { (void)device; (void)s; memcpy(dst, src, n); return 0; }
 int qzstd_hip_memset(int device, void *s, void *dst, int v, size_t n) { (void)device; (void)s; memset(dst, v, n); return 0; }
@@ -51,13 +81,14 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
 {
     uint32_t b;
     qzo_profile_t pf;
-    (void)device; (void)stream;
+    (void)stream;
     if (qzo_profile_for_level(level, maxBlockLen, &pf)) { snprintf(gErr, sizeof gErr, "mock: bad level"); return -1; }
     if (qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen) > workBytes || (workBytes && !d_work)) {
         snprintf(gErr, sizeof gErr, "mock: workspace missing or too small");
         return -1;
     }
     __sync_fetch_and_add(&gLaunches, 1);
+    if (device >= 0 && device < 64) __sync_fetch_and_add(&gLaunchDev[device], 1);
     for (b = 0; b < nBlocks; b++) {
         const qzstd_hip_block_t *k = &d_blocks[b];
         const size_t n = qzo_find_sequences(&pf, (const uint8_t *)d_src + k->srcOff, k->srcLen,

@@ -77,6 +77,7 @@ def stats_of(plug, st):
 
 @pytest.mark.parametrize("level,chunk", [(1, 131072), (3, 65536), (6, 131072), (12, 32768)])
 def test_unchanged_caller_guessed_lookahead(mock, zstd, oracle, level, chunk):
+    """the transparent look-ahead is opt-in (QZSTD_HIP_LOOKAHEAD=1): off by default, nothing behind a block is read"""
     data = K.by_name("mix", 24 * chunk + 777, seed=level)
     buf = (C.c_char * len(data)).from_buffer_copy(data)
     st = mock.lib.QZSTD_createSeqProdState()
@@ -84,7 +85,36 @@ def test_unchanged_caller_guessed_lookahead(mock, zstd, oracle, level, chunk):
     stats = stats_of(mock, st)
     mock.lib.QZSTD_freeSeqProdState(st)
     assert got == oracle_frames(zstd, oracle, data, chunk, level)
+    assert stats[0] == 0 and stats[1] == 25, stats  # default: every block took the per-block path
+    with restarted(mock, QZSTD_HIP_LOOKAHEAD="1"):
+        st = mock.lib.QZSTD_createSeqProdState()
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, level)
+        stats = stats_of(mock, st)
+        mock.lib.QZSTD_freeSeqProdState(st)
+    assert got == oracle_frames(zstd, oracle, data, chunk, level)
     assert stats[2] == 0 and stats[0] >= 16, stats  # nothing announced; most blocks came from guesses
+
+
+def test_guess_stays_inside_the_callers_mapping(mock, zstd, oracle):
+    """a guess never reads past the end of the mapping that holds the block of the callback, even when the next
+    mapping is readable"""
+    chunk, nblk = 65536, 6
+    big = mmap.mmap(-1, 2 * nblk * chunk)  # one mapping; split into two VMAs by giving the halves different protections
+    base = C.addressof(C.c_char.from_buffer(big))
+    libc = C.CDLL(None, use_errno=True)
+    data = K.by_name("text", nblk * chunk, seed=5)
+    big[:nblk * chunk] = data
+    big[nblk * chunk:] = K.by_name("binary", nblk * chunk, seed=6)
+    assert libc.mprotect(C.c_void_p(base + nblk * chunk), C.c_size_t(nblk * chunk), 1) == 0  # PROT_READ only: another VMA
+    with restarted(mock, QZSTD_HIP_LOOKAHEAD="1", QZSTD_HIP_DEBUG="3"):
+        st = mock.lib.QZSTD_createSeqProdState()
+        got = frames_of(zstd, mock.producer_addr, st, base, nblk * chunk, chunk, 1)
+        served = stats_of(mock, st)[0]
+        mock.lib.QZSTD_freeSeqProdState(st)
+    assert got == oracle_frames(zstd, oracle, data, chunk, 1)
+    assert served >= 3
+    assert libc.mprotect(C.c_void_p(base + nblk * chunk), C.c_size_t(nblk * chunk), 3) == 0
+    del got
 
 
 @pytest.mark.parametrize("mode", ["1", "2"])  # fault-safe read by process_vm_readv / through a pipe
@@ -205,7 +235,8 @@ plug.lib.QZSTD_stopQatDevice()
 assert ok == [True] * 6, ok
 print("OK")
 ''' % (os.path.join(ROOT, "tools"), MOCK_SO)
-    for env in ({"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SLOTS": "3"}, {"QZSTD_HIP_LOOKAHEAD": "0"}, {"QZSTD_HIP_LOOKAHEAD": "2"},
+    for env in ({"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SLOTS": "3"}, {"QZSTD_HIP_LOOKAHEAD": "1"}, {"QZSTD_HIP_LOOKAHEAD": "2"},
+                {"QZSTD_MOCK_DEVICES": "4"},
                 {"QZSTD_HIP_EXT_REPCODES": "1"}):
         out = subprocess.run(["python", "-c", script], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
         assert out.returncode == 0 and "OK" in out.stdout, (env, out.stderr[-800:])
@@ -223,10 +254,115 @@ def test_lookahead_never_changes_the_output(mock, zstd):
         mock.lib.QZSTD_freeSeqProdState(st)
         return fr
 
-    on = {c: run(c) for c in (1 << 20, 393216)}
-    with restarted(mock, QZSTD_HIP_LOOKAHEAD="0"):
-        off = {c: run(c) for c in (1 << 20, 393216)}
+    off = {c: run(c) for c in (1 << 20, 393216)}  # the default
+    with restarted(mock, QZSTD_HIP_LOOKAHEAD="1"):
+        on = {c: run(c) for c in (1 << 20, 393216)}
     with restarted(mock, QZSTD_HIP_LOOKAHEAD="2"):
         piped = {c: run(c) for c in (1 << 20, 393216)}
     assert on == off == piped
     assert b"".join(zstd.decompress(f, 1 << 20) for f in on[1 << 20]) == data
+
+
+def test_announced_buffer_that_changes_is_never_served_stale(mock, zstd, oracle):
+    """announce two blocks, compress the first, overwrite the buffer, compress the second — the
+    callback's bytes no longer equal the staged copy, so the announcement is dropped and the block is match-found
+    afresh; and an announcement the caller walks away from does not linger"""
+    chunk = 131072
+    a, b = K.by_name("text", 2 * chunk, seed=21), K.by_name("weblog", 2 * chunk, seed=22)
+    buf = (C.c_char * (2 * chunk)).from_buffer_copy(a)
+    st = mock.lib.QZSTD_createSeqProdState()
+    assert mock.lib.QZSTD_hintSource(st, buf, 2 * chunk, chunk, 1) == 0
+
+    def overwrite(c):
+        if c == 1:
+            C.memmove(buf, b, 2 * chunk)
+
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), 2 * chunk, chunk, 1, before=overwrite)
+    want = oracle_frames(zstd, oracle, a[:chunk] + b[chunk:], chunk, 1)
+    assert got == want
+    assert zstd.decompress(got[1], chunk) == b[chunk:]
+    assert stats_of(mock, st)[:2] == [1, 1]  # block 0 from the announcement, block 1 on its own
+    # abandoned announcement: announce 8 blocks, use one, then compress elsewhere — it is dropped after a while
+    big = (C.c_char * (8 * chunk)).from_buffer_copy(K.by_name("mix", 8 * chunk, seed=23))
+    other = K.by_name("binary", 24 * chunk, seed=24)
+    obuf = (C.c_char * len(other)).from_buffer_copy(other)
+    assert mock.lib.QZSTD_hintSource(st, big, 8 * chunk, chunk, 1) == 0
+    frames_of(zstd, mock.producer_addr, st, C.addressof(big), chunk, chunk, 1)
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(obuf), len(other), chunk, 1)
+    assert got == oracle_frames(zstd, oracle, other, chunk, 1)
+    mock.lib.QZSTD_freeSeqProdState(st)
+
+
+def test_time_out_returns_the_error_and_libzstd_falls_back(mock, zstd):
+    """reference: 2 s of polling, then ZSTD_SEQUENCE_PRODUCER_ERROR (src/qatseqprod.c:1261-1285) so that
+    ZSTD_c_enableSeqProducerFallback takes over; here QZSTD_HIP_TIMEOUT_MS, a stalled (mock) stream, and the stream
+    comes back into service once it has drained"""
+    import time
+    chunk = 65536
+    data = K.by_name("text", 4 * chunk, seed=31)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    mock.lib.qzstd_mock_stall_ms.argtypes = [C.c_int]
+    with restarted(mock, QZSTD_HIP_TIMEOUT_MS="50"):
+        st = mock.lib.QZSTD_createSeqProdState()
+        seqs = (B.Sequence * B.sequence_bound(chunk))()
+        mock.lib.qzstd_mock_stall_ms(400)
+        t0 = time.time()
+        rc = mock.lib.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 1, 1 << 17)
+        dt = time.time() - t0
+        assert rc == B.SEQ_ERROR and 0.04 <= dt < 0.35, (rc, dt)
+        # with the fallback enabled libzstd compresses the frame itself while the device is wedged
+        zc = zstd.cctx(1, producer=mock.producer_addr, state=st, fallback=True, validate=True)
+        frame = zstd.compress2(zc, data[:chunk])
+        assert zstd.decompress(frame, chunk) == data[:chunk]
+        # an announcement on the wedged device fails the same way; its callbacks then take the per-block path
+        mock.lib.qzstd_mock_stall_ms(0)
+        time.sleep(0.01)
+        rc = mock.lib.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 1, 1 << 17)
+        assert rc != B.SEQ_ERROR and rc > 1  # drained: back in service
+        zstd.free(zc)
+        mock.lib.QZSTD_freeSeqProdState(st)
+
+
+def test_announcement_is_split_across_the_gpus(mock, zstd, oracle):
+    """north star: the batch shards across the GPUs of a node with per-GPU streams and host-side gather (no collective).
+    Reference analogue: instances interleaved across devices, src/qatseqprod.c:601-630.  Four mock devices: an
+    announcement of 32 blocks becomes four launches, one per device; frames equal the oracle's"""
+    chunk = 65536
+    data = K.by_name("system", 32 * chunk)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_launches_on.argtypes = [C.c_int]
+    with restarted(mock, QZSTD_MOCK_DEVICES="4"):
+        before = [L.qzstd_mock_launches_on(d) for d in range(4)]
+        st = L.QZSTD_createSeqProdState()
+        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) == 0
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 3)
+        assert stats_of(mock, st)[:2] == [32, 0]
+        L.QZSTD_freeSeqProdState(st)
+        after = [L.qzstd_mock_launches_on(d) for d in range(4)]
+        assert [a - b for a, b in zip(after, before)] == [1, 1, 1, 1]
+        # QZSTD_HIP_SPLIT=1 keeps an announcement on the state's own GPU
+    with restarted(mock, QZSTD_MOCK_DEVICES="4", QZSTD_HIP_SPLIT="1"):
+        before = sum(L.qzstd_mock_launches_on(d) for d in range(4))
+        st = L.QZSTD_createSeqProdState()
+        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) == 0
+        got1 = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 3)
+        L.QZSTD_freeSeqProdState(st)
+        assert sum(L.qzstd_mock_launches_on(d) for d in range(4)) - before == 1
+    want = oracle_frames(zstd, oracle, data, chunk, 3)
+    assert got == want and got1 == want
+
+
+def test_dense_block_is_redone_alone(mock, zstd, oracle):
+    """a block with more sequences than a batch's result pitch (16384) is redone with the caller's full capacity"""
+    import random
+    rng = random.Random(7)
+    words = [bytes(rng.randrange(97, 123) for _ in range(5)) for _ in range(200)]
+    data = b"".join(rng.choice(words) + bytes([rng.randrange(256)]) for _ in range(131072 // 6 + 1))[:131072]
+    n, _ = oracle.find(oracle.profile(1, 131072), data, cap=B.sequence_bound(131072))
+    assert n > 16384, n
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    st = mock.lib.QZSTD_createSeqProdState()
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), 131072, 1)
+    mock.lib.QZSTD_freeSeqProdState(st)
+    assert got == oracle_frames(zstd, oracle, data, 131072, 1)
