@@ -10,9 +10,15 @@ collective besides the timing barrier / MAX).
 
 Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit, roofline
 (HBM-bound integer kernel: algorithmic bytes = block bytes read + 16 B per sequence
-written), cpu_baseline (the CPU oracle timed on a bounded sample), plus the
-north-star's own CPU baseline (libzstd's internal match-finder, plugin unregistered)
-and the compression ratio of the produced sequences vs software zstd.
+written).  `value` is the hot path with its input resident in HBM (the contract's definition);
+what BASELINE.json's metric literally names — input MB/s through ZSTD_compress2 with the plugin
+registered — is `value_e2e` (+ `e2e_sweep` over thread counts, wall clock next to sum of
+per-thread rates), measured in the same run by the C benchmark tool next to `cpu_baseline` =
+libzstd's own match-finder with the plugin unregistered (the north star's CPU baseline), timed
+with BOTH the libzstd 1.5.x the producer API needs and the system's optimised 1.4.x
+(BASELINE.md §2).  Further legs: `pcie_pipeline` (host-pinned in, host-pinned out, three chunks
+in flight: what a GPU delivers when nothing is resident), `frontend` (the batch front-end of
+include/qzstd_frontend.h), the oracle port on one core (`cpu_oracle_port`).
 """
 from __future__ import annotations
 
@@ -84,7 +90,7 @@ def load_corpus(name: str, size: int) -> tuple[bytes, str]:
 
 # ----------------------------------------------------------------------------- CPU legs
 def cpu_oracle_leg(data: bytes, block: int, level: int, seconds: float):
-    """cpu_baseline: the CPU restatement of the same match-finder ("port"), 1 thread."""
+    """the CPU restatement of the same match-finder (the oracle, a "port"), 1 thread: a side key, not the baseline"""
     orc = B.Oracle()
     prof = orc.profile(level, block)
     cap = B.sequence_bound(block)
@@ -101,38 +107,176 @@ def cpu_oracle_leg(data: bytes, block: int, level: int, seconds: float):
             "sample": "oracle/qzstd_oracle.c qzo_find_sequences, first %d blocks of the batch, 1 thread" % (done // block)}
 
 
-def c_benchmark(sample: bytes, block: int, level: int, threads: int, mode: int, hint: int = 0, ext_rep: int = 0,
-                loops: int = 2, env: dict | None = None):
-    """run qat-zstd-plugin_amd/test/benchmark (counterpart of the reference's test/benchmark.c: T threads,
-    one CCtx each, one ZSTD_compress2 per chunk, each chunk its own frame) on a sample file"""
-    import re
+def host_cpu_budget():
+    """(logical CPUs, cores this process may actually use): a cgroup CPU quota (cpu.max) caps the second one"""
+    ncpu = os.cpu_count() or 1
+    quota = float(ncpu)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = min(quota, float(q) / float(per))
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        quota = min(quota, float(len(os.sched_getaffinity(0))))
+    except Exception:  # noqa: BLE001
+        pass
+    return ncpu, quota
+
+
+def build_tools():
     import subprocess
-    import tempfile
     tdir = os.path.join(B.PKG_DIR, "test")
     zpath = B.find_libzstd()
+    subprocess.call(["make", "-C", B.PKG_DIR, "ZSTDLIB=" + zpath], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for tgt in ("benchmark", "benchmark_sw", "frontbench"):
+        subprocess.call(["make", "-C", tdir, tgt, "ZSTDLIB=" + zpath], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return tdir
+
+
+def c_benchmark(sample_file: str, block: int, level: int, threads: int, mode: int, hint: int = 0, ext_rep: int = 0,
+                loops: int = 2, env: dict | None = None, tool: str = "benchmark"):
+    """run qat-zstd-plugin_amd/test/benchmark (counterpart of the reference's test/benchmark.c: T threads,
+    one CCtx each, one ZSTD_compress2 per chunk, each chunk its own frame) on a sample file.  tool="benchmark_sw" is the
+    same source built software-only against the system's libzstd 1.4.x."""
+    import re
+    import subprocess
+    tdir = os.path.join(B.PKG_DIR, "test")
     try:
-        subprocess.check_call(["make", "-C", tdir, "benchmark", "ZSTDLIB=" + zpath], stdout=subprocess.DEVNULL,
-                              stderr=subprocess.DEVNULL)
-        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
-            f.write(sample)
-            name = f.name
-        cmd = [os.path.join(tdir, "benchmark"), "-m%d" % mode, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level,
-               "-E%d" % ext_rep] + (["-H%d" % hint] if hint else []) + [name]
+        exe = os.path.join(tdir, tool)
+        if not os.path.isfile(exe):
+            return {"error": "%s not built" % tool}
+        cmd = [exe, "-m%d" % mode, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level,
+               "-E%d" % ext_rep] + (["-H%d" % hint] if hint else []) + [sample_file]
         t0 = time.perf_counter()
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
         wall = time.perf_counter() - t0
-        os.unlink(name)
-        agg = re.search(r"aggregate compression ([0-9.]+) MB/s", out.stderr)
+        agg = re.search(r"aggregate compression ([0-9.]+) MB/s \(sum of per-thread rates\), ([0-9.]+) MB/s by the wall clock", out.stderr)
+        ver = re.search(r"libzstd ([0-9.]+);", out.stderr)
         first = re.search(r"Compression: (\d+) -> (\d+) ", out.stderr)
         lat = re.search(r"P50 ([0-9.]+)\s+P75 [0-9.]+\s+P99 ([0-9.]+)", out.stderr)
         if out.returncode != 0 or not agg or not first:
             return {"error": (out.stderr or "benchmark failed")[-300:]}
-        return {"MBps": float(agg.group(1)), "threads": threads, "bytes_per_thread": int(first.group(1)),
+        return {"MBps_wall": float(agg.group(2)), "MBps_sum_of_thread_rates": float(agg.group(1)), "threads": threads,
+                "libzstd": ver.group(1) if ver else None,
+                "bytes_per_thread": int(first.group(1)), "loops": loops,
                 "csize": int(first.group(2)), "ratio": round(int(first.group(1)) / max(int(first.group(2)), 1), 4),
                 "latency_us_p50": float(lat.group(1)) if lat else None, "latency_us_p99": float(lat.group(2)) if lat else None,
-                "tool": "qat-zstd-plugin_amd/test/benchmark " + " ".join(cmd[1:-1]), "wall_s": round(wall, 2)}
+                "tool": "qat-zstd-plugin_amd/test/%s " % tool + " ".join(cmd[1:-1]) + (" env " + " ".join("%s=%s" % kv for kv in env.items()) if env else ""),
+                "wall_s": round(wall, 2)}
     except Exception as e:  # noqa: BLE001 - the bench line must still be printed
         return {"error": repr(e)[:300]}
+
+
+def frontbench(sample_file: str, block: int, level: int, threads: int, mode: int, loops: int = 3, seg_mib: int = 4, ext_rep: int = 0,
+               env: dict | None = None):
+    """qat-zstd-plugin_amd/test/frontbench: ONE buffer through the batch front-end (include/qzstd_frontend.h), bytes / wall clock"""
+    import re
+    import subprocess
+    exe = os.path.join(B.PKG_DIR, "test", "frontbench")
+    try:
+        if not os.path.isfile(exe):
+            return {"error": "frontbench not built"}
+        cmd = [exe, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level, "-E%d" % ext_rep, "-s%d" % seg_mib, "-m%d" % mode, sample_file]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
+        m = re.search(r": (\d+) -> (\d+) bytes, wall-clock ([0-9.]+) MB/s \(mean of \d+ passes; best ([0-9.]+) MB/s\), (\d+) block\(s\) from announcements, (\d+) per block, (PASS|FAIL)", out.stdout)
+        if out.returncode != 0 or not m:
+            return {"error": (out.stdout + out.stderr)[-300:]}
+        return {"MBps_wall": float(m.group(3)), "MBps_wall_best_pass": float(m.group(4)), "threads": threads, "bytes": int(m.group(1)),
+                "csize": int(m.group(2)), "blocks_from_announcements": int(m.group(5)), "blocks_per_block_path": int(m.group(6)),
+                "roundtrip": m.group(7), "tool": "qat-zstd-plugin_amd/test/frontbench " + " ".join(cmd[1:-1])}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
+def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, chunk_blocks: int = 512, depth: int = 3,
+                      passes: int = 3):
+    """Host-pinned -> host-pinned sequence production through the C ABI, nothing resident: the input sits in pinned host
+    memory, every chunk of `chunk_blocks` blocks goes H2D on its own stream, is match-found there, and the kernel writes
+    counts + sequences straight into pinned host result buffers (posted PCIe writes) — `depth` chunks in flight, so
+    the copy of chunk k+1 overlaps the kernel of chunk k and the result writes of chunk k-1 (BASELINE config 5's
+    "host double-buffered pinned H2D/D2H overlapping compute", at the level of the C ABI).  GB/s of input per GPU."""
+    L = plug.lib
+    pitch = 16384  # result entries per block (the product's QZ_HINT_PITCH)
+    nb = min(len(shard) // block, 4096)
+    nchunks = nb // chunk_blocks
+    if nchunks < depth:
+        return {"error": "batch too small for the pipeline leg"}
+    cbytes = chunk_blocks * block
+    L.qzstd_hip_host_alloc.restype = C.c_void_p
+    L.qzstd_hip_host_device_ptr.restype = C.c_void_p
+    L.qzstd_hip_stream_create.restype = C.c_void_p
+    L.qzstd_hip_malloc.restype = C.c_void_p
+    h_in = L.qzstd_hip_host_alloc(C.c_size_t(nchunks * cbytes))
+    lanes = []
+    try:
+        assert h_in, plug.err()
+        C.memmove(h_in, shard[:nchunks * cbytes], nchunks * cbytes)
+        for _ in range(depth):
+            ln = {"stream": L.qzstd_hip_stream_create(device), "d_src": L.qzstd_hip_malloc(device, C.c_size_t(cbytes + 64)),
+                  "h_seqs": L.qzstd_hip_host_alloc(C.c_size_t(chunk_blocks * pitch * 16)),
+                  "h_cnt": L.qzstd_hip_host_alloc(C.c_size_t(chunk_blocks * 4)),
+                  "h_desc": L.qzstd_hip_host_alloc(C.c_size_t(chunk_blocks * C.sizeof(B.HipBlock)))}
+            assert all(ln.values()), plug.err()
+            desc = (B.HipBlock * chunk_blocks).from_address(ln["h_desc"])
+            for i in range(chunk_blocks):
+                desc[i].srcOff, desc[i].seqOff, desc[i].srcLen, desc[i].seqCap = i * block, i * pitch, block, pitch
+            ln["dv"] = [L.qzstd_hip_host_device_ptr(C.c_void_p(ln[k])) for k in ("h_seqs", "h_cnt", "h_desc")]
+            work = L.qzstd_hip_workspace_bytes(level, chunk_blocks, block)
+            ln["work"] = work
+            ln["d_work"] = L.qzstd_hip_malloc(device, C.c_size_t(work)) if work else None
+            lanes.append(ln)
+
+        def run_pass():
+            errs = seqs = 0
+            t0 = time.perf_counter()
+            for k in range(nchunks + depth):
+                ln = lanes[k % depth]
+                if k >= depth:  # the lane's previous chunk: wait, then its results are in host memory
+                    assert L.qzstd_hip_stream_wait(device, C.c_void_p(ln["stream"]), 20000) == 0, plug.err()
+                    cnt = (C.c_uint32 * chunk_blocks).from_address(ln["h_cnt"])
+                    for v in cnt:
+                        if v == B.NSEQ_ERROR:
+                            errs += 1
+                        else:
+                            seqs += v
+                if k < nchunks:
+                    rc = L.qzstd_hip_memcpy_h2d(device, C.c_void_p(ln["stream"]), C.c_void_p(ln["d_src"]),
+                                                C.c_void_p(h_in + k * cbytes), C.c_size_t(cbytes))
+                    rc = rc or L.qzstd_hip_find_sequences(device, C.c_void_p(ln["stream"]), level, C.c_void_p(ln["d_src"]),
+                                                          C.c_void_p(ln["dv"][2]), chunk_blocks, block, C.c_void_p(ln["dv"][0]),
+                                                          C.c_void_p(ln["dv"][1]), C.c_void_p(ln["d_work"]) if ln["d_work"] else None,
+                                                          C.c_size_t(ln["work"]))
+                    assert rc == 0, plug.err()
+            return time.perf_counter() - t0, errs, seqs
+
+        run_pass()  # warm-up
+        best, errs, seqs = None, 0, 0
+        tot = 0.0
+        for _ in range(passes):
+            dt, errs, seqs = run_pass()
+            tot += dt
+            best = dt if best is None else min(best, dt)
+        nbytes = nchunks * cbytes
+        return {"GBps_input_per_gpu": round(nbytes * passes / tot / 1e9, 2), "GBps_best_pass": round(nbytes / best / 1e9, 2),
+                "bytes_per_pass": nbytes, "chunk_blocks": chunk_blocks, "chunks_in_flight": depth, "passes": passes,
+                "result_bytes_per_pass": 16 * seqs, "dense_blocks_over_pitch": errs,
+                "what": "pinned host -> H2D -> kernel -> counts + sequences written by the kernel into pinned host memory; "
+                        "%d chunks of %d blocks in flight on separate streams" % (depth, chunk_blocks)}
+    except AssertionError as e:
+        return {"error": str(e)[:300]}
+    finally:
+        for ln in lanes:
+            for k in ("h_seqs", "h_cnt", "h_desc"):
+                if ln.get(k):
+                    L.qzstd_hip_host_free(C.c_void_p(ln[k]))
+            for k in ("d_src", "d_work"):
+                if ln.get(k):
+                    L.qzstd_hip_free(device, C.c_void_p(ln[k]))
+            if ln.get("stream"):
+                L.qzstd_hip_stream_destroy(device, C.c_void_p(ln["stream"]))
+        if h_in:
+            L.qzstd_hip_host_free(C.c_void_p(h_in))
 
 
 # ----------------------------------------------------------------------------- main
@@ -238,47 +382,82 @@ def main():
             "sequences_per_block": round(seq_total / max(nb - n_err, 1), 1), "error_blocks": n_err,
         }
         if not a.no_cpu and world == 1:  # CPU legs on rank 0 at N=1 only (bench contract)
-            ncpu = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_oracle_leg(shard, block, level, a.cpu_seconds)
-            # north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape,
-            # measured by the C tool in the same run on the host cores of this box
-            sample = shard[:min(len(shard), 512 * block)]
-            thr = min(ncpu, 16)  # <= QZ_DEFAULT_SLOTS_PER_DEVICE: one slot per thread
-            sw = c_benchmark(sample, block, level, thr, mode=0, loops=6)
-            out["cpu_libzstd_sw"] = {"lib": os.path.basename(B.find_libzstd()), "host_cores": ncpu, **sw}
-            # end to end through ZSTD_compress2 with the plugin registered: 4 MiB look-ahead hints (the GPU match-finds
-            # segment k+1 while the thread entropy-codes segment k) ...
-            e2e = c_benchmark(sample, block, level, thr, mode=1, hint=1, loops=6)
-            if "csize" in e2e and "csize" in sw:
-                e2e["csize_vs_sw"] = round(e2e["csize"] / sw["csize"], 4)
-                e2e["ratio_within_2pct"] = e2e["csize"] <= sw["csize"] * 1.02
-            out["e2e_zstd_compress2_plugin"] = e2e
-            # ... the same with ZSTD_c_searchForExternalRepcodes on (-E1) and the repeat-offset aware parse ...
-            rep = c_benchmark(sample, block, level, thr, mode=1, hint=16, ext_rep=1, loops=6,
-                              env={"QZSTD_HIP_EXT_REPCODES": "1"})
+            import tempfile
+            ncpu, quota = host_cpu_budget()
+            out["host"] = {"logical_cpus": ncpu, "usable_cores": round(quota, 1),
+                           "note": "a cgroup CPU quota caps what threads can add: past usable_cores, more threads only hide latency"}
+            build_tools()
+            out["pcie_pipeline"] = pcie_pipeline_leg(plug, shard, block, level, local)
+            out["cpu_oracle_port"] = cpu_oracle_leg(shard, block, level, min(a.cpu_seconds, 6.0))
+            # one sample file for every tool run (per-thread buffer, as the reference's benchmark reads one file per run)
+            sample = shard[:min(len(shard), 256 * block)]
+            with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+                f.write(sample)
+                fname = f.name
+            base_t = max(1, min(int(quota), 128))
+            # north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape, measured
+            # by the C tool in the same run on the host cores of this box — with the 1.5.x library the producer API needs
+            # and with the system's optimised 1.4.x (the 1.5.7 in this image is a slow build)
+            sw = c_benchmark(fname, block, level, base_t, mode=0, loops=6)
+            sw14 = c_benchmark(fname, block, level, base_t, mode=0, loops=8, tool="benchmark_sw")
+            out["cpu_libzstd_1_5"] = sw
+            out["cpu_libzstd_1_4"] = sw14
+            best_sw = max([x for x in (sw, sw14) if "MBps_wall" in x], key=lambda x: x["MBps_wall"], default=None)
+            if best_sw:
+                out["cpu_baseline"] = {"value": best_sw["MBps_wall"], "unit": "MB/s", "cores": base_t, "kind": "reference",
+                                       "sample": "libzstd %s own match-finder, plugin unregistered (the reference's software path, test/benchmark.c -m0 shape): "
+                                                 "%d threads x %d MiB x %d loops, one frame per %d KiB chunk, wall clock; the same with libzstd %s: %s MB/s"
+                                                 % (best_sw["libzstd"], base_t, len(sample) >> 20, best_sw["loops"], block >> 10,
+                                                    (sw if best_sw is sw14 else sw14).get("libzstd"), (sw if best_sw is sw14 else sw14).get("MBps_wall"))}
+            # end to end through ZSTD_compress2 with the plugin registered, thread sweep (wall clock AND sum of rates):
+            #   announced   QZSTD_hintSource 4 MiB ahead (-H4): the GPU match-finds segment k+1 while the thread entropy-codes k
+            #   plain       unchanged callers, library defaults: every block through the coalescer
+            #   lookahead   unchanged callers with the opt-in transparent look-ahead (QZSTD_HIP_LOOKAHEAD=1)
+            sweep = []
+            for t in sorted({base_t, 2 * base_t, min(4 * base_t, 128)}):
+                row = {"threads": t}
+                for name, kw in (("announced", dict(hint=4)), ("plain", {}), ("lookahead", dict(env={"QZSTD_HIP_LOOKAHEAD": "1"}))):
+                    r = c_benchmark(fname, block, level, t, mode=1, loops=6 if t <= base_t else 3, **kw)
+                    row[name] = {k: r.get(k) for k in ("MBps_wall", "MBps_sum_of_thread_rates", "csize", "latency_us_p50", "error") if k in r}
+                    if "csize" in r and "csize" in sw:
+                        row[name]["csize_vs_sw"] = round(r["csize"] / sw["csize"], 4)
+                sweep.append(row)
+            out["e2e_sweep"] = sweep
+            cands = [(row[n]["MBps_wall"], row["threads"], n) for row in sweep for n in ("announced", "plain", "lookahead") if row[n].get("MBps_wall")]
+            if cands:
+                v, t, n = max(cands)
+                out["value_e2e"] = {"value": v, "unit": "MB/s", "what": "input MB/s through ZSTD_compress2, plugin registered (%s callers), %d threads, "
+                                    "wall clock of the compression phase, level %d, %d KiB chunks, libzstd %s" % (n, t, level, block >> 10, sw.get("libzstd")),
+                                    "vs_cpu_libzstd_1_5": round(v / sw["MBps_wall"], 3) if sw.get("MBps_wall") else None,
+                                    "vs_cpu_libzstd_1_4": round(v / sw14["MBps_wall"], 3) if sw14.get("MBps_wall") else None,
+                                    "ratio_within_2pct": all(row[n2].get("csize_vs_sw", 1.0) <= 1.02 for row in sweep for n2 in ("announced", "plain"))}
+            # the batch front-end (include/qzstd_frontend.h): ONE buffer, a pool of CCtx threads, bytes / wall clock of the call
+            out["frontend"] = {"gpu": frontbench(fname, block, level, base_t, 1), "gpu_2x_threads": frontbench(fname, block, level, 2 * base_t, 1),
+                               "software": frontbench(fname, block, level, base_t, 0)}
+            # ... the announced path with ZSTD_c_searchForExternalRepcodes on (-E1) and the repeat-offset aware parse
+            rep = c_benchmark(fname, block, level, base_t, mode=1, hint=16, ext_rep=1, loops=4, env={"QZSTD_HIP_EXT_REPCODES": "1"})
             if "csize" in rep and "csize" in sw:
                 rep["csize_vs_sw"] = round(rep["csize"] / sw["csize"], 4)
-            out["e2e_zstd_compress2_plugin_repcodes"] = rep
-            # ... and for unchanged callers (no hints at all): the plugin's transparent look-ahead guesses that the bytes
-            # behind the current block come next (fault-safe read, verified when used); what misses goes per block
-            # through the coalescer
-            un = c_benchmark(sample, block, level, thr, mode=1, loops=6)
-            if "csize" in un and "csize" in sw:
-                un["csize_vs_sw"] = round(un["csize"] / sw["csize"], 4)
-            out["e2e_zstd_compress2_plugin_unchanged_callers"] = un
-            out["e2e_zstd_compress2_plugin_unchanged_callers_no_lookahead"] = c_benchmark(
-                sample[:128 * block], block, level, thr, mode=1, loops=4, env={"QZSTD_HIP_LOOKAHEAD": "0"})
-            # BASELINE config 3's level on the same framing: software level 6 vs the plugin (hash chains + repeat-offset
-            # aware parse, -E1), a quarter of the sample
+            out["e2e_announced_repcodes"] = rep
+            # BASELINE config 3's level on the same framing, libzstd defaults (no -E1): software level 6 vs the plugin
+            # (exact hash chains), a quarter of the sample; and config 4's: level 12 on 32 KiB chunks
             if level == 1:
-                s6 = sample[:len(sample) // 4]
-                sw6 = c_benchmark(s6, block, 6, thr, mode=0, loops=2)
-                p6 = c_benchmark(s6, block, 6, thr, mode=1, hint=16, ext_rep=1, loops=4, env={"QZSTD_HIP_EXT_REPCODES": "1"})
-                if "csize" in p6 and "csize" in sw6:
-                    p6["csize_vs_sw"] = round(p6["csize"] / sw6["csize"], 4)
-                    p6["speedup_vs_sw"] = round(p6["MBps"] / max(sw6["MBps"], 1e-9), 2)
-                out["level6_cpu_libzstd_sw"] = sw6
-                out["level6_e2e_plugin_repcodes"] = p6
+                with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+                    f.write(sample[:len(sample) // 4])
+                    f6 = f.name
+                for key, lv, blk in (("level6", 6, block), ("level12_32k", 12, 32768)):
+                    swl = c_benchmark(f6, blk, lv, base_t, mode=0, loops=1)
+                    sw14l = c_benchmark(f6, blk, lv, base_t, mode=0, loops=2, tool="benchmark_sw")
+                    pl = c_benchmark(f6, blk, lv, base_t, mode=1, hint=8, loops=2)
+                    if "csize" in pl and "csize" in swl:
+                        pl["csize_vs_sw"] = round(pl["csize"] / swl["csize"], 4)
+                        pl["ratio_within_2pct"] = pl["csize"] <= swl["csize"] * 1.02
+                        pl["speedup_vs_libzstd_1_5"] = round(pl["MBps_wall"] / max(swl["MBps_wall"], 1e-9), 2)
+                        if "MBps_wall" in sw14l:
+                            pl["speedup_vs_libzstd_1_4"] = round(pl["MBps_wall"] / max(sw14l["MBps_wall"], 1e-9), 2)
+                    out[key] = {"cpu_libzstd_1_5": swl, "cpu_libzstd_1_4": sw14l, "e2e_announced": pl}
+                os.unlink(f6)
+            os.unlink(fname)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

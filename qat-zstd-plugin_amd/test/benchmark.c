@@ -12,6 +12,8 @@
  * Written from scratch; one additive option:  -H<n>  announce each thread's buffer to the plugin
  * one segment ahead with QZSTD_hintSource(), so that the GPU match-finds segment k+1 in one batched
  * launch while this thread's libzstd entropy-codes segment k.
+ * -DQZ_SOFTWARE_ONLY builds the -m0 half alone, against any libzstd >= 1.4 (no producer API needed): the software
+ * baseline timed with an optimised system libzstd next to the 1.5.x the plugin needs.
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -20,6 +22,21 @@
 #include <time.h>
 
 #include "qatseqprod.h"
+
+#ifdef QZ_SOFTWARE_ONLY /* no plugin, no producer API: stand-ins that never run (mode is forced to 0) */
+static int swStart(void) { return 0; }
+static void swStop(void) {}
+static void *swState(void) { return NULL; }
+static void swFree(void *s) { (void)s; }
+static int swHint(void *s, const void *p, size_t n, size_t b, int l) { (void)s; (void)p; (void)n; (void)b; (void)l; return 0; }
+static void swRegister(ZSTD_CCtx *zc, void *st, void *fn) { (void)zc; (void)st; (void)fn; }
+#define QZSTD_startQatDevice swStart
+#define QZSTD_stopQatDevice swStop
+#define QZSTD_createSeqProdState swState
+#define QZSTD_freeSeqProdState swFree
+#define QZSTD_hintSource swHint
+#define ZSTD_registerSequenceProducer(zc, st, fn) swRegister(zc, st, NULL)
+#endif
 
 #define MB_BYTES 1000000.0 /* MB = 10^6 bytes, as in the reference (:56) */
 #define NBUCKETS 200
@@ -110,7 +127,7 @@ static void usage(const char *exe)
 {
     fprintf(stderr,
             "Usage: %s [options] file\n"
-            "  -t#   threads [1-128] (default 1)\n"
+            "  -t#   threads [1-1024] (default 1; the reference stops at 128)\n"
             "  -l#   loops [1-1000000] (default 1)\n"
             "  -c#   chunk size, K/M suffix allowed (default 32K)\n"
             "  -E#   searchForExternalRepcodes 0 auto, 1 enable, 2 disable (default auto)\n"
@@ -119,6 +136,8 @@ static void usage(const char *exe)
             "  -m#   0 software zstd, 1 GPU sequence producer (default 1)\n"
             "  -H#   look-ahead with QZSTD_hintSource: 1 = 4 MiB segments, n>1 = n MiB segments (default 0 = off)\n", exe);
 }
+
+static unsigned long gCompStartNs, gCompEndNs;
 
 static void *worker(void *arg)
 {
@@ -145,8 +164,13 @@ static void *worker(void *arg)
     }
     if (ok) {
         const int e = o->extRep == 1 ? ZSTD_ps_enable : (o->extRep == 2 ? ZSTD_ps_disable : ZSTD_ps_auto);
+#ifdef QZ_SOFTWARE_ONLY
+        (void)e; /* a parameter of zstd >= 1.5.4; it only matters for external sequences */
+        if (ZSTD_isError(ZSTD_CCtx_setParameter(zc, ZSTD_c_compressionLevel, (int)o->level))) {
+#else
         if (ZSTD_isError(ZSTD_CCtx_setParameter(zc, ZSTD_c_searchForExternalRepcodes, e)) ||
             ZSTD_isError(ZSTD_CCtx_setParameter(zc, ZSTD_c_compressionLevel, (int)o->level))) {
+#endif
             fprintf(stderr, "thread %u: cannot set parameters\n", w->id);
             ok = 0;
         }
@@ -161,6 +185,7 @@ static void *worker(void *arg)
     const size_t segBytes = segChunks * o->chunk;
     const int useHint = o->mode == 1 && o->hint && o->chunk % grid == 0 && (grid & 15) == 0 && segBytes <= ((size_t)16 << 20);
     pthread_barrier_wait(&gStart);
+    if (w->id == 0) gCompStartNs = nowNs(); /* wall clock of the compression phase: first barrier .. last thread done */
     for (unsigned l = 0; ok && l < o->loops; l++) {
         size_t off = 0, dpos = 0;
         if (useHint) { /* announce the first segment; later ones are announced one segment ahead */
@@ -196,6 +221,11 @@ static void *worker(void *arg)
             off += n;
         }
         total = dpos;
+    }
+    {
+        const unsigned long tEnd = nowNs();
+        unsigned long prev = __atomic_load_n(&gCompEndNs, __ATOMIC_RELAXED);
+        while (tEnd > prev && !__atomic_compare_exchange_n(&gCompEndNs, &prev, tEnd, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     }
     if (ok) { /* verify: decompress every frame back to back, compare with the source */
         size_t off = 0, dpos = 0;
@@ -251,7 +281,10 @@ int main(int argc, char **argv)
         default: usage(argv[0]); return a[1] == 'h' || a[1] == 'H' ? 0 : 1;
         }
     }
-    if (!file || o.threads < 1 || o.threads > 128 || o.loops < 1 || o.loops > 1000000 || o.chunk < 1 ||
+#ifdef QZ_SOFTWARE_ONLY
+    o.mode = 0;
+#endif
+    if (!file || o.threads < 1 || o.threads > 1024 || o.loops < 1 || o.loops > 1000000 || o.chunk < 1 ||
         o.level < 1 || o.level > 12 || o.mode > 1 || o.extRep > 2) {
         usage(argv[0]);
         return 1;
@@ -289,9 +322,12 @@ int main(int argc, char **argv)
         sumDec += ws[t].decompMBps;
     }
     const double wall = (double)(nowNs() - w0) / 1e9;
+    const double compWall = gCompEndNs > gCompStartNs ? (double)(gCompEndNs - gCompStartNs) / 1e9 : 0.0;
+    fprintf(stderr, "libzstd %s; ", ZSTD_versionString());
     fprintf(stderr, "%s level %u chunk %zu threads %u: aggregate compression %.1f MB/s (sum of per-thread rates), "
-                    "decompression %.1f MB/s, wall %.3f s\n", o.mode ? "GPU sequence producer" : "software zstd", o.level,
-            o.chunk, o.threads, sumComp, sumDec, wall);
+                    "%.1f MB/s by the wall clock of the compression phase (%.3f s), decompression %.1f MB/s, wall %.3f s\n",
+            o.mode ? "GPU sequence producer" : "software zstd", o.level, o.chunk, o.threads, sumComp,
+            compWall > 0 ? (double)o.srcSize * o.loops * o.threads / MB_BYTES / compWall : 0.0, compWall, sumDec, wall);
     if (gSamples)
         fprintf(stderr, "Latency (us): P25 %.1f  P50 %.1f  P75 %.1f  P99 %.1f  avg %.1f  min %.1f  max %.1f  (%lu calls)\n",
                 percentileNs(25) / 1e3, percentileNs(50) / 1e3, percentileNs(75) / 1e3, percentileNs(99) / 1e3,

@@ -366,3 +366,50 @@ def test_dense_block_is_redone_alone(mock, zstd, oracle):
     got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), 131072, 1)
     mock.lib.QZSTD_freeSeqProdState(st)
     assert got == oracle_frames(zstd, oracle, data, 131072, 1)
+
+
+def test_batch_front_end_over_the_mock(mock, zstd, oracle):
+    """include/qzstd_frontend.h: a pool of CCtx threads fed from one segment counter, every segment
+    announced one claim ahead; frames are the oracle's, every block comes from an announcement"""
+    front_so = os.path.join(ROOT, "tests", "mock", "libqzstdfront_mock.so")
+    subprocess.check_call(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-shared", "-fPIC", "-pthread",
+                           "-I" + os.path.join(ROOT, "include"), "-o", front_so,
+                           os.path.join(B.PKG_DIR, "frontend", "qzstd_frontend.c"), MOCK_SO, zstd.path,
+                           "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)])
+    F = C.CDLL(front_so)
+
+    class Params(C.Structure):
+        _fields_ = [("nThreads", C.c_int), ("level", C.c_int), ("chunkSize", C.c_size_t), ("segmentBytes", C.c_size_t),
+                    ("extRepcodes", C.c_int), ("useProducer", C.c_int)]
+
+    F.QZSTD_createFront.restype = C.c_void_p
+    F.QZSTD_createFront.argtypes = [C.POINTER(Params)]
+    F.QZSTD_frontFrameStride.restype = C.c_size_t
+    F.QZSTD_frontFrameStride.argtypes = [C.c_void_p]
+    F.QZSTD_frontCompress.restype = C.c_size_t
+    F.QZSTD_frontCompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    F.QZSTD_frontCompact.restype = C.c_size_t
+    F.QZSTD_frontCompact.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_size_t]
+    F.QZSTD_frontStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong)]
+    F.QZSTD_freeFront.argtypes = [C.c_void_p]
+    chunk = 65536
+    data = K.by_name("system", 37 * chunk + 1234)
+    for level, threads in ((1, 3), (6, 5)):
+        prm = Params(threads, level, chunk, 8 * chunk, 0, 1)
+        f = F.QZSTD_createFront(C.byref(prm))
+        assert f
+        stride = F.QZSTD_frontFrameStride(f)
+        n = (len(data) + chunk - 1) // chunk
+        dst = C.create_string_buffer(n * stride)
+        sizes = (C.c_size_t * n)()
+        for _ in range(2):  # the pool is persistent: a second job on the same front
+            assert F.QZSTD_frontCompress(f, data, len(data), dst, len(dst), sizes) == n
+        frames = [dst.raw[c * stride:c * stride + sizes[c]] for c in range(n)]
+        assert frames == oracle_frames(zstd, oracle, data, chunk, level)
+        st = (C.c_ulong * 2)()
+        F.QZSTD_frontStats(f, st)
+        assert st[0] == 2 * n and st[1] == 0, list(st)
+        total = F.QZSTD_frontCompact(f, dst, sizes, n)
+        assert total == sum(sizes) and dst.raw[:total] == b"".join(frames)
+        F.QZSTD_freeFront(f)
+    assert F.QZSTD_createFront(C.byref(Params(0, 1, chunk, 0, 0, 1))) is None

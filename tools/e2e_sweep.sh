@@ -1,22 +1,25 @@
 #!/bin/bash
-# End-to-end sweep of the C benchmark tool on a GPU box: software zstd vs the plugin, with and
-# without look-ahead hints.  Usage: tools/e2e_sweep.sh [MiB of corpus, default 64] [level, default 1]
-MB=${1:-64}; LV=${2:-1}
-cd "$(dirname "$0")/.."
-python - "$MB" <<'PY'
-import sys; sys.path.insert(0,'tools')
-import qz_corpus as K
-open('/tmp/corpus.bin','wb').write(K.by_name('system', int(sys.argv[1])<<20))
+# End-to-end sweep of the C benchmark tool on the GPU box: software vs plugin (unchanged callers, announcements,
+# opt-in transparent look-ahead) over thread counts.  Usage: tools/e2e_sweep.sh [MiB per thread, default 16] [level, default 1] [chunk]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+MB=${1:-16}; L=${2:-1}; C=${3:-131072}
+cd $R
+ZL=$(python - <<'PY'
+import sys; sys.path.insert(0, "tools"); import qz_bind as B; print(B.find_libzstd())
 PY
-Z=$(python -c "import sys; sys.path.insert(0,'tools'); import qz_bind as B; print(B.find_libzstd())")
-make -C qat-zstd-plugin_amd/test benchmark ZSTDLIB=$Z >/dev/null
-cd qat-zstd-plugin_amd/test
-echo "cores: $(nproc)"
-for T in 1 16 32; do
-  echo "== software zstd  t$T"; ./benchmark -m0 -t$T -l2 -c128K -L$LV /tmp/corpus.bin 2>&1 | tail -2
-done
-for H in 0 1 2 8 16; do
-  for T in 1 16 32; do
-    echo "== plugin H$H t$T"; ./benchmark -m1 -t$T -l2 -c128K -L$LV -H$H /tmp/corpus.bin 2>&1 | tail -2
+)
+make -C qat-zstd-plugin_amd/test benchmark ZSTDLIB=$ZL >/dev/null 2>&1
+python - <<PY
+import sys; sys.path.insert(0, "tools"); import qz_corpus as K
+open("/tmp/e2e.bin","wb").write(K.by_name("system", $MB << 20))
+PY
+BM=qat-zstd-plugin_amd/test/benchmark
+echo "nproc $(nproc) level $L chunk $C, $MB MiB per thread"
+for T in ${THREADS:-1 16 64 128 256}; do
+  for cfg in "sw:-m0" "plain:-m1" "hint:-m1 -H4" "la:-m1"; do
+    name=${cfg%%:*}; args=${cfg#*:}
+    env=""; [ $name = la ] && env="QZSTD_HIP_LOOKAHEAD=1"
+    out=$(env $env timeout 300 $BM $args -t$T -l${LOOPS:-2} -c$C -L$L /tmp/e2e.bin 2>&1 | grep "aggregate compression")
+    echo "T=$T $name: $(echo $out | sed 's/.*aggregate compression //; s/decompression.*//')"
   done
 done

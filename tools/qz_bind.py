@@ -17,7 +17,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(ROOT, "qat-zstd-plugin_amd")
-PLUGIN_SO = os.path.join(PKG_DIR, "lib", "libqatseqprod.so")
+PLUGIN_SO = os.environ.get("QZ_PLUGIN_SO") or os.path.join(PKG_DIR, "lib", "libqatseqprod.so")  # override: A/B kernel builds
 ORACLE_SO = os.path.join(ROOT, "oracle", "libqzstd_oracle.so")
 
 SEQ_ERROR = C.c_size_t(-1).value
