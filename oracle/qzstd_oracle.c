@@ -64,12 +64,12 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     /* levels 1-2: 6400 + no long table = 81.6 KB of LDS, two blocks per CU; levels 3-4: a bigger
      * table plus a second table keyed by 8 bytes (the double-fast idea of zstd's levels 3-4), one block per CU;
      * levels >= 5: exact hash chains (zstd: greedy / lazy / lazy2 / btlazy2 over a 4-byte hash), where the size
-     * of the head table hardly matters (a collision costs one chain step): 6400 again, two blocks per CU */
+     * of the head table hardly matters (a collision costs one chain step): 5888 entries, two blocks per CU */
     const int chains = level >= 5;
-    out->tableSize = chains ? 6400u : (level >= 3 ? 16000u : 6400u);
+    out->tableSize = chains ? 5888u : (level >= 3 ? 16000u : 6400u);
     out->longSize = (!chains && level >= 3) ? 8192u : 0u;
     out->tileLog = 9;
-    out->capLen = level >= 9 ? 128u : 64u;
+    out->capLen = level >= 9 ? 128u : (level >= 5 ? 64u : 48u);
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;

@@ -83,7 +83,7 @@ struct LaunchArgs {
     uint4 *seqs; /* ZSTD_Sequence = 4 x u32 */
     uint32_t *nseq;
     qzstd_hip_profile_t prof; /* the level's search profile (block-size independent) */
-    uint32_t *chain;          /* levels >= 6: per-block predecessor chains, chainStride words per block */
+    uint4 *chain;             /* levels >= 5: per-block chain entries (four links each), chainStride entries per block */
     uint32_t chainStride;
 #ifdef QZ_DEBUG_DUMP
     uint32_t dbg; /* profiling build only: ablation switches (QZSTD_HIP_ABLATE) */
@@ -171,6 +171,14 @@ __device__ __forceinline__ uint32_t rd32u(const Src &s, uint32_t a, bool far)
 {
     uint32_t D[2];
     load_dw<2>(s, a, far, D);
+    return __builtin_amdgcn_alignbyte(D[1], D[0], a & 3u);
+}
+
+/* the same with the ring offset r of position a already known */
+__device__ __forceinline__ uint32_t rd32_r(const Src &s, uint32_t a, uint32_t r, bool far)
+{
+    uint32_t D[2];
+    load_dw_r<2>(s, a, r, far, D);
     return __builtin_amdgcn_alignbyte(D[1], D[0], a & 3u);
 }
 
@@ -547,7 +555,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     uint32_t *nearTab = tblL + pf.longSize;
     uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
     uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kPvStride] per-position parse words         */
-    uint32_t *turnCtr = pv + 2u * kPvStride;           /* whose turn it is to update the tables (CHAIN)   */
+    uint32_t *turnCtr = pv + 2u * kPvStride;           /* whose turn it is to update the tables (TURNS)   */
+    uint32_t *slotTag = turnCtr + 16u;                 /* [kTile] (CHAIN) slot | tag << 16 of the tile's positions, for the insert wave */
     const uint8_t *gsrc = args.src + blk.srcOff;
     const uint4 *g128 = reinterpret_cast<const uint4 *>(gsrc);
     Src src;
@@ -595,6 +604,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 }
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
+                if (CHAIN) __syncthreads(); /* B1b: the matchers' insert step */
                 QZ_PLAP(pW1)
                 if (work) parse_rep_span(pf, src, pvT, base, base + kTile, n, nh, lane, st);
                 QZ_PLAP(pI2)
@@ -613,6 +623,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                                           k << kTileLog, n, lane, st);
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
+                if (CHAIN) __syncthreads(); /* B1b: the matchers' insert step */
                 QZ_PLAP(pW1)
                 if (work)
                     parse_tile<kSplit, kWin>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
@@ -689,6 +700,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             slot = __umulhi(mix, pf.tableSize);
             nslot = mix >> nearShift;
             if (!TURNS) old = tbl[slot]; /* with turns the slot is read when the wave's turn comes */
+            if (CHAIN) old = tbl[slot];  /* the slot before the tile: if no earlier position of this tile shares it, that IS the predecessor */
             if (pf.nearTab) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
             if (validL) { /* second table, keyed by the first 8 bytes */
                 const uint32_t m8 = (v * kPrime1) ^ (oa[1] * kPrime2);
@@ -696,6 +708,13 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 tagL = (m8 >> 3) & kTagMask;
                 if (!TURNS) oldL = tblL[slotL];
             }
+        }
+        uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+        if (CHAIN) {
+            /* the chain entry of that probable predecessor, fetched now so that it is there when the inserts are done (a
+             * position of an earlier tile: its entry was stored at least one barrier ago) */
+            if (valid && old != 0u) pre = (args.chain + (size_t)blockIdx.x * args.chainStride)[(old >> kTagBits) - 1u];
+            slotTag[tid] = valid ? (slot | (((mix >> 3) & kTagMask) << 16)) : kNone;
         }
         QZ_LAP(dI1)
         __syncthreads(); /* B1 */
@@ -710,67 +729,137 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         offB = offA; lenB = lenA;
         uint32_t cl = 0, off = 0; /* capped candidate length, offset */
         if (CHAIN) {
-            /* Levels >= 5: exact hash chains (oracle: qzo_candidates_chain).  The waves take turns in position order;
-             * at its turn a wave reads its slots (newest earlier position + 1, with that position's tag), inserts
-             * its own positions (ds_max: the newest wins), and orders the positions that share a slot INSIDE the
-             * wave with ballots, so every position gets its exact predecessor.  The links of the current tile
-             * stay in LDS (chainT: later waves of this tile may walk them at once); all links also go to device
-             * memory (chainB), where later tiles find them (ordered by the barriers in between). */
-            uint32_t *chainB = args.chain + (size_t)blockIdx.x * args.chainStride;
-            uint32_t *chainT = nearTab; /* [kTile] links of the tile in progress */
+            /* Levels >= 5: exact hash chains (oracle: qzo_candidates_chain): every position gets its exact predecessor in
+             * its slot, and walks chainDepth links from there.
+             *  - INSERT.  One wave (wave 0) updates the head table for the whole tile, window by window: read the slot,
+             *    ds_max the own entry, read the slot back.  LDS operations of one wave execute in order, so the eight
+             *    windows are pipelined back to back and still see each other exactly as sequential inserts would; no
+             *    hand-over between waves.  Positions of one window that share a slot are ordered with ballots (the
+             *    read-back differs from the own entry for all but the newest of them).  Result: P1T[i] = predecessor
+             *    entry ((position + 1) << 14 | tag, 0 = none) of position t0 + i.
+             *  - CHAIN ENTRIES hold up to FOUR links (predecessor, its predecessor, ...), so a walk needs a dependent
+             *    load only every fourth link.  The entry of p = {P1} + the first three links of P1's entry: prefetched in
+             *    interval 1 when P1 lies in an earlier tile; hopped together from P1T when it lies in this tile (an
+             *    entry may then be shorter than four — the walk simply continues from its last link).  Entries go to
+             *    device memory (args.chain, 16 B per position); later tiles find them there. */
+            uint4 *chainB = args.chain + (size_t)blockIdx.x * args.chainStride;
+            uint32_t *P1T = nearTab; /* [kTile] */
             const uint32_t tag = (mix >> 3) & kTagMask;
-            const uint32_t mine = ((p + 1u) << kTagBits) | tag;
-            const uint32_t turn = it * (uint32_t)kMatchWaves + wave;
-            uint32_t spins = 0, predE = 0;
-            while (__hip_atomic_load(turnCtr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != turn && ++spins < (1u << 22))
-                __builtin_amdgcn_s_sleep(1);
-            if (valid) {
-                predE = tbl[slot];
-                atomicMax(&tbl[slot], mine);
-            }
-            {
-                /* lanes that are not the newest of their slot in this window have a same-slot lane above them */
-                const uint32_t fin = valid ? __hip_atomic_load(&tbl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : mine;
-                u64 rem = __ballot(fin != mine);
-                while (rem) {
-                    const uint32_t s0 = rdlane(slot, (uint32_t)__builtin_ctzll(rem));
-                    const bool in = valid && slot == s0;
-                    const u64 grp = __ballot(in);
-                    const u64 lower = grp & below(lane);
-                    const uint32_t e = (uint32_t)__shfl((int)mine, lower ? 63 - __builtin_clzll(lower) : (int)lane);
-                    if (in && lower) predE = e; /* the nearest lower lane of the group */
-                    rem &= ~grp;
+            if (wave == 0u) {
+                uint32_t stv[kWin], prd[kWin], fin[kWin];
+#pragma unroll
+                for (uint32_t k = 0; k < kWin; k++) stv[k] = slotTag[64u * k + lane];
+#pragma unroll
+                for (uint32_t k = 0; k < kWin; k++) {
+                    const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
+                    prd[k] = 0u;
+                    fin[k] = mineK;
+                    if (stv[k] != kNone) {
+                        uint32_t *e = &tbl[stv[k] & 0xFFFFu];
+                        prd[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        atomicMax(e, mineK);
+                        fin[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < kWin; k++) {
+                    const bool vk = stv[k] != kNone;
+                    const uint32_t slotK = stv[k] & 0xFFFFu;
+                    const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
+                    /* lanes that are not the newest of their slot in this window have a same-slot lane above them */
+                    u64 rem = __ballot(fin[k] != mineK);
+                    uint32_t predLane = lane;
+                    while (rem) {
+                        const uint32_t s0 = rdlane(slotK, (uint32_t)__builtin_ctzll(rem));
+                        const bool in = vk && slotK == s0;
+                        const u64 grp = __ballot(in);
+                        const u64 lower = grp & below(lane);
+                        if (in && lower) predLane = 63u - (uint32_t)__builtin_clzll(lower); /* the nearest lower lane of the group */
+                        rem &= ~grp;
+                    }
+                    const uint32_t fromLane = (uint32_t)__shfl((int)mineK, (int)predLane);
+                    P1T[64u * k + lane] = vk ? (predLane != lane ? fromLane : prd[k]) : 0u;
                 }
             }
-            chainT[tid] = valid ? predE : 0u;
-            if (lane == 0u) __hip_atomic_store(turnCtr, turn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (valid) chainB[p] = predE;
+            __syncthreads(); /* B1b */
+            /* the entry of the own position */
+            uint32_t E[4] = { 0u, 0u, 0u, 0u };
+            if (valid) {
+                E[0] = P1T[tid];
+                if (E[0] != 0u && (E[0] >> kTagBits) - 1u < t0) { /* predecessor in an earlier tile: == `old`, whose entry is here */
+                    E[1] = pre.x; E[2] = pre.y; E[3] = pre.z;
+                } else {
+#pragma unroll
+                    for (int i = 1; i < 4; i++) { /* hop inside the tile */
+                        const uint32_t q = (E[i - 1] >> kTagBits) - 1u;
+                        if (E[i - 1] == 0u || q < t0) break;
+                        E[i] = P1T[q - t0];
+                    }
+                }
+                chainB[p] = make_uint4(E[0], E[1], E[2], E[3]);
+            }
             /* the walk: chainDepth links, newest first; a link whose tag differs is a slot collision (skipped without
              * touching its bytes); the candidate with the highest gain stays, the nearer one on a tie */
             const uint32_t cap = valid ? umin(pf.capLen, n - p) : 0u;
-            uint32_t linkE = valid ? predE : 0u;
+            uint32_t walked = 0;
             int bg = 0;
-            for (uint32_t d = 0; d < pf.chainDepth; d++) {
-                if (!__ballot(linkE != 0u)) break;
-                if (linkE != 0u) {
-                    const uint32_t q = (linkE >> kTagBits) - 1u;
-                    const bool hit = (linkE & kTagMask) == tag && (pf.window == 0u || p - q <= pf.window);
-                    linkE = q >= t0 ? chainT[q - t0] : chainB[q]; /* next link: in flight during the compare */
-                    if (hit && !QZ_ABLATED(2u)) {
-                        const bool far = p - q > kNear;
-                        uint32_t l = head_len(src, oa, q, ring_back(rp, p - q), far);
-                        if (l == 16u && cap > 16u) {
-                            for (;;) {
-                                const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q, far);
-                                l += c;
-                                if (c < 32u || l >= cap) break;
+            while (__ballot(E[0] != 0u)) {
+                uint32_t N[4] = { 0u, 0u, 0u, 0u };
+                if (E[0] != 0u) {
+                    /* the entry behind the last link of this one: in flight during the compares */
+                    const uint32_t last = E[3] ? E[3] : (E[2] ? E[2] : (E[1] ? E[1] : E[0]));
+                    const uint32_t ql = (last >> kTagBits) - 1u;
+                    const uint32_t cnt = E[3] ? 4u : (E[2] ? 3u : (E[1] ? 2u : 1u));
+                    if (walked + cnt < pf.chainDepth) {
+                        if (ql < t0) {
+                            const uint4 v = chainB[ql];
+                            N[0] = v.x; N[1] = v.y; N[2] = v.z; N[3] = v.w;
+                        } else {
+                            N[0] = P1T[ql - t0];
+#pragma unroll
+                            for (int i = 1; i < 4; i++) {
+                                const uint32_t q = (N[i - 1] >> kTagBits) - 1u;
+                                if (N[i - 1] == 0u || q < t0) break;
+                                N[i] = P1T[q - t0];
                             }
                         }
-                        l = umin(l, cap);
-                        const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
-                        if (l >= 4u && (cl == 0u || g > bg)) { cl = l; off = p - q; bg = g; }
                     }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t linkE = E[k];
+                        if (linkE != 0u && walked + (uint32_t)k < pf.chainDepth) {
+                            const uint32_t q = (linkE >> kTagBits) - 1u;
+                            const bool hit = (linkE & kTagMask) == tag && (pf.window == 0u || p - q <= pf.window);
+                            bool maybe = hit && !QZ_ABLATED(2u);
+                            const bool far = p - q > kNear;
+                            if (maybe && cl != 0u) {
+                                /* links come nearest first, so a later one can only win with MORE matching bytes than the best so
+                                 * far (its offset costs at least as much): it has to match at byte cl, in particular.  Four bytes
+                                 * ending there are compared before anything else (what zstd's chain search does too); a best
+                                 * that already fills the cap cannot be beaten at all.  Skips most of the full compares. */
+                                maybe = cl < cap &&
+                                        rd32_r(src, p + cl - 3u, ring_fwd(rp, cl - 3u), false) ==
+                                            rd32_r(src, q + cl - 3u, ring_fwd(ring_back(rp, p - q), cl - 3u), far);
+                            }
+                            if (maybe) {
+                                uint32_t l = head_len(src, oa, q, ring_back(rp, p - q), far);
+                                if (l == 16u && cap > 16u) {
+                                    for (;;) {
+                                        const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q, far);
+                                        l += c;
+                                        if (c < 32u || l >= cap) break;
+                                    }
+                                }
+                                l = umin(l, cap);
+                                const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
+                                if (l >= 4u && (cl == 0u || g > bg)) { cl = l; off = p - q; bg = g; }
+                            }
+                        }
+                    }
+                    walked += cnt;
                 }
+#pragma unroll
+                for (int k = 0; k < 4; k++) E[k] = N[k];
             }
         } else {
         if (TURNS) {
@@ -1134,8 +1223,8 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (a.prof.chainDepth) {
         const size_t need = qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen);
         if (!d_work || workBytes < need) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
-        a.chain = static_cast<uint32_t *>(d_work);
-        a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint32_t));
+        a.chain = static_cast<uint4 *>(d_work);
+        a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
     }
     a.src = static_cast<const uint8_t *>(d_src);
     a.blocks = d_blocks;

@@ -30,13 +30,13 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
      * levels 3-4: 16000 entries + a second table keyed by 8 bytes (the double-fast idea of zstd's
      * levels 3-4) = 152.8 KB -> one block per CU;
      * levels >= 5: exact hash chains over a 4-byte hash (zstd: greedy / lazy / lazy2 / btlazy2); the size of the
-     * head table hardly matters there (a collision costs one chain step): 6400 again -> two blocks per CU */
+     * head table hardly matters there (a collision costs one chain step): 5888 entries -> two blocks per CU */
     {
         const int chains = level >= 5;
-        out->tableSize = chains ? 6400u : (level >= 3 ? 16000u : 6400u);
+        out->tableSize = chains ? 5888u : (level >= 3 ? 16000u : 6400u);
         out->longSize = (!chains && level >= 3) ? 8192u : 0u;
         out->tileLog = 9;
-        out->capLen = level >= 9 ? 128u : 64u;
+        out->capLen = level >= 9 ? 128u : (level >= 5 ? 64u : 48u); /* levels 1-4: one 32-byte step after the 16-byte head; capped matches are extended when taken */
         out->minMatch = 4;
         out->farLog1 = 12;
         out->farLog2 = 16;
@@ -64,12 +64,12 @@ size_t qzstd_hip_sequence_bound(size_t srcSize)
     return srcSize / 3 + 1 + srcSize / 1024 + 1;
 }
 
-/* device scratch of one launch: the predecessor chains of levels >= 6, 4 B per position of every block */
+/* device scratch of one launch: the chain entries of levels >= 5, 16 B (four links) per position of every block */
 size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockLen)
 {
     qzstd_hip_profile_t p;
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX || qzstd_hip_profile_for_level(level, maxBlockLen, &p) || !p.chainDepth) return 0;
-    return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * sizeof(uint32_t);
+    return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * 16u; /* four links per position */
 }
 
 #define QZ_RING_BYTES (49152u + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip) */
@@ -86,6 +86,7 @@ size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
            + (4u << p.tileLog)     /* tile-local near table / the current tile's chain links (levels >= 5) */
            + 2u * ((4u << p.tileLog) + 32u) /* per-position parse words (+ override spill), 2 tiles in flight */
            + 2u * ((1u << p.tileLog) >> 6) * 32u /* per-window emission records, x2 */
+           + (p.chainDepth ? (4u << p.tileLog) : 0u) /* chain levels: slot | tag of the tile's positions, for the insert wave */
            + QZ_LDS_CTRL;
     return need <= QZ_LDS_MAX ? need : 0;
 }
