@@ -106,6 +106,8 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 below(uint32_t c) { return c >= 64u ? ~0ull : ((1ull << c) - 1ull); }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return umax(umax(a, b), c); }
 
 /* where the block's bytes can be read from: the LDS ring (recent bytes) or HBM (anything) */
 /* explicit address spaces: through generic pointers the compiler falls back to FLAT loads for the ring */
@@ -369,7 +371,8 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
  * the equality bitmap of the next 64 bytes, and the match length at position cursor+k is the run of ones from bit k,
  * capped at kRepCap = 32.  The first position whose best option is not beaten by the next one (by more than 4
  * quarter bytes of gain) or the one after (by more than 11) is taken; a window without any option is skipped.
- * Per position the matchers leave   capped length (bits 0-7) | offset (bits 8-24); bit 31 stays clear (kChosenBit).
+ * Per position the matchers leave   hash gain (bits 0-9, 0 = no usable candidate) | offset (bits 10-26); bit 31 stays clear
+ * (kChosenBit).
  * Every chosen match is written back over the parse words of its first three positions (behind the
  * cursor: dead) as {offset, length, index, literal anchor} for the emitting wave: no masks, no ranks.
  */
@@ -389,7 +392,9 @@ __device__ __forceinline__ uint32_t ring_byte(const Src &s, uint32_t x, bool far
     return reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(s.ring)[umin(m, m - kRing)];
 }
 
-/* equality bitmap of the 64 bytes from `cur` against the bytes `rp` back (0 when rp == 0): bit b = byte cur+b matches */
+/* equality bitmap of the 64 bytes from `cur` against the bytes `rp` back (0 when rp == 0): bit b = byte cur+b matches.
+ * General form (any offset, sources beyond the ring's reach come from HBM); the parse loop below only uses it when one of
+ * the repeats is farther back than the ring holds */
 __device__ __forceinline__ u64 rep_bitmap(const Src &src, uint32_t cur, uint32_t rp, uint32_t n, uint32_t lane)
 {
     const uint32_t bpos = cur + lane;
@@ -398,8 +403,18 @@ __device__ __forceinline__ u64 rep_bitmap(const Src &src, uint32_t cur, uint32_t
     return __ballot(eq);
 }
 
+/* scalar x mod kRing for x < 3 * kRing (kept in SGPRs by the parse wave) */
+__device__ __forceinline__ uint32_t ring_off_s(uint32_t a)
+{
+    const uint32_t m = umin(a, a - kRing);
+    return umin(m, m - kRing);
+}
+
 /* parse from the cursor up to `limit` (a window boundary inside the tile that starts at `base`): one window
- * evaluation per iteration, state in SGPRs */
+ * evaluation per iteration, state in SGPRs.  Everything an iteration reads from LDS — the window's parse words, the 64 bytes
+ * from the cursor and the bytes one repeat-1 / repeat-2 offset before them — is fetched up front in ONE round trip
+ * (addresses depend on the scalars only), the run lengths come from the two ballots with a funnel shift + ffbl, the hash
+ * gains were computed by the matcher waves (G in the low 10 bits of the word). */
 __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, const Src &src, uint32_t *pvT,
                                                uint32_t base, uint32_t limit, uint32_t n, uint32_t nh, uint32_t lane,
                                                RepState &st)
@@ -408,23 +423,31 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
     while (st.cur < stop) {
         const uint32_t W = umin(pf.repWin, tileLim - st.cur), V = umin(W + 2u, tileLim - st.cur);
         uint32_t wd = 0;
-        if (lane < V) wd = pvT[st.cur + lane - base]; /* the candidate of the window position */
-        const u64 M1 = rep_bitmap(src, st.cur, st.rep1, n, lane);
-        const u64 M2 = rep_bitmap(src, st.cur, st.rep2, n, lane);
-        uint32_t rl1 = 0, rl2 = 0;
-        if (lane < V) {
-            /* bit kRepCap set: the run is counted up to the cap only (and ctz never sees 0) */
-            const u64 z1 = ~(M1 >> lane) | (1ull << kRepCap), z2 = ~(M2 >> lane) | (1ull << kRepCap);
-            rl1 = (uint32_t)__builtin_ctzll(z1);
-            rl2 = (uint32_t)__builtin_ctzll(z2);
+        if (lane < V) wd = pvT[st.cur + lane - base]; /* the candidate of the window position: gain | offset << 10 */
+        u64 M1, M2;
+        if (st.rep1 <= kNear && st.rep2 <= kNear) { /* the usual case: both sources inside the ring */
+            const uint32_t rc = rdfirst(ring_off_s(st.cur));
+            const uint32_t r1 = rdfirst(ring_off_s(st.cur - st.rep1)), r2 = rdfirst(ring_off_s(st.cur - st.rep2)); /* offsets never reach before the block */
+            uint32_t oa = rc + lane, o1 = r1 + lane, o2 = r2 + lane;
+            oa = umin(oa, oa - kRing); o1 = umin(o1, o1 - kRing); o2 = umin(o2, o2 - kRing);
+            const __attribute__((address_space(3))) uint8_t *rb = reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(src.ring);
+            const uint32_t A = rb[oa], B1 = rb[o1], B2 = rb[o2]; /* three byte loads, one wait */
+            const bool inBlock = lane < n - st.cur;
+            M1 = __ballot(inBlock && st.rep1 != 0u && A == B1);
+            M2 = __ballot(inBlock && st.rep2 != 0u && A == B2);
+        } else {
+            M1 = rep_bitmap(src, st.cur, st.rep1, n, lane);
+            M2 = rep_bitmap(src, st.cur, st.rep2, n, lane);
         }
+        /* run of ones from bit `lane`, counted up to the cap: lanes < 18 always have 32 bits of look-ahead in the low
+         * word of the shifted bitmap (funnel shift), ffbl of an all-ones word gives -1 -> the cap */
+        const uint32_t x1 = __builtin_amdgcn_alignbit((uint32_t)(M1 >> 32), (uint32_t)M1, lane);
+        const uint32_t x2 = __builtin_amdgcn_alignbit((uint32_t)(M2 >> 32), (uint32_t)M2, lane);
+        const uint32_t rl1 = umin(first_diff_bit(~x1), kRepCap), rl2 = umin(first_diff_bit(~x2), kRepCap);
         const uint32_t rg1 = rl1 < kRepMin ? 0u : (rl1 >= kRepCap ? 1000u : 4u * rl1 + 36u);
         const uint32_t rg2 = rl2 < kRepMin ? 0u : (rl2 >= kRepCap ? 999u : 4u * rl2 + 35u);
-        const uint32_t cl = wd & 0xFFu, co = wd >> 8;
-        uint32_t G = 0, opt = 0;
-        if (cl != 0u && cl >= min_len(pf, co)) G = 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(co + 1u));
-        if (rg1 > G) { G = rg1; opt = 1u; }
-        if (rg2 > G) { G = rg2; opt = 2u; }
+        const uint32_t Gh = wd & 0x3FFu;
+        const uint32_t G = lane < V ? umax3(Gh, rg1, rg2) : 0u;
         /* the gains one and two positions on: whole-wave DPP shifts (lane i reads lane i+1); lanes >= V hold 0 */
         const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x130, 0xF, 0xF, true);
         const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G1, 0x130, 0xF, 0xF, true);
@@ -435,16 +458,20 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
             continue;
         }
         const uint32_t ks = (uint32_t)__builtin_ctzll(m);
-        const uint32_t o = rdlane(opt, ks);
+        const uint32_t gh = rdlane(Gh, ks), g1 = rdlane(rg1, ks), g2 = rdlane(rg2, ks);
         const uint32_t q = st.cur + ks;
         uint32_t off, L, from;
-        if (o == 0u) {
-            off = rdlane(co, ks);
-            L = rdlane(cl, ks);
+        if (g1 <= gh && g2 <= gh) { /* the candidate (a repeat has to gain strictly more) */
+            off = rdlane(wd, ks) >> 10;
+            L = (gh - 32u + (31u - (uint32_t)__builtin_clz(off + 1u))) >> 2; /* the gain holds the length: 4 len + 32 - bits(offset) */
             from = pf.capLen;
+        } else if (g2 > umax(gh, g1)) {
+            off = st.rep2;
+            L = rdlane(rl2, ks);
+            from = kRepCap;
         } else {
-            off = o == 1u ? st.rep1 : st.rep2;
-            L = rdlane(o == 1u ? rl1 : rl2, ks);
+            off = st.rep1;
+            L = rdlane(rl1, ks);
             from = kRepCap;
         }
         if (L == from) L = extend_match(src, q, off, from, umin(n, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
@@ -959,7 +986,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             const u64 rest = endj < 64u ? startMask >> endj : 0ull;
             uint32_t nx = endj >= 64u ? endj : (rest ? endj + (uint32_t)__builtin_ctzll(rest) : 64u);
             nx = capped ? kNxCapped : nx;
-            pv[(it & 1u) * kPvStride + tid] = REP ? (cl | (off << 8)) : pack_pos(nx, ns, capped ? off : cl);
+            /* REP: the hash gain (0 = no usable candidate; 4 len + 32 - bits(offset) < 1024) | offset << 10; bit 31 stays clear */
+            const uint32_t gRep = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
+            pv[(it & 1u) * kPvStride + tid] = REP ? (gRep | (off << 10)) : pack_pos(nx, ns, capped ? off : cl);
         }
         offA = off;
         lenA = cl;

@@ -11,8 +11,13 @@ def main():
     sizes = [int(a) for a in sys.argv[1:]] or [600, 1500, 3000, 9000, 131072]
     corpus = os.environ.get("QZ_CORPUS", "text")
     off0 = int(os.environ.get("QZ_OFFSET", "0"))
+    degen = [bytes(131072), b"\xff" * 70000, b"ab" * 50000, b"abc" * 40000, (b"0123456789" * 13108)[:131072],
+             bytes(range(256)) * 512, b"x" + bytes(5000), K.incompressible(9, 131072),
+             (b"abcdefgh" * 5 + b"X") * 3000, b"".join(b"record%05d;" % (i % 97) + bytes(53) for i in range(2000))]
     if corpus == "records":
-        base = b"".join(b"record%05d;" % (i % 97) + bytes(53) for i in range(2000))
+        base = degen[9]
+    elif corpus.startswith("degen"):
+        base = degen[int(corpus[5:])]
     else:
         base = K.by_name(corpus, off0 + 140000)[off0:]
     for n in sizes:
