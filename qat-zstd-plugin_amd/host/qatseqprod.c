@@ -1098,15 +1098,7 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
         if (work) sl->dBatchWork = qzGrowDev(sl->device, sl->dBatchWork, &sl->dBatchWorkCap, work);
         if (work && !sl->dBatchWork) goto fail;
     }
-    for (b = b0; b < b1; b++) {
-        const size_t o = b * h->block;
-        h->hDesc[b].srcOff = o - o0; /* relative to this part's device buffer */
-        /* results go straight into the pinned buffer, QZ_HINT_PITCH entries per block: a block with more
-         * sequences reports an error and is redone by the per-block path when its callback comes */
-        h->hDesc[b].seqOff = b * QZ_HINT_PITCH;
-        h->hDesc[b].srcLen = (unsigned int)(h->size - o < h->block ? h->size - o : h->block);
-        h->hDesc[b].seqCap = (unsigned int)(qzstd_hip_sequence_bound(h->block) < QZ_HINT_PITCH ? qzstd_hip_sequence_bound(h->block) : QZ_HINT_PITCH);
-    }
+    for (b = b0; b < b1; b++) h->hDesc[b].srcOff = b * h->block - o0; /* relative to this part's device buffer */
     /* everything below is queued on the slot's stream and returns immediately */
     if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc + o0, bytes) ||
         qzstd_hip_find_sequences(sl->device, sl->stream, level, sl->dBatchSrc, (const qzstd_hip_block_t *)h->dvDesc + b0,
@@ -1168,6 +1160,21 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     h->block = blockSize;
     h->level = compressionLevel;
     h->nb = nb;
+    {
+        /* descriptors of every block (also of ranges that cannot be queued: the callbacks' grid arithmetic reads them).
+         * Results go straight into the pinned buffer, QZ_HINT_PITCH entries per block: a block with more sequences
+         * reports an error and is redone by the per-block path when its callback comes */
+        const size_t bound = qzstd_hip_sequence_bound(blockSize);
+        size_t b;
+        for (b = 0; b < nb; b++) {
+            const size_t o = b * blockSize;
+            h->hDesc[b].srcOff = o;
+            h->hDesc[b].seqOff = b * QZ_HINT_PITCH;
+            h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
+            h->hDesc[b].seqCap = (unsigned int)(bound < QZ_HINT_PITCH ? bound : QZ_HINT_PITCH);
+            h->hCount[b] = QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
+        }
+    }
     /* contiguous block ranges, one per GPU, starting at this state's own GPU; a range is worth a launch from 4 blocks */
     parts = speculative ? 1 : gProc.split;
     if ((size_t)parts > nb / 4) parts = nb / 4 ? (int)(nb / 4) : 1;
