@@ -42,7 +42,7 @@ static void swRegister(ZSTD_CCtx *zc, void *st, void *fn) { (void)zc; (void)st; 
 #define NBUCKETS 200
 
 typedef struct {
-    unsigned threads, loops, level, mode, extRep, hint, split;
+    unsigned threads, loops, level, mode, extRep, hint, split, fallback;
     size_t chunk;
     const unsigned char *src;
     size_t srcSize;
@@ -134,6 +134,7 @@ static void usage(const char *exe)
             "  -S#   ZSTD_c_blockSplitterLevel (zstd >= 1.5.7): 0 auto, 1 = blocks of multi-block frames stay 128 KiB\n"
             "  -L#   compression level [1-12] (default 1)\n"
             "  -m#   0 software zstd, 1 GPU sequence producer (default 1)\n"
+            "  -F#   1 = ZSTD_c_enableSeqProducerFallback (producer errors fall back to libzstd's own match-finder)\n"
             "  -H#   look-ahead with QZSTD_hintSource: 1 = 4 MiB segments, n>1 = n MiB segments (default 0 = off)\n", exe);
 }
 
@@ -175,6 +176,9 @@ static void *worker(void *arg)
             ok = 0;
         }
         if (ok && o->split) (void)ZSTD_CCtx_setParameter(zc, ZSTD_c_blockSplitterLevel, (int)o->split); /* older zstd: ignored */
+#ifndef QZ_SOFTWARE_ONLY
+        if (ok && o->fallback && o->mode == 1) (void)ZSTD_CCtx_setParameter(zc, ZSTD_c_enableSeqProducerFallback, 1);
+#endif
     }
     /* look-ahead: segments of -H MiB (1 -> 4 MiB), a whole number of chunks, on libzstd's block grid */
     /* frames of several blocks: libzstd 1.5.7 cuts them into 32..128 KiB blocks unless -S1 keeps them at 128 KiB;
@@ -264,7 +268,7 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-    Options o = { 1, 1, 1, 1, 0, 0, 0, 32 * 1024, NULL, 0 };
+    Options o = { 1, 1, 1, 1, 0, 0, 0, 0, 32 * 1024, NULL, 0 };
     const char *file = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -278,6 +282,7 @@ int main(int argc, char **argv)
         case 'm': o.mode = (unsigned)atoi(a + 2); break;
         case 'H': o.hint = (unsigned)atoi(a + 2); break;
         case 'S': o.split = (unsigned)atoi(a + 2); break;
+        case 'F': o.fallback = (unsigned)atoi(a + 2); break;
         default: usage(argv[0]); return a[1] == 'h' || a[1] == 'H' ? 0 : 1;
         }
     }
