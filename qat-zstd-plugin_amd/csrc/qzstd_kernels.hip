@@ -1149,7 +1149,10 @@ int qzstd_hip_stream_wait(int device, void *stream, unsigned timeoutMs)
 {
     QZ_SET_DEVICE(device);
     /* poll instead of hipStreamSynchronize: a wedged kernel must not take the calling thread with it.  Busy polls for
-     * the first 200 us (the latency of a small request), then yields, then naps */
+     * the first QZSTD_HIP_SPIN_US microseconds (default 50), then naps between polls so
+     * that a waiting caller does not burn a core other callers could entropy-code on (QZSTD_HIP_NAP_US, default 20) */
+    static const long long spinUs = [] { const char *v = getenv("QZSTD_HIP_SPIN_US"); return v ? atoll(v) : 50ll; }();
+    static const long napNs = [] { const char *v = getenv("QZSTD_HIP_NAP_US"); return (v ? atol(v) : 20l) * 1000l; }();
     struct timespec t0, t;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (;;) {
@@ -1162,9 +1165,9 @@ int qzstd_hip_stream_wait(int device, void *stream, unsigned timeoutMs)
             snprintf(g_err, sizeof(g_err), "stream still busy after %u ms", timeoutMs);
             return 1;
         }
-        if (us < 200) continue;
-        if (us < 5000) sched_yield();
-        else { const struct timespec nap = { 0, 100000 }; nanosleep(&nap, nullptr); }
+        if (us < spinUs) continue;
+        if (napNs <= 0) sched_yield();
+        else { const struct timespec nap = { 0, us < 20000 ? napNs : 200000l }; nanosleep(&nap, nullptr); }
     }
 }
 
