@@ -431,13 +431,15 @@ def main():
                                     "vs_cpu_libzstd_1_5": round(v / sw["MBps_wall"], 3) if sw.get("MBps_wall") else None,
                                     "vs_cpu_libzstd_1_4": round(v / sw14["MBps_wall"], 3) if sw14.get("MBps_wall") else None,
                                     "ratio_within_2pct": all(row[n2].get("csize_vs_sw", 1.0) <= 1.02 for row in sweep for n2 in ("announced", "plain"))}
-            # the batch front-end (include/qzstd_frontend.h): ONE big buffer (a quarter of the batch), a pool of CCtx threads fed
+            # the batch front-end (include/qzstd_frontend.h): ONE big buffer (half of the batch, 2 MiB segments), a pool of CCtx threads fed
             # from a shared segment counter, bytes / wall clock of the whole call
             with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
-                f.write(shard[:min(len(shard), 2048 * block)])
+                f.write(shard[:min(len(shard), 4096 * block)])
                 fbig = f.name
-            out["frontend"] = {"gpu": frontbench(fbig, block, level, base_t, 1), "gpu_2x_threads": frontbench(fbig, block, level, 2 * base_t, 1),
-                               "software_libzstd_1_5": frontbench(fbig, block, level, base_t, 0, loops=1)}
+            t_more = max(base_t + 1, int(1.25 * base_t))  # a few more workers than cores: a worker that waits for the GPU frees its core
+            out["frontend"] = {"gpu": frontbench(fbig, block, level, base_t, 1, seg_mib=2),
+                               "gpu_more_threads": frontbench(fbig, block, level, t_more, 1, seg_mib=2),
+                               "software_libzstd_1_5": frontbench(fbig, block, level, base_t, 0, loops=1, seg_mib=2)}
             os.unlink(fbig)
             # ... the announced path with ZSTD_c_searchForExternalRepcodes on (-E1) and the repeat-offset aware parse
             rep = c_benchmark(fname, block, level, base_t, mode=1, hint=16, ext_rep=1, loops=4, env={"QZSTD_HIP_EXT_REPCODES": "1"})

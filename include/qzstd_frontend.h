@@ -32,7 +32,7 @@ typedef struct {
     int nThreads;        /* worker threads (>= 1) */
     int level;           /* 1..12 */
     size_t chunkSize;    /* bytes per frame, > 0 */
-    size_t segmentBytes; /* bytes announced at a time, rounded to whole chunks, <= 16 MiB (0 = 4 MiB) */
+    size_t segmentBytes; /* bytes announced at a time, rounded to whole chunks, <= 16 MiB (0 = 2 MiB) */
     int extRepcodes;     /* ZSTD_c_searchForExternalRepcodes: 0 auto, 1 enable, 2 disable (the reference's -E) */
     int useProducer;     /* 1 = register the GPU sequence producer (with software fallback), 0 = software zstd (baseline) */
 } QZSTD_FrontParams;

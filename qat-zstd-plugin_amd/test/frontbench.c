@@ -33,7 +33,7 @@ static size_t parseSize(const char *s)
 
 int main(int argc, char **argv)
 {
-    QZSTD_FrontParams p = { 16, 1, 131072, (size_t)4 << 20, 0, 1 };
+    QZSTD_FrontParams p = { 16, 1, 131072, (size_t)2 << 20, 0, 1 };
     unsigned loops = 3;
     const char *file = NULL;
     for (int i = 1; i < argc; i++) {
