@@ -410,13 +410,13 @@ def main():
                                                  % (best_sw["libzstd"], base_t, len(sample) >> 20, best_sw["loops"], block >> 10,
                                                     (sw if best_sw is sw14 else sw14).get("libzstd"), (sw if best_sw is sw14 else sw14).get("MBps_wall"))}
             # end to end through ZSTD_compress2 with the plugin registered, thread sweep (wall clock AND sum of rates):
-            #   announced   QZSTD_hintSource 4 MiB ahead (-H4): the GPU match-finds segment k+1 while the thread entropy-codes k
+            #   announced   QZSTD_hintSource 2 MiB ahead (-H2): the GPU match-finds segment k+1 while the thread entropy-codes k
             #   plain       unchanged callers, library defaults: every block through the coalescer
             #   lookahead   unchanged callers with the opt-in transparent look-ahead (QZSTD_HIP_LOOKAHEAD=1)
             sweep = []
-            for t in sorted({base_t, 2 * base_t, min(4 * base_t, 128)}):
+            for t in sorted({base_t, max(base_t + 1, int(1.25 * base_t)), 2 * base_t, min(4 * base_t, 128)}):
                 row = {"threads": t}
-                for name, kw in (("announced", dict(hint=4)), ("plain", {}), ("lookahead", dict(env={"QZSTD_HIP_LOOKAHEAD": "1"}))):
+                for name, kw in (("announced", dict(hint=2)), ("plain", {}), ("lookahead", dict(env={"QZSTD_HIP_LOOKAHEAD": "1"}))):
                     r = c_benchmark(fname, block, level, t, mode=1, loops=6 if t <= base_t else 3, **kw)
                     row[name] = {k: r.get(k) for k in ("MBps_wall", "MBps_sum_of_thread_rates", "csize", "latency_us_p50", "error") if k in r}
                     if "csize" in r and "csize" in sw:
