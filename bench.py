@@ -135,7 +135,7 @@ def build_tools():
 
 
 def c_benchmark(sample_file: str, block: int, level: int, threads: int, mode: int, hint: int = 0, ext_rep: int = 0,
-                loops: int = 2, env: dict | None = None, tool: str = "benchmark"):
+                loops: int = 2, env: dict | None = None, tool: str = "benchmark", split: int = 0):
     """run qat-zstd-plugin_amd/test/benchmark (counterpart of the reference's test/benchmark.c: T threads,
     one CCtx each, one ZSTD_compress2 per chunk, each chunk its own frame) on a sample file.  tool="benchmark_sw" is the
     same source built software-only against the system's libzstd 1.4.x."""
@@ -147,7 +147,7 @@ def c_benchmark(sample_file: str, block: int, level: int, threads: int, mode: in
         if not os.path.isfile(exe):
             return {"error": "%s not built" % tool}
         cmd = [exe, "-m%d" % mode, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level,
-               "-E%d" % ext_rep] + (["-H%d" % hint] if hint else []) + [sample_file]
+               "-E%d" % ext_rep] + (["-H%d" % hint] if hint else []) + (["-S%d" % split] if split else []) + [sample_file]
         t0 = time.perf_counter()
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
         wall = time.perf_counter() - t0
@@ -466,6 +466,15 @@ def main():
                         if "MBps_wall" in sw14l:
                             pl["speedup_vs_libzstd_1_4"] = round(pl["MBps_wall"] / max(sw14l["MBps_wall"], 1e-9), 2)
                     out[key] = {"cpu_libzstd_1_5": swl, "cpu_libzstd_1_4": sw14l, "e2e_announced": pl}
+                # BASELINE config 5's shape: 4 MiB frames (32 producer calls per frame), level 3, ZSTD_c_blockSplitterLevel = 1 so that
+                # libzstd keeps the blocks of a frame at 128 KiB (its 1.5.7 pre-splitter otherwise cuts them at arbitrary offsets)
+                sw5 = c_benchmark(fname, 4 << 20, 3, base_t, mode=0, loops=2, split=1)
+                p5 = c_benchmark(fname, 4 << 20, 3, base_t, mode=1, hint=4, loops=3, split=1)
+                if "csize" in p5 and "csize" in sw5:
+                    p5["csize_vs_sw"] = round(p5["csize"] / sw5["csize"], 4)
+                    p5["speedup_vs_libzstd_1_5"] = round(p5["MBps_wall"] / max(sw5["MBps_wall"], 1e-9), 2)
+                    p5["note"] = "software matches across the whole 4 MiB frame, the producer contract parses every 128 KiB block without history"
+                out["config5_shape_4MiB_frames_L3"] = {"cpu_libzstd_1_5": sw5, "e2e_announced": p5}
                 os.unlink(f6)
             os.unlink(fname)
         print(json.dumps(out))
