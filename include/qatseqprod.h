@@ -91,7 +91,7 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState);
  * the announced block grid from that result.  Purely an optimisation: callbacks that do
  * not match the hint take the normal single-block path.  `blockSize` is the block grid
  * (131072 for plain ZSTD_compress2; the frame/chunk size when each chunk is its own
- * frame).  Returns 0 when the hint was accepted.
+ * frame; 1024 .. 131072, a multiple of 16; at most 16 MiB per call).  Returns 0 when the hint was accepted, -1 otherwise.
  *
  * The call is asynchronous: it copies at most 16 MiB into pinned memory, queues the
  * transfers and the launches, and returns.  A state holds two announcements, so a caller

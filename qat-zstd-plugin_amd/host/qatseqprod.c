@@ -177,7 +177,8 @@ typedef struct {
     size_t size, block, nb;
     int level;
     unsigned char *hSrc;      /* pinned staging copy of the buffer */
-    ZSTD_Sequence *hSeqs;     /* pinned, nb x QZ_HINT_PITCH */
+    size_t pitch;             /* result entries per block: min(QZ_HINT_PITCH, ZSTD_sequenceBound(block)) */
+    ZSTD_Sequence *hSeqs;     /* pinned, nb x pitch */
     unsigned int *hCount;     /* pinned */
     qzstd_hip_block_t *hDesc; /* pinned */
     void *dvSeqs, *dvCount, *dvDesc; /* device-side addresses of the three: the kernels use them directly */
@@ -864,12 +865,12 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 int usable = 1;
                 for (bi = b; bi < e; bi++) {
                     const size_t count = h->hCount[bi];
-                    if (count == QZSTD_HIP_NSEQ_ERROR || count == 0 || count > QZ_HINT_PITCH) { usable = 0; break; }
+                    if (count == QZSTD_HIP_NSEQ_ERROR || count == 0 || count > h->pitch) { usable = 0; break; }
                     total += count - 1;
                 }
                 if (usable && total < outSeqsCapacity - 1) {
                     for (bi = b; bi < e; bi++) {
-                        const ZSTD_Sequence *q = h->hSeqs + bi * QZ_HINT_PITCH;
+                        const ZSTD_Sequence *q = h->hSeqs + bi * h->pitch;
                         const size_t count = h->hCount[bi];
                         if (count > 1) {
                             memcpy(outSeqs + out, q, (count - 1) * sizeof(ZSTD_Sequence));
@@ -1132,13 +1133,15 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
 
     qzHintDrop(h); /* an old announcement that was never consumed */
     nb = (srcSize + blockSize - 1) / blockSize;
+    /* a fine grid means many blocks: the result area is sized by what a block of that size can produce at most */
+    h->pitch = qzstd_hip_sequence_bound(blockSize) < QZ_HINT_PITCH ? qzstd_hip_sequence_bound(blockSize) : QZ_HINT_PITCH;
     blocksBytes = nb * sizeof(qzstd_hip_block_t);
     srcBytes = (srcSize + 63) & ~(size_t)63;
 
     h->hSrc = (unsigned char *)qzGrowHost(h->hSrc, &h->hSrcCap, srcBytes);
     h->hDesc = (qzstd_hip_block_t *)qzGrowHost(h->hDesc, &h->hDescCap, blocksBytes);
     h->hCount = (unsigned int *)qzGrowHost(h->hCount, &h->hCountCap, nb * sizeof(unsigned int));
-    h->hSeqs = (ZSTD_Sequence *)qzGrowHost(h->hSeqs, &h->hSeqsCap, nb * QZ_HINT_PITCH * sizeof(ZSTD_Sequence));
+    h->hSeqs = (ZSTD_Sequence *)qzGrowHost(h->hSeqs, &h->hSeqsCap, nb * h->pitch * sizeof(ZSTD_Sequence));
     h->dvDesc = qzstd_hip_host_device_ptr(h->hDesc);
     h->dvCount = qzstd_hip_host_device_ptr(h->hCount);
     h->dvSeqs = qzstd_hip_host_device_ptr(h->hSeqs);
@@ -1164,14 +1167,13 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
         /* descriptors of every block (also of ranges that cannot be queued: the callbacks' grid arithmetic reads them).
          * Results go straight into the pinned buffer, QZ_HINT_PITCH entries per block: a block with more sequences
          * reports an error and is redone by the per-block path when its callback comes */
-        const size_t bound = qzstd_hip_sequence_bound(blockSize);
         size_t b;
         for (b = 0; b < nb; b++) {
             const size_t o = b * blockSize;
             h->hDesc[b].srcOff = o;
-            h->hDesc[b].seqOff = b * QZ_HINT_PITCH;
+            h->hDesc[b].seqOff = b * h->pitch;
             h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
-            h->hDesc[b].seqCap = (unsigned int)(bound < QZ_HINT_PITCH ? bound : QZ_HINT_PITCH);
+            h->hDesc[b].seqCap = (unsigned int)h->pitch;
             h->hCount[b] = QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
         }
     }
@@ -1210,7 +1212,8 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     QZSTD_Hint_T *h;
     int k, inflight = 0;
 
-    if (!s || !src || srcSize == 0 || srcSize > QZ_HINT_MAX_BYTES || blockSize == 0 || blockSize > QZSTD_HIP_BLOCK_MAX ||
+    /* the grid: 1 KiB (libzstd's smallest ZSTD_c_maxBlockSize) .. 128 KiB, a multiple of 16 */
+    if (!s || !src || srcSize == 0 || srcSize > QZ_HINT_MAX_BYTES || blockSize < 1024 || blockSize > QZSTD_HIP_BLOCK_MAX ||
         (blockSize & 15))
         return -1;
     if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) return -1;
