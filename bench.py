@@ -381,6 +381,47 @@ def main():
                          "input_read_frac_of_peak": round(size / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "sequences_per_block": round(seq_total / max(nb - n_err, 1), 1), "error_blocks": n_err,
         }
+        if not a.no_cpu and world == 1 and level == 1 and block == 131072:
+            # the other BASELINE levels through the same entry point, resident input, HIP events (side keys, not the metric):
+            # config 3's level 6 on 128 KiB blocks, config 4's level 12 on 32 KiB web-log blocks
+            def side_kernel(lv, blk, nblk, src_bytes):
+                try:
+                    t_src = torch.empty(nblk * blk + 64, dtype=torch.uint8, device=dev)
+                    t_src[:nblk * blk].copy_(torch.frombuffer(bytearray(src_bytes[:nblk * blk]), dtype=torch.uint8))
+                    st2 = B.sequence_bound(blk)
+                    t_seqs = torch.empty((nblk * st2, 4), dtype=torch.int32, device=dev)
+                    t_cnt = torch.zeros(nblk, dtype=torch.int32, device=dev)
+                    dsc = (B.HipBlock * nblk)()
+                    for i in range(nblk):
+                        dsc[i].srcOff, dsc[i].seqOff, dsc[i].srcLen, dsc[i].seqCap = i * blk, i * st2, blk, st2
+                    t_desc = torch.empty(C.sizeof(dsc), dtype=torch.uint8, device=dev)
+                    t_desc.copy_(torch.frombuffer(bytearray(bytes(dsc)), dtype=torch.uint8))
+                    wk = L.qzstd_hip_workspace_bytes(lv, nblk, blk)
+                    t_work = torch.empty(max(wk, 4), dtype=torch.uint8, device=dev)
+                    torch.cuda.synchronize()
+
+                    def go():
+                        rc2 = L.qzstd_hip_find_sequences(local, C.c_void_p(stream.cuda_stream), lv, C.c_void_p(t_src.data_ptr()),
+                                                         C.c_void_p(t_desc.data_ptr()), nblk, blk, C.c_void_p(t_seqs.data_ptr()),
+                                                         C.c_void_p(t_cnt.data_ptr()), C.c_void_p(t_work.data_ptr()), wk)
+                        if rc2 != 0:
+                            raise RuntimeError(plug.err())
+                    go()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    for _ in range(3):
+                        go()
+                    e1.record(stream)
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / 3
+                    c2 = t_cnt.cpu().numpy().astype("uint32")
+                    return {"level": lv, "block_bytes": blk, "blocks": nblk, "kernel_ms": round(ms, 3),
+                            "input_GBps": round(nblk * blk / (ms * 1e-3) / 1e9, 2), "ms_per_GiB": round(ms * (1 << 30) / (nblk * blk), 1),
+                            "sequences_per_block": round(float(c2[c2 != 0xFFFFFFFF].mean()), 1), "error_blocks": int((c2 == 0xFFFFFFFF).sum())}
+                except Exception as e:  # noqa: BLE001
+                    return {"error": repr(e)[:200]}
+            out["kernel_other_levels"] = {"config3_level6_128KiB": side_kernel(6, 131072, 2048, shard),
+                                          "config4_level12_32KiB_weblog": side_kernel(12, 32768, 8192, K.weblog(4, 64 * K.MiB) * 4)}
         if not a.no_cpu and world == 1:  # CPU legs on rank 0 at N=1 only (bench contract)
             import tempfile
             ncpu, quota = host_cpu_budget()

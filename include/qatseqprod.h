@@ -100,6 +100,11 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState);
  * stream; every kernel writes its results into the announcement's pinned host buffers
  * (QZSTD_HIP_SPLIT=n limits the split to n GPUs, 1 keeps it on the state's own GPU).
  *
+ * Streaming callers (ZSTD_compressStream2 with small feeds, the zstd CLI): libzstd hands the producer blocks out
+ * of its own window buffer, so the callback never names announced memory.  Announcements of up to 256 grid blocks
+ * are therefore also matched BY CONTENT: a callback whose size, first and last 8 bytes and — verified by memcmp —
+ * bytes equal an announced grid block is served from it.  Announce what you read, on the 128 KiB grid of the stream.
+ *
  * Contract: the announced bytes should not change until their callbacks have come.  The
  * plugin does not rely on it — every callback served from an announcement is compared with
  * the staged copy first (memcmp); if the buffer was rewritten the announcement is dropped

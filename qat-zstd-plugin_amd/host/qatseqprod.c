@@ -161,6 +161,7 @@ static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DE
 #define QZ_HINT_MAX_BYTES ((size_t)16 << 20)
 #define QZ_HINT_PITCH ((size_t)16384) /* blocks with more sequences take the per-block path */
 #define QZ_HINT_PARTS 8
+#define QZ_CONTENT_LOOKUP_BLOCKS 256u /* announcements with more grid blocks are matched by address only */
 typedef struct {
     int st;   /* 0 none, 1 in flight on the GPU (slot held), 2 ready, 3 failed */
     int slot; /* index of the slot held while in flight */
@@ -178,6 +179,8 @@ typedef struct {
     int level;
     unsigned char *hSrc;      /* pinned staging copy of the buffer */
     size_t pitch;             /* result entries per block: min(QZ_HINT_PITCH, ZSTD_sequenceBound(block)) */
+    unsigned long long *keys; /* per grid block: size + first / last 8 bytes folded (content look-up for streaming callers) */
+    size_t keysCap;
     ZSTD_Sequence *hSeqs;     /* pinned, nb x pitch */
     unsigned int *hCount;     /* pinned */
     qzstd_hip_block_t *hDesc; /* pinned */
@@ -209,6 +212,15 @@ typedef struct {
 static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block);
 static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t blockSize, int compressionLevel);
 static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need);
+
+/* cheap fingerprint of a block: its size and its first and last 8 bytes (a candidate is always verified with memcmp) */
+static unsigned long long qzBlockKey(const unsigned char *p, size_t n)
+{
+    unsigned long long a, b;
+    memcpy(&a, p, 8);
+    memcpy(&b, p + n - 8, 8);
+    return a ^ (b * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)n << 40);
+}
 
 const char *QZSTD_version(void)
 {
@@ -694,6 +706,7 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
         qzstd_hip_host_free(s->hint[k].hSeqs);
         qzstd_hip_host_free(s->hint[k].hCount);
         qzstd_hip_host_free(s->hint[k].hDesc);
+        free(s->hint[k].keys);
     }
     if (s->pipeFd[0] >= 0) close(s->pipeFd[0]);
     if (s->pipeFd[1] >= 0) close(s->pipeFd[1]);
@@ -828,25 +841,40 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
             int pi, ok = 1;
             if (h->st == 0) continue;
             if (k < 2) announced = 1;
-            if (h->level != compressionLevel || p < h->base || p + srcSize > h->base + h->size) continue;
-            rel = (size_t)(p - h->base);
-            b = rel / h->block;
-            if (rel % h->block != 0 || b >= h->nb) continue;
-            for (e = b; e < h->nb && covered < srcSize; e++) covered += h->hDesc[e].srcLen;
-            /* a GUESS must not change what the caller gets: it serves a callback only block for block (joining
-             * independently parsed grid blocks costs ratio; for announcements that is the announcer's choice) */
-            if (covered != srcSize || e - b > 8 || (k >= 2 && e - b != 1)) {
-                QZ_LOG(3, "look-ahead %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
-                continue;
-            }
-            if (memcmp(h->hSrc + rel, src, srcSize) != 0) {
-                /* a guess that was read before these bytes were final, or an announced buffer that was rewritten */
-                if (k >= 2) guessMissed = 1;
-                else {
-                    QZ_LOG(2, "announcement %d: the buffer changed after it was announced; dropped\n", k);
-                    qzHintDrop(h);
+            if (h->level != compressionLevel) continue;
+            if (p >= h->base && p + srcSize <= h->base + h->size) { /* by address: the callback names announced memory */
+                rel = (size_t)(p - h->base);
+                b = rel / h->block;
+                if (rel % h->block != 0 || b >= h->nb) continue;
+                for (e = b; e < h->nb && covered < srcSize; e++) covered += h->hDesc[e].srcLen;
+                /* a GUESS must not change what the caller gets: it serves a callback only block for block (joining
+                 * independently parsed grid blocks costs ratio; for announcements that is the announcer's choice) */
+                if (covered != srcSize || e - b > 8 || (k >= 2 && e - b != 1)) {
+                    QZ_LOG(3, "look-ahead %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
+                    continue;
                 }
-                continue;
+                if (memcmp(h->hSrc + rel, src, srcSize) != 0) {
+                    /* a guess that was read before these bytes were final, or an announced buffer that was rewritten */
+                    if (k >= 2) guessMissed = 1;
+                    else {
+                        QZ_LOG(2, "announcement %d: the buffer changed after it was announced; dropped\n", k);
+                        qzHintDrop(h);
+                    }
+                    continue;
+                }
+            } else {
+                /* by content: a streaming caller (ZSTD_compressStream2 with small feeds, the zstd CLI) announces the buffer it
+                 * read into, but libzstd hands the producer blocks out of its OWN window buffer.  An announced grid block with
+                 * the same size, the same first and last 8 bytes and — verified — the same bytes serves such a callback
+                 * just as well (the sequences depend on nothing but the block's bytes). */
+                unsigned long long key;
+                if (k >= 2 || srcSize < 16 || h->nb > QZ_CONTENT_LOOKUP_BLOCKS || !h->keys) continue;
+                key = qzBlockKey((const unsigned char *)src, srcSize);
+                for (b = 0; b < h->nb; b++)
+                    if (h->keys[b] == key && h->hDesc[b].srcLen == srcSize && memcmp(h->hSrc + b * h->block, src, srcSize) == 0) break;
+                if (b >= h->nb) continue;
+                rel = b * h->block;
+                e = b + 1;
             }
             /* the parts that hold these blocks: wait for them (usually long done) */
             for (pi = 0; pi < h->nParts; pi++) {
@@ -1163,6 +1191,13 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     h->block = blockSize;
     h->level = compressionLevel;
     h->nb = nb;
+    if (!speculative && nb <= QZ_CONTENT_LOOKUP_BLOCKS) {
+        if (h->keysCap < nb) {
+            free(h->keys);
+            h->keys = (unsigned long long *)malloc(nb * sizeof(*h->keys));
+            h->keysCap = h->keys ? nb : 0;
+        }
+    }
     {
         /* descriptors of every block (also of ranges that cannot be queued: the callbacks' grid arithmetic reads them).
          * Results go straight into the pinned buffer, QZ_HINT_PITCH entries per block: a block with more sequences
@@ -1175,6 +1210,8 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
             h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
             h->hDesc[b].seqCap = (unsigned int)h->pitch;
             h->hCount[b] = QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
+            if (!speculative && h->keys && nb <= h->keysCap && nb <= QZ_CONTENT_LOOKUP_BLOCKS)
+                h->keys[b] = h->hDesc[b].srcLen >= 16 ? qzBlockKey(h->hSrc + o, h->hDesc[b].srcLen) : 0ull;
         }
     }
     /* contiguous block ranges, one per GPU, starting at this state's own GPU; a range is worth a launch from 4 blocks */

@@ -413,3 +413,46 @@ def test_batch_front_end_over_the_mock(mock, zstd, oracle):
         assert total == sum(sizes) and dst.raw[:total] == b"".join(frames)
         F.QZSTD_freeFront(f)
     assert F.QZSTD_createFront(C.byref(Params(0, 1, chunk, 0, 0, 1))) is None
+
+
+def test_streaming_caller_is_served_from_an_announcement_by_content(mock, zstd, oracle):
+    """ZSTD_compressStream2 with small feeds: libzstd hands the producer blocks out of its own window buffer, so the
+    callback's address never lies inside what the caller announced.  An announced grid block with the same bytes serves
+    it all the same (fingerprint + memcmp): every full block of the stream comes from the announcement."""
+    L = zstd.lib
+
+    class InB(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    class OutB(C.Structure):
+        _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(OutB), C.POINTER(InB), C.c_int]
+    L.ZSTD_compressStream2.restype = C.c_size_t
+    data = K.by_name("system", 9 * 131072 + 5000)
+    announced = (C.c_char * len(data)).from_buffer_copy(data)  # what the caller read the file into ...
+    feed = (C.c_char * len(data)).from_buffer_copy(data)       # ... and a different buffer it feeds libzstd from
+    st = mock.lib.QZSTD_createSeqProdState()
+    zc = zstd.cctx(1, producer=mock.producer_addr, state=st, fallback=False, validate=True, blockSplitterLevel=1)
+    assert mock.lib.QZSTD_hintSource(st, announced, len(data), 131072, 1) == 0
+    dst = C.create_string_buffer(L.ZSTD_compressBound(len(data)))
+    out = OutB(C.addressof(dst), len(dst), 0)
+    pos = 0
+    while pos < len(data):
+        n = min(50000, len(data) - pos)
+        inb = InB(C.addressof(feed) + pos, n, 0)
+        while inb.pos < inb.size:
+            r = L.ZSTD_compressStream2(zc, C.byref(out), C.byref(inb), B.e_continue)
+            assert not zstd.is_error(r), zstd.err(r)
+        pos += n
+    inb = InB(None, 0, 0)
+    while True:
+        r = L.ZSTD_compressStream2(zc, C.byref(out), C.byref(inb), B.e_end)
+        assert not zstd.is_error(r), zstd.err(r)
+        if r == 0:
+            break
+    stats = stats_of(mock, st)
+    zstd.free(zc)
+    mock.lib.QZSTD_freeSeqProdState(st)
+    assert zstd.decompress(dst.raw[:out.pos], len(data)) == data
+    assert stats[0] >= 9 and stats[0] + stats[1] == 10, stats  # the nine full blocks (and maybe the tail) by content
