@@ -519,3 +519,46 @@ def test_callbacks_spanning_several_grid_blocks(started, zstd, oracle):
     want = _compress_chunks_raw(zstd, type("P", (), {"producer_addr": C.cast(cb, C.c_void_p)})(), None, C.addressof(buf), len(data),
                                 131072, 1)
     assert got == want
+
+
+def test_streaming_caller_is_served_from_an_announcement_by_content(started, zstd):
+    """ZSTD_compressStream2 fed 50 000 bytes at a time from a different buffer than the announced one: libzstd's blocks come
+    out of its own window buffer, the announcement is matched by content (fingerprint + memcmp)"""
+    L = zstd.lib
+
+    class InB(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    class OutB(C.Structure):
+        _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(OutB), C.POINTER(InB), C.c_int]
+    L.ZSTD_compressStream2.restype = C.c_size_t
+    data = K.by_name("system", 24 * 131072 + 777)
+    announced = (C.c_char * len(data)).from_buffer_copy(data)
+    feed = (C.c_char * len(data)).from_buffer_copy(data)
+    st = started.lib.QZSTD_createSeqProdState()
+    zc = zstd.cctx(3, producer=started.producer_addr, state=st, fallback=False, validate=True, blockSplitterLevel=1)
+    assert started.lib.QZSTD_hintSource(st, announced, len(data), 131072, 3) == 0
+    dst = C.create_string_buffer(L.ZSTD_compressBound(len(data)))
+    out = OutB(C.addressof(dst), len(dst), 0)
+    pos = 0
+    while pos < len(data):
+        n = min(50000, len(data) - pos)
+        inb = InB(C.addressof(feed) + pos, n, 0)
+        while inb.pos < inb.size:
+            r = L.ZSTD_compressStream2(zc, C.byref(out), C.byref(inb), B.e_continue)
+            assert not zstd.is_error(r), zstd.err(r)
+        pos += n
+    inb = InB(None, 0, 0)
+    while True:
+        r = L.ZSTD_compressStream2(zc, C.byref(out), C.byref(inb), B.e_end)
+        assert not zstd.is_error(r), zstd.err(r)
+        if r == 0:
+            break
+    stats = (C.c_ulong * 4)()
+    started.lib.QZSTD_hintStats(st, C.byref(stats))
+    zstd.free(zc)
+    started.lib.QZSTD_freeSeqProdState(st)
+    assert zstd.decompress(dst.raw[:out.pos], len(data)) == data
+    assert stats[0] >= 24 and stats[0] + stats[1] == 25, list(stats)
