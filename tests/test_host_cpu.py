@@ -37,6 +37,18 @@ def test_library_exports_every_declared_symbol(plugin):
         assert hasattr(plugin.lib, name), "libqatseqprod.so does not export " + name
 
 
+def test_front_end_library_exports_what_its_header_declares(plugin):
+    """include/qzstd_frontend.h <-> lib/libqzstdfront.so (built when a libzstd >= 1.5.4 is found; it is in this image)"""
+    import ctypes
+    declared = declared_functions("qzstd_frontend.h")
+    assert declared == {"QZSTD_createFront", "QZSTD_frontFrameStride", "QZSTD_frontCompress", "QZSTD_frontCompact",
+                        "QZSTD_frontStats", "QZSTD_freeFront"}
+    B.Zstd()  # libzstd first (RTLD_GLOBAL): the front-end links against it
+    lib = ctypes.CDLL(os.path.join(B.PKG_DIR, "lib", "libqzstdfront.so"))
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libqzstdfront.so does not export " + name
+
+
 def test_static_library_has_the_reference_artefact_name():
     """libqatseqprod.a / .so / qatseqprod.h: artefact names of reference src/Makefile:85-95"""
     assert os.path.isfile(os.path.join(B.PKG_DIR, "lib", "libqatseqprod.a"))
