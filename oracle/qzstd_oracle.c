@@ -88,6 +88,9 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
      * level 2, which buys its better ratio with them */
     out->subTileLog = (chains || level == 2) ? 6u : 0u;
+    /* levels 1-4 (plain parse): no match crosses a 32 KiB boundary, so that a lone block can be parsed as four segments in
+     * parallel (each workgroup inserts the block before its segment, parses its segment) with the same result */
+    out->segLog = (!chains && !out->repWin) ? 15u : 0u;
     return 0;
 }
 
@@ -115,6 +118,22 @@ static inline uint32_t qzo_near_slot(uint32_t m, uint32_t tileLog)
 static inline uint32_t qzo_tag(uint32_t m)
 {
     return (m >> 3) & QZO_TAG_MASK;
+}
+
+/* end of p's segment (profile.segLog), or n */
+static inline uint32_t qzo_seg_end(const qzo_profile_t *pf, uint32_t p, uint32_t n)
+{
+    uint32_t e;
+    if (!pf->segLog) return n;
+    e = ((p >> pf->segLog) + 1u) << pf->segLog;
+    return e < n ? e : n;
+}
+
+/* a position takes part (is looked up and inserted) only if the bytes it hashes lie inside its segment: a workgroup
+ * that parses one segment sees the block up to the segment's end and must come to the same tables */
+static inline int qzo_hashable(const qzo_profile_t *pf, uint32_t p, uint32_t n, uint32_t bytes)
+{
+    return p + bytes <= qzo_seg_end(pf, p, n);
 }
 
 static inline uint32_t qzo_prefix_len(const uint8_t *src, uint32_t q, uint32_t p, uint32_t maxLen)
@@ -156,6 +175,7 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
             for (p = t0; p < t1; p++) {
                 const uint32_t m = qzo_mix(src + p, pf->hashBytes);
                 const uint32_t hn = qzo_near_slot(m, pf->tileLog);
+                if (!qzo_hashable(pf, p, n, pf->hashBytes)) continue;
                 const uint32_t e = ((p - t0) << QZO_TAG_BITS) | qzo_tag(m);
                 if (e < near[hn]) near[hn] = e;
             }
@@ -166,8 +186,10 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
             for (p = s0; p < s1; p++) {
                 const uint32_t v = qzo_rd32(src + p);
                 const uint32_t m = qzo_mix(src + p, pf->hashBytes);
-                const uint32_t cap = pf->capLen < n - p ? pf->capLen : n - p;
+                const uint32_t room = qzo_seg_end(pf, p, n) - p; /* a match never leaves its segment */
+                const uint32_t cap = pf->capLen < room ? pf->capLen : room;
                 uint32_t bestLen = 0, bestOff = 0;
+                if (!qzo_hashable(pf, p, n, pf->hashBytes)) continue;
                 /* probe 1: newest position of EARLIER (sub-)tiles in this slot (table as it was before the sub-tile) */
                 const uint32_t e = tbl[qzo_slot(m, pf->tableSize)];
                 if (e != 0 && (e & QZO_TAG_MASK) == qzo_tag(m)) {
@@ -179,7 +201,7 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
                     }
                 }
                 /* probe 3 (levels >= 3): newest position of EARLIER tiles whose first 8 bytes hash alike */
-                if (p < nl) {
+                if (p < nl && qzo_hashable(pf, p, n, 8u)) {
                     const uint32_t m8 = qzo_mix8(src + p);
                     const uint32_t eL = tblL[qzo_slot(m8, pf->longSize)];
                     if (eL != 0 && (eL & QZO_TAG_MASK) == qzo_tag(m8)) {
@@ -208,8 +230,9 @@ static void qzo_candidates(const qzo_profile_t *pf, const uint8_t *src, uint32_t
             /* insert the sub-tile: ascending order == "largest position wins" (GPU: ds_max_u32) */
             for (p = s0; p < s1; p++) {
                 const uint32_t m = qzo_mix(src + p, pf->hashBytes);
+                if (!qzo_hashable(pf, p, n, pf->hashBytes)) continue;
                 tbl[qzo_slot(m, pf->tableSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m);
-                if (p < nl) {
+                if (p < nl && qzo_hashable(pf, p, n, 8u)) {
                     const uint32_t m8 = qzo_mix8(src + p);
                     tblL[qzo_slot(m8, pf->longSize)] = ((p + 1u) << QZO_TAG_BITS) | qzo_tag(m8);
                 }
@@ -302,7 +325,8 @@ static inline uint32_t qzo_extend(const qzo_profile_t *pf, const uint8_t *src, u
                                   uint32_t from)
 {
     const uint32_t l0 = ((p >> pf->extLog) + 2u) << pf->extLog;
-    const uint32_t lim = l0 < n ? l0 : n;
+    const uint32_t se = qzo_seg_end(pf, p, n);
+    const uint32_t lim = l0 < se ? l0 : se;
     const uint32_t q = p - off;
     uint32_t L = from;
     while (p + L < lim && src[q + L] == src[p + L]) L++;
@@ -398,17 +422,25 @@ static size_t qzo_parse_rep(const qzo_profile_t *pf, const uint8_t *src, uint32_
 size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t srcSize,
                           qzo_seq_t *out, size_t cap)
 {
+    return qzo_find_sequences_from(pf, src, srcSize, 0, out, cap);
+}
+
+size_t qzo_find_sequences_from(const qzo_profile_t *pf, const uint8_t *src, size_t srcSize, size_t parseFrom,
+                               qzo_seq_t *out, size_t cap)
+{
     const uint32_t n = (uint32_t)srcSize;
     uint32_t nh;
     qzo_cand_t *cand;
     uint32_t *tbl, *near, *tblL, *chain;
-    uint32_t p = 0, anchor = 0;
+    uint32_t p = (uint32_t)parseFrom, anchor = (uint32_t)parseFrom;
     size_t ns = 0;
 
     if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
         pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->lazy > 4 || (pf->chainDepth && (pf->nearTab || pf->longSize)) || pf->chainDepth > 64 || pf->subTileLog > pf->tileLog || (pf->subTileLog && pf->subTileLog < 4) || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
         return QZO_ERROR;
+    if (pf->segLog && (pf->segLog < pf->tileLog || pf->segLog > 17 || pf->repWin || pf->chainDepth)) return QZO_ERROR;
+    if (parseFrom && (!pf->segLog || (parseFrom & ((1u << pf->segLog) - 1u)) || parseFrom >= srcSize)) return QZO_ERROR;
     nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
 
     cand = (qzo_cand_t *)malloc(sizeof(qzo_cand_t) * (n + 1));
@@ -426,19 +458,16 @@ size_t qzo_find_sequences(const qzo_profile_t *pf, const uint8_t *src, size_t sr
         goto done;
     }
     while (p < nh) {
-        uint32_t L, off, q, b = 0;
+        uint32_t L, off, q, b = 0, floor;
         if (!qzo_is_start(pf, cand, nh, p)) { p++; continue; } /* no usable candidate, or deferred by a lazy rule */
         L = cand[p].len;
         off = cand[p].off;
         q = p - off;
-        if (L == pf->capLen) { /* hit the candidate-phase cap: extend to the true end */
-            /* ... but never past the end of the NEXT 1<<extLog cell: bounds the parallel extension
-             * work (a longer repeat simply continues as another sequence) */
-            const uint32_t l0 = ((p >> pf->extLog) + 2u) << pf->extLog;
-            const uint32_t lim = l0 < n ? l0 : n;
-            while (p + L < lim && src[q + L] == src[p + L]) L++;
-        }
-        while (b < pf->backExt && p - b > anchor && q - b > 0 && src[p - b - 1] == src[q - b - 1]) b++;
+        if (L == pf->capLen) L = qzo_extend(pf, src, n, p, off, L); /* hit the candidate-phase cap: extend to the true (bounded) end */
+        /* backward extension into the pending literals, never across the start of p's segment */
+        floor = pf->segLog ? (p >> pf->segLog) << pf->segLog : 0u;
+        if (floor < anchor) floor = anchor;
+        while (b < pf->backExt && p - b > floor && q - b > 0 && src[p - b - 1] == src[q - b - 1]) b++;
         if (ns + 1 >= cap - 1) { ns = QZO_ERROR; goto done; } /* src/qatseqprod.c:1073-1076 */
         out[ns].offset = off;
         out[ns].litLength = p - b - anchor;

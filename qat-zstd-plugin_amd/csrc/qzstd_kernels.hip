@@ -218,6 +218,12 @@ __device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&oa)[
     return B >> 3;
 }
 
+/* end of p's segment (profile.segLog: no match crosses a multiple of 1 << segLog), or n */
+__device__ __forceinline__ uint32_t seg_end(const qzstd_hip_profile_t &pf, uint32_t p, uint32_t n)
+{
+    return pf.segLog ? umin(n, ((p >> pf.segLog) + 1u) << pf.segLog) : n;
+}
+
 __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint32_t off)
 {
     return pf.minMatch + ((off >> pf.farLog1) ? 1u : 0u) + ((off >> pf.farLog2) ? 1u : 0u);
@@ -334,7 +340,7 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
                     }
                     /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
                     const uint32_t pj = w0 + j;
-                    const uint32_t lim = umin(n, ((pj >> pf.extLog) + 2u) << pf.extLog);
+                    const uint32_t lim = umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog);
                     const uint32_t xl = extend_match(src, pj, payload, pf.capLen, lim, lane);
                     if (!ext0) ext0 = (j << 24) | xl; else ext1 = (j << 24) | xl;
                     c = e = j + xl;
@@ -527,7 +533,7 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
     if (ch) {
         const uint32_t p = w0 + lane, q = p - off;
         const uint32_t lit = p - prevEnd;
-        const uint32_t maxb = umin(umin(pf.backExt, lit), q);
+        const uint32_t maxb = umin(umin(umin(pf.backExt, lit), q), pf.segLog ? (p & ((1u << pf.segLog) - 1u)) : p);
         uint32_t b = 0;
         if (maxb) {
             /* the 4 bytes before p and before q, top byte = nearest; count equal bytes from the top */
@@ -573,6 +579,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     const qzstd_hip_profile_t pf = args.prof;
     const uint32_t nh = n >= pf.hashBytes ? n - pf.hashBytes + 1u : 0u; /* hashable positions */
     const uint32_t nTiles = (nh + kTile - 1u) >> kTileLog;
+    /* segment mode (qzstd_hip_block_t.parseFrom): tiles before the segment are only inserted into the tables */
+    const uint32_t firstTile = blk.parseFrom >> kTileLog;
+    if (blk.parseFrom != 0u && (pf.segLog == 0u || REP || CHAIN || (blk.parseFrom & ((1u << pf.segLog) - 1u)) != 0u || blk.parseFrom >= n)) {
+        if (tid == 0u) args.nseq[blockIdx.x] = QZSTD_HIP_NSEQ_ERROR; /* not a segment boundary of this level: refused */
+        return; /* uniform: before the first barrier */
+    }
 
     /* ---- LDS layout (81 600 B: two workgroups per CU) ---- */
     uint32_t *ring32 = reinterpret_cast<uint32_t *>(smem);
@@ -641,9 +653,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             nseqEnd = st.nseq;
             anchorEnd = st.anchor;
         } else {
-            ParseState st = { 0u, 0u, 0u };
+            ParseState st = { blk.parseFrom, blk.parseFrom, 0u };
             for (uint32_t it = 0; it < nTiles + 2u; it++) {
-                const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
+                const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u;
                 if (work)
                     parse_tile<0, kSplit>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
@@ -696,7 +708,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         const uint32_t p = t0 + tid; /* own position in tile it */
         const uint32_t stamp = (nTilesMax - 1u - (it & (nTilesMax - 1u))) << stampShift;
         uint32_t mix = 0, old = 0;
-        const bool valid = it < nTiles && p < nh;
+        /* a position takes part only if the bytes it hashes lie inside its segment (oracle: qzo_hashable) */
+        const bool valid = it < nTiles && p < nh && p + pf.hashBytes <= seg_end(pf, p, n);
+        const bool history = it < firstTile; /* uniform: a tile before the segment (segment mode): inserted, not matched */
 
         /* ================= interval 1 ================= */
         /* the position's own first 20 bytes (5 aligned dwords): issued first so that their LDS latency
@@ -710,12 +724,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         const uint32_t fpos = t0 + kLook + tid * 16u; /* iteration it stages [t0 + kLook, t0 + kLook + kTile) */
         const bool refill = it >= 1u && tid < kTile / 16u && fpos < nPad;
         if (refill) fresh = g128[fpos >> 4];
-        if (it >= 2u && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
+        if (it >= 2u + firstTile && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
             emit_window<REP>(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, pv + (it & 1u) * kPvStride + 64u * wave,
                              offB, lenB, t0 - 2u * kTile + 64u * wave, lane, out, blk.seqCap,
                              REP ? srec[(it & 1u) * kWin * kSrecWords] : 0u);
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
-        const bool validL = HAS_LONG && valid && p + 8u <= n;
+        const bool validL = HAS_LONG && valid && p + 8u <= seg_end(pf, p, n);
         uint32_t oa[4]; /* the position's first 16 bytes, byte-aligned: hashed now, compared against every candidate later */
 #pragma unroll
         for (int i = 0; i < 4; i++) oa[i] = __builtin_amdgcn_alignbyte(own[i + 1], own[i], p & 3u);
@@ -728,7 +742,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             nslot = mix >> nearShift;
             if (!TURNS) old = tbl[slot]; /* with turns the slot is read when the wave's turn comes */
             if (CHAIN) old = tbl[slot];  /* the slot before the tile: if no earlier position of this tile shares it, that IS the predecessor */
-            if (pf.nearTab) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
+            if (pf.nearTab && !history) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
             if (validL) { /* second table, keyed by the first 8 bytes */
                 const uint32_t m8 = (v * kPrime1) ^ (oa[1] * kPrime2);
                 slotL = __umulhi(m8, pf.longSize);
@@ -913,7 +927,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 atomicMax(&tbl[slot], ((p + 1u) << kTagBits) | tag);
                 if (validL) atomicMax(&tblL[slotL], ((p + 1u) << kTagBits) | tagL);
             }
-            const uint32_t cap = umin(pf.capLen, n - p);
+            if (!history) {
+            const uint32_t cap = umin(pf.capLen, seg_end(pf, p, n) - p); /* a match never leaves its segment */
             /* candidate 1: newest position of earlier tiles (known since interval 1: its bytes are fetched
              * while the near-table read is still in flight); candidate 2: earliest of this tile */
             uint32_t q1 = kNone, q2 = kNone;
@@ -951,9 +966,10 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             if (l1 >= 4u) { cl = l1; off = p - q1; }
             if (l3 >= 4u && l3 > cl) { cl = l3; off = p - q3; }   /* 8-byte table: only if strictly longer */
             if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }  /* same tile: ties go to the nearer source */
+            }
         }
         }
-        if (it < nTiles && !QZ_ABLATED(4u)) {
+        if (it < nTiles && !history && !QZ_ABLATED(4u)) {
             /* start flags: the lazy rules compare capped lengths and never look across the window edge */
             const bool take = cl != 0u && cl >= min_len(pf, off);
             bool defer1, defer2, defer3 = false;
@@ -1213,7 +1229,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12 (optionally | QZSTD_HIP_LEVEL_REPCODES)");
     if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
         a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 16 || a.prof.chainDepth > 64 ||
-        a.prof.lazy > 4 || (a.prof.subTileLog != 0u && a.prof.subTileLog != 6u) ||
+        a.prof.lazy > 4 || (a.prof.subTileLog != 0u && a.prof.subTileLog != 6u) || (a.prof.segLog != 0u && (a.prof.segLog < kTileLog || a.prof.segLog > 17u || a.prof.repWin || a.prof.chainDepth)) ||
         (a.prof.chainDepth && (a.prof.subTileLog != 6u || a.prof.longSize || a.prof.nearTab)) || (a.prof.longSize && a.prof.subTileLog))
         return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);

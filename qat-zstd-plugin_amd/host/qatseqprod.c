@@ -104,10 +104,13 @@ typedef struct {
 #define QZ_BATCH_MAX 128
 #define QZ_BATCHES 4
 #define QZ_BATCH_PITCH ((size_t)16384) /* sequences per block in the batch's result area; denser blocks are redone alone */
+#define QZ_SEGS_MAX 4 /* a block of a level whose profile has segLog is submitted as up to four segments (lone-request latency) */
 typedef struct {
     const void *src;
     size_t srcSize, cap, rc;
     int level;
+    int nSeg, dense;                /* segments submitted; the batch's result area was too small: redo alone */
+    unsigned int segCnt[QZ_SEGS_MAX]; /* sequences per segment, each including its delimiter */
 } QZSTD_Req_T;
 
 typedef struct {
@@ -118,8 +121,8 @@ typedef struct {
     unsigned char *hSrc;      /* pinned, QZ_BATCH_MAX x QZ_SRC_STRIDE */
     unsigned char *dSrc;      /* device, same size */
     ZSTD_Sequence *hSeqs;     /* pinned, QZ_BATCH_MAX x QZ_BATCH_PITCH */
-    qzstd_hip_block_t *hDesc; /* pinned */
-    unsigned int *hCount;     /* pinned */
+    qzstd_hip_block_t *hDesc; /* pinned, QZ_BATCH_MAX x QZ_SEGS_MAX */
+    unsigned int *hCount;     /* pinned, QZ_BATCH_MAX x QZ_SEGS_MAX */
     void *dvSeqs, *dvDesc, *dvCount; /* device-side addresses of hSeqs / hDesc / hCount */
     void *stream;
     void *dWork; /* launch scratch, grow-only */
@@ -150,10 +153,11 @@ typedef struct {
     int lookaheadLogged;
     int timeoutMs;           /* QZSTD_HIP_TIMEOUT_MS */
     int split;               /* QZSTD_HIP_SPLIT: announced buffers are split across this many GPUs (default: all) */
+    int splitBlocks;         /* QZSTD_HIP_SPLIT_BLOCKS (default 1): per-block requests of segmentable levels go as segments */
     pthread_mutex_t mutex;
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, PTHREAD_MUTEX_INITIALIZER };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, PTHREAD_MUTEX_INITIALIZER };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
  * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
@@ -391,8 +395,8 @@ static int qzSetupBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
     bt->dSrc = (unsigned char *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * QZ_SRC_STRIDE);
     bt->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SRC_STRIDE);
     bt->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_BATCH_PITCH * sizeof(ZSTD_Sequence));
-    bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(qzstd_hip_block_t));
-    bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_BATCH_MAX * sizeof(unsigned int));
+    bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SEGS_MAX * sizeof(qzstd_hip_block_t));
+    bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SEGS_MAX * sizeof(unsigned int));
     bt->dvSeqs = qzstd_hip_host_device_ptr(bt->hSeqs);
     bt->dvDesc = qzstd_hip_host_device_ptr(bt->hDesc);
     bt->dvCount = qzstd_hip_host_device_ptr(bt->hCount);
@@ -405,23 +409,50 @@ static int qzSetupBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
     return QZSTD_OK;
 }
 
-/* the leader's job: one launch per level present in the batch (called WITHOUT c->mu held) */
+/* the leader's job: one launch per level present in the batch (called WITHOUT c->mu held).
+ * Lone-request latency: at the levels whose profile allows it (segLog: no match crosses a 32 KiB boundary) a block goes
+ * to the GPU as up to four SEGMENT work items — each workgroup inserts the block before its segment into its tables and
+ * parses its segment only — which finish in about 40 % of the time one workgroup needs for the whole block; the
+ * caller joins the segments' sequence lists (identical to the whole block's list by construction). */
 static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
 {
     const int n = bt->n, dev = c->device;
-    int order[QZ_BATCH_MAX];
-    int i, j, g0, failed = 0, launches = 0;
+    int order[QZ_BATCH_MAX], first[QZ_BATCH_MAX];
+    int i, j, k = 0, g0, failed = 0, launches = 0;
     /* requests grouped by level (insertion sort, stable: the usual batch has one level) */
     for (i = 0; i < n; i++) {
         for (j = i; j > 0 && bt->req[order[j - 1]].level > bt->req[i].level; j--) order[j] = order[j - 1];
         order[j] = i;
     }
     for (j = 0; j < n; j++) {
-        const QZSTD_Req_T *r = &bt->req[order[j]];
-        bt->hDesc[j].srcOff = (size_t)order[j] * QZ_SRC_STRIDE;
-        bt->hDesc[j].seqOff = (size_t)order[j] * QZ_BATCH_PITCH;
-        bt->hDesc[j].srcLen = (unsigned int)r->srcSize;
-        bt->hDesc[j].seqCap = (unsigned int)(r->cap < QZ_BATCH_PITCH ? r->cap : QZ_BATCH_PITCH);
+        QZSTD_Req_T *r = &bt->req[order[j]];
+        qzstd_hip_profile_t pf;
+        size_t seg = 0;
+        int sg;
+        r->nSeg = 1;
+        r->dense = 0;
+        if (gProc.splitBlocks && qzstd_hip_profile_for_level(r->level, r->srcSize, &pf) == 0 && pf.segLog) {
+            seg = (size_t)1 << pf.segLog;
+            if (r->srcSize > seg && (r->srcSize + seg - 1) / seg <= QZ_SEGS_MAX) r->nSeg = (int)((r->srcSize + seg - 1) / seg);
+        }
+        first[j] = k;
+        for (sg = 0; sg < r->nSeg; sg++, k++) {
+            qzstd_hip_block_t *d = &bt->hDesc[k];
+            d->srcOff = (size_t)order[j] * QZ_SRC_STRIDE;
+            d->reserved = 0;
+            if (r->nSeg == 1) {
+                d->seqOff = (size_t)order[j] * QZ_BATCH_PITCH;
+                d->srcLen = (unsigned int)r->srcSize;
+                d->seqCap = (unsigned int)(r->cap < QZ_BATCH_PITCH ? r->cap : QZ_BATCH_PITCH);
+                d->parseFrom = 0;
+            } else { /* segment sg: the block up to the segment's end, parsed from the segment's start */
+                const size_t end = (size_t)(sg + 1) * seg;
+                d->seqOff = (size_t)order[j] * QZ_BATCH_PITCH + (size_t)sg * (QZ_BATCH_PITCH / QZ_SEGS_MAX);
+                d->srcLen = (unsigned int)(end < r->srcSize ? end : r->srcSize);
+                d->seqCap = (unsigned int)(QZ_BATCH_PITCH / QZ_SEGS_MAX);
+                d->parseFrom = (unsigned int)((size_t)sg * seg);
+            }
+        }
     }
     /* one copy in, one launch per level, one wait: the kernel reads the descriptors from and writes the sequences and
      * counts to this batch's pinned host buffers directly (posted PCIe writes while it runs), which takes two
@@ -430,18 +461,19 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
     for (g0 = 0; g0 < n && !failed; ) {
         const int level = bt->req[order[g0]].level;
         unsigned int maxLen = 0;
-        int g1 = g0;
+        int g1 = g0, k0 = first[g0], k1;
         size_t work;
         while (g1 < n && bt->req[order[g1]].level == level) {
-            if (bt->hDesc[g1].srcLen > maxLen) maxLen = bt->hDesc[g1].srcLen;
+            if (bt->req[order[g1]].srcSize > maxLen) maxLen = (unsigned int)bt->req[order[g1]].srcSize;
             g1++;
         }
-        work = qzstd_hip_workspace_bytes(level, (unsigned int)(g1 - g0), maxLen);
+        k1 = g1 < n ? first[g1] : k;
+        work = qzstd_hip_workspace_bytes(level, (unsigned int)(k1 - k0), maxLen);
         if (work > bt->dWorkCap && launches) failed = qzWait(dev, bt->stream) != 0; /* the scratch is about to be replaced */
         if (work && !failed) bt->dWork = qzGrowDev(dev, bt->dWork, &bt->dWorkCap, work);
         failed = failed || (work && !bt->dWork) ||
-                 qzstd_hip_find_sequences(dev, bt->stream, level, bt->dSrc, (const qzstd_hip_block_t *)bt->dvDesc + g0,
-                                          (unsigned int)(g1 - g0), maxLen, bt->dvSeqs, (unsigned int *)bt->dvCount + g0,
+                 qzstd_hip_find_sequences(dev, bt->stream, level, bt->dSrc, (const qzstd_hip_block_t *)bt->dvDesc + k0,
+                                          (unsigned int)(k1 - k0), maxLen, bt->dvSeqs, (unsigned int *)bt->dvCount + k0,
                                           bt->dWork, bt->dWorkCap);
         launches++;
         g0 = g1;
@@ -453,9 +485,18 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
     }
     for (j = 0; j < n; j++) {
         QZSTD_Req_T *r = &bt->req[order[j]];
-        const size_t cnt = failed ? QZSTD_HIP_NSEQ_ERROR : bt->hCount[j];
-        /* capacity rule, reference :1318-1322 */
-        r->rc = (cnt == QZSTD_HIP_NSEQ_ERROR || cnt == 0 || cnt >= r->cap - 1) ? ZSTD_SEQUENCE_PRODUCER_ERROR : cnt;
+        size_t total = 1;
+        int sg, bad = failed;
+        for (sg = 0; sg < r->nSeg && !bad; sg++) {
+            const unsigned int cnt = bt->hCount[first[j] + sg];
+            r->segCnt[sg] = cnt;
+            if (cnt == QZSTD_HIP_NSEQ_ERROR || cnt == 0) bad = 1;
+            else total += cnt - 1;
+        }
+        /* capacity rule, reference :1318-1322; a result area of the batch that was too small (not the caller's
+         * capacity) means: redo this block alone */
+        if (bad) r->dense = !failed && (r->nSeg > 1 || r->cap > QZ_BATCH_PITCH);
+        r->rc = (bad || total >= r->cap - 1) ? ZSTD_SEQUENCE_PRODUCER_ERROR : total;
     }
     if (failed) QZ_LOG(1, "device request failed: %s\n", qzstd_hip_last_error());
     c->launches += (unsigned long)launches;
@@ -530,9 +571,31 @@ static size_t qzCoalescedBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSe
     pthread_mutex_unlock(&c->mu);
 
     rc = bt->req[i].rc;
-    if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR)
-        memcpy(outSeqs, bt->hSeqs + (size_t)i * QZ_BATCH_PITCH, rc * sizeof(ZSTD_Sequence));
-    dense = rc == ZSTD_SEQUENCE_PRODUCER_ERROR && outSeqsCapacity > QZ_BATCH_PITCH && !bt->stuck;
+    if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) {
+        const QZSTD_Req_T *r = &bt->req[i];
+        if (r->nSeg == 1) {
+            memcpy(outSeqs, bt->hSeqs + (size_t)i * QZ_BATCH_PITCH, rc * sizeof(ZSTD_Sequence));
+        } else { /* join the segments: the trailing literals of one flow into the first sequence of the next */
+            size_t out = 0, carry = 0;
+            int sg;
+            for (sg = 0; sg < r->nSeg; sg++) {
+                const ZSTD_Sequence *q = bt->hSeqs + (size_t)i * QZ_BATCH_PITCH + (size_t)sg * (QZ_BATCH_PITCH / QZ_SEGS_MAX);
+                const size_t count = r->segCnt[sg];
+                if (count > 1) {
+                    memcpy(outSeqs + out, q, (count - 1) * sizeof(ZSTD_Sequence));
+                    outSeqs[out].litLength += (unsigned int)carry;
+                    out += count - 1;
+                    carry = 0;
+                }
+                carry += q[count - 1].litLength;
+            }
+            outSeqs[out].offset = 0;
+            outSeqs[out].litLength = (unsigned int)carry;
+            outSeqs[out].matchLength = 0;
+            outSeqs[out].rep = 0;
+        }
+    }
+    dense = rc == ZSTD_SEQUENCE_PRODUCER_ERROR && bt->req[i].dense && !bt->stuck;
 
     pthread_mutex_lock(&c->mu);
     if (++bt->consumed == bt->n) { /* last one out hands the batch back */
@@ -605,6 +668,7 @@ int QZSTD_startQatDevice(void)
          * from level 10): repeat-offset aware sequences at every level */
         gProc.levelFlags = (rep && atoi(rep) > 0) ? QZSTD_HIP_LEVEL_REPCODES : 0;
         gProc.timeoutMs = qzEnvInt("QZSTD_HIP_TIMEOUT_MS", QZ_DEFAULT_TIMEOUT_MS, 1, 600000);
+        gProc.splitBlocks = qzEnvInt("QZSTD_HIP_SPLIT_BLOCKS", 1, 0, 1);
         {
             /* The transparent look-ahead READS memory behind the block a callback names, so it is strictly opt-in:
              * QZSTD_HIP_LOOKAHEAD = 0 / unset: off; 1: on; 2: on and always through a pipe.  It needs a fault-safe read:
@@ -743,6 +807,8 @@ static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeq
     sl->hDesc->seqOff = 0;
     sl->hDesc->srcLen = (unsigned int)srcSize;
     sl->hDesc->seqCap = (unsigned int)cap;
+    sl->hDesc->parseFrom = 0;
+    sl->hDesc->reserved = 0;
     {
         const size_t work = qzstd_hip_workspace_bytes(level, 1, (unsigned int)srcSize);
         if (work) sl->dWork = qzGrowDev(sl->device, sl->dWork, &sl->dWorkCap, work);
@@ -1209,6 +1275,8 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
             h->hDesc[b].seqOff = b * h->pitch;
             h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
             h->hDesc[b].seqCap = (unsigned int)h->pitch;
+            h->hDesc[b].parseFrom = 0;
+            h->hDesc[b].reserved = 0;
             h->hCount[b] = QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
             if (!speculative && h->keys && nb <= h->keysCap && nb <= QZ_CONTENT_LOOKUP_BLOCKS)
                 h->keys[b] = h->hDesc[b].srcLen >= 16 ? qzBlockKey(h->hSrc + o, h->hDesc[b].srcLen) : 0ull;

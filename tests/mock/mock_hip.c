@@ -91,8 +91,8 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (device >= 0 && device < 64) __sync_fetch_and_add(&gLaunchDev[device], 1);
     for (b = 0; b < nBlocks; b++) {
         const qzstd_hip_block_t *k = &d_blocks[b];
-        const size_t n = qzo_find_sequences(&pf, (const uint8_t *)d_src + k->srcOff, k->srcLen,
-                                            (qzo_seq_t *)d_seqs + k->seqOff, k->seqCap);
+        const size_t n = qzo_find_sequences_from(&pf, (const uint8_t *)d_src + k->srcOff, k->srcLen, k->parseFrom,
+                                                 (qzo_seq_t *)d_seqs + k->seqOff, k->seqCap);
         d_nseq[b] = n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n;
     }
     return 0;

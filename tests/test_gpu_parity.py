@@ -109,3 +109,26 @@ def test_randomised_blocks(gpu_plugin, oracle, level, seed):
             b[s0:s0 + 900] = bytes([rng.randrange(256)]) * 900
         blocks.append(bytes(b[:n]))
     check_blocks(gpu_plugin, oracle, blocks, level)
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_segment_work_items(gpu_plugin, oracle, level):
+    """qzstd_hip_block_t.parseFrom (levels 1-4): a work item that holds a block up to a segment's end and parses the
+    segment only (what the per-block path submits, four items per 128 KiB block) — bit-exact against the oracle's
+    qzo_find_sequences_from, ragged sizes included; a parseFrom that is no segment boundary is refused"""
+    items, froms = [], []
+    for gen, size in (("text", 131072), ("system", 131072), ("weblog", 100001), ("binary", 70000), ("mix", 33000)):
+        blk = K.by_name(gen, size, seed=29)
+        for s0 in range(0, len(blk), 32768):
+            items.append(blk[:min(len(blk), s0 + 32768)])
+            froms.append(s0)
+    counts, seqs, stride = gpu_plugin.find_batch(items, level, parse_from=froms)
+    for i, (blk, s0) in enumerate(zip(items, froms)):
+        want_n, want = oracle.find(oracle.profile(level, len(blk)), blk, cap=stride, parse_from=s0)
+        assert counts[i] == want_n, "item %d (len %d from %d): %d sequences, oracle %d" % (i, len(blk), s0, counts[i], want_n)
+        assert np.array_equal(seqs_to_np(seqs, i * stride, want_n), seqs_to_np(want, 0, want_n)), "item %d differs" % i
+    blk = K.text(3, 70000)
+    counts, _, _ = gpu_plugin.find_batch([blk, blk, blk], level, parse_from=[1000, 98304, 32768])
+    assert counts[0] == B.NSEQ_ERROR and counts[1] == B.NSEQ_ERROR and counts[2] != B.NSEQ_ERROR
+    counts, _, _ = gpu_plugin.find_batch([blk], 6, parse_from=[32768])
+    assert counts[0] == B.NSEQ_ERROR

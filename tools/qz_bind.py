@@ -174,7 +174,7 @@ class Zstd:
 class OracleProfile(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("tableSize", "tileLog", "capLen", "minMatch", "farLog1",
                                           "farLog2", "lazy", "backExt", "nearTab", "window",
-                                          "hashBytes", "extLog", "longSize", "repWin", "chainDepth", "subTileLog")]
+                                          "hashBytes", "extLog", "longSize", "repWin", "chainDepth", "subTileLog", "segLog")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -189,6 +189,9 @@ class Oracle:
         L.qzo_find_sequences.argtypes = [C.POINTER(OracleProfile), C.c_void_p, C.c_size_t,
                                          C.POINTER(Sequence), C.c_size_t]
         L.qzo_find_sequences.restype = C.c_size_t
+        L.qzo_find_sequences_from.argtypes = [C.POINTER(OracleProfile), C.c_void_p, C.c_size_t, C.c_size_t,
+                                              C.POINTER(Sequence), C.c_size_t]
+        L.qzo_find_sequences_from.restype = C.c_size_t
         L.qzo_validate.argtypes = [C.POINTER(Sequence), C.c_size_t, C.c_size_t, C.c_size_t]
         L.qzo_reconstruct_check.argtypes = [C.POINTER(Sequence), C.c_size_t, C.c_void_p, C.c_size_t]
         L.qzo_reconstruct_check.restype = C.c_size_t
@@ -208,11 +211,12 @@ class Oracle:
             raise ValueError("bad level %d" % level)
         return p
 
-    def find(self, prof: OracleProfile, data: bytes, cap: int | None = None):
+    def find(self, prof: OracleProfile, data: bytes, cap: int | None = None, parse_from: int = 0):
+        """sequences of a block; parse_from != 0: of the segment that starts there (data = the block up to the segment's end)"""
         n = len(data)
         cap = cap or (n // 3 + 1 + n // 1024 + 1)
         out = (Sequence * cap)()
-        r = self.lib.qzo_find_sequences(C.byref(prof), data, n, out, cap)
+        r = self.lib.qzo_find_sequences_from(C.byref(prof), data, n, parse_from, out, cap)
         return r, out
 
     def stats(self, seqs, n):
@@ -231,7 +235,8 @@ class HipProfile(OracleProfile):
 
 
 class HipBlock(C.Structure):
-    _fields_ = [("srcOff", C.c_uint64), ("seqOff", C.c_uint64), ("srcLen", C.c_uint32), ("seqCap", C.c_uint32)]
+    _fields_ = [("srcOff", C.c_uint64), ("seqOff", C.c_uint64), ("srcLen", C.c_uint32), ("seqCap", C.c_uint32),
+                ("parseFrom", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 NSEQ_ERROR = 0xFFFFFFFF
@@ -308,7 +313,7 @@ class Plugin:
             raise RuntimeError("%s failed: %s" % (what, self.err()))
 
     def find_batch(self, blocks: list[bytes], level: int = 1, device: int = 0, stride: int | None = None,
-                   caps: list[int] | None = None):
+                   caps: list[int] | None = None, parse_from: list[int] | None = None):
         """Run the HIP match-finder over `blocks` through the C ABI (device memory managed
         with qzstd_hip_malloc / memcpy).  Returns (counts, list of Sequence arrays)."""
         L = self.lib
@@ -329,6 +334,7 @@ class Plugin:
             desc[i].seqOff = i * stride
             desc[i].srcLen = len(b)
             desc[i].seqCap = caps[i] if caps else stride
+            desc[i].parseFrom = parse_from[i] if parse_from else 0  # segment mode: the item parses [parseFrom, len) only
         d_src = L.qzstd_hip_malloc(device, total)
         d_desc = L.qzstd_hip_malloc(device, C.sizeof(desc))
         d_seqs = L.qzstd_hip_malloc(device, nb * stride * 16)
