@@ -88,9 +88,10 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
      * level 2, which buys its better ratio with them */
     out->subTileLog = (chains || level == 2) ? 6u : 0u;
-    /* levels 1-4 (plain parse): no match crosses a 32 KiB boundary, so that a lone block can be parsed as four segments in
-     * parallel (each workgroup inserts the block before its segment, parses its segment) with the same result */
-    out->segLog = (!chains && !out->repWin) ? 15u : 0u;
+    /* no match crosses a 32 KiB boundary (and the repeat-aware parse forgets its offsets there), so that a lone block can be
+     * parsed as four segments in parallel (each workgroup inserts the block before its segment, parses its segment) with
+     * the same result */
+    out->segLog = 15u;
     return 0;
 }
 
@@ -266,9 +267,12 @@ static void qzo_candidates_chain(const qzo_profile_t *pf, const uint8_t *src, ui
     for (p = 0; p < nh; p++) {
         const uint32_t v = qzo_rd32(src + p);
         const uint32_t sl = qzo_slot(qzo_mix(src + p, pf->hashBytes), pf->tableSize);
-        const uint32_t cap = pf->capLen < n - p ? pf->capLen : n - p;
-        uint32_t link = tbl[sl], d, bestLen = 0, bestOff = 0;
+        const uint32_t room = qzo_seg_end(pf, p, n) - p; /* a match never leaves its segment */
+        const uint32_t cap = pf->capLen < room ? pf->capLen : room;
+        uint32_t link, d, bestLen = 0, bestOff = 0;
         int bg = 0;
+        if (!qzo_hashable(pf, p, n, pf->hashBytes)) continue; /* hashes bytes of the next segment: takes no part */
+        link = tbl[sl];
         chain[p] = link;
         tbl[sl] = p + 1u;
         for (d = 0; d < pf->chainDepth && link != 0u; d++) {
@@ -359,24 +363,30 @@ static inline uint32_t qzo_rep_gain(uint32_t l, uint32_t r)
  * repeat probes as two byte-equality ballots.
  */
 static size_t qzo_parse_rep(const qzo_profile_t *pf, const uint8_t *src, uint32_t n, uint32_t nh,
-                            const qzo_cand_t *cand, qzo_seq_t *out, size_t cap)
+                            const qzo_cand_t *cand, qzo_seq_t *out, size_t cap, uint32_t parseFrom)
 {
-    uint32_t cur = 0, anchor = 0, rep[2] = { 0u, 0u };
+    uint32_t cur = parseFrom, anchor = parseFrom, rep[2] = { 0u, 0u };
+    uint32_t repSeg = pf->segLog ? parseFrom >> pf->segLog : 0u; /* the segment the repeat offsets were collected in */
     size_t ns = 0;
     while (cur < nh) {
         const uint32_t tileEnd = ((cur >> pf->tileLog) + 1u) << pf->tileLog;
         const uint32_t lim = tileEnd < nh ? tileEnd : nh;
         const uint32_t W = pf->repWin < lim - cur ? pf->repWin : lim - cur; /* positions on offer */
         const uint32_t V = W + 2u < lim - cur ? W + 2u : lim - cur;         /* ... + look-ahead for the deferral */
-        uint32_t G[34], opt[34], k, r, q = 0, off = 0, L = 0, b = 0;
+        uint32_t G[34], opt[34], k, r, q = 0, off = 0, L = 0, b = 0, floor;
         int found = 0;
+        if (pf->segLog && (cur >> pf->segLog) != repSeg) { /* a new segment starts without repeat offsets */
+            rep[0] = rep[1] = 0u;
+            repSeg = cur >> pf->segLog;
+        }
         for (k = 0; k < V; k++) {
             const uint32_t p = cur + k;
             G[k] = qzo_hash_gain(pf, &cand[p]);
             opt[k] = 0;
             for (r = 0; r < 2u; r++) {
                 if (rep[r] != 0u) {
-                    const uint32_t mx = n - p < QZO_REP_CAP ? n - p : QZO_REP_CAP;
+                    const uint32_t room = qzo_seg_end(pf, p, n) - p;
+                    const uint32_t mx = room < QZO_REP_CAP ? room : QZO_REP_CAP;
                     const uint32_t g = qzo_rep_gain(qzo_prefix_len(src, p - rep[r], p, mx), r);
                     if (g > G[k]) { G[k] = g; opt[k] = 1u + r; }
                 }
@@ -389,7 +399,8 @@ static size_t qzo_parse_rep(const qzo_profile_t *pf, const uint8_t *src, uint32_
             found = 1;
             q = cur + k;
             if (opt[k]) {
-                const uint32_t mx = n - q < QZO_REP_CAP ? n - q : QZO_REP_CAP;
+                const uint32_t room = qzo_seg_end(pf, q, n) - q;
+                const uint32_t mx = room < QZO_REP_CAP ? room : QZO_REP_CAP;
                 off = rep[opt[k] - 1u];
                 L = qzo_prefix_len(src, q - off, q, mx);
                 if (L == QZO_REP_CAP) L = qzo_extend(pf, src, n, q, off, L);
@@ -400,7 +411,9 @@ static size_t qzo_parse_rep(const qzo_profile_t *pf, const uint8_t *src, uint32_
             }
         }
         if (!found) { cur += W; continue; }
-        while (b < pf->backExt && q - b > anchor && q - off - b > 0 && src[q - b - 1] == src[q - off - b - 1]) b++;
+        floor = pf->segLog ? (q >> pf->segLog) << pf->segLog : 0u; /* never backwards across the start of q's segment */
+        if (floor < anchor) floor = anchor;
+        while (b < pf->backExt && q - b > floor && q - off - b > 0 && src[q - b - 1] == src[q - off - b - 1]) b++;
         if (ns + 1 >= cap - 1) return QZO_ERROR; /* src/qatseqprod.c:1073-1076 */
         out[ns].offset = off;
         out[ns].litLength = q - b - anchor;
@@ -439,7 +452,7 @@ size_t qzo_find_sequences_from(const qzo_profile_t *pf, const uint8_t *src, size
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
         pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->lazy > 4 || (pf->chainDepth && (pf->nearTab || pf->longSize)) || pf->chainDepth > 64 || pf->subTileLog > pf->tileLog || (pf->subTileLog && pf->subTileLog < 4) || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
         return QZO_ERROR;
-    if (pf->segLog && (pf->segLog < pf->tileLog || pf->segLog > 17 || pf->repWin || pf->chainDepth)) return QZO_ERROR;
+    if (pf->segLog && (pf->segLog < pf->tileLog || pf->segLog > 17)) return QZO_ERROR;
     if (parseFrom && (!pf->segLog || (parseFrom & ((1u << pf->segLog) - 1u)) || parseFrom >= srcSize)) return QZO_ERROR;
     nh = n >= pf->hashBytes ? n - pf->hashBytes + 1 : 0;
 
@@ -454,7 +467,7 @@ size_t qzo_find_sequences_from(const qzo_profile_t *pf, const uint8_t *src, size
     else qzo_candidates(pf, src, n, cand, tbl, near, tblL);
 
     if (pf->repWin) {
-        ns = qzo_parse_rep(pf, src, n, nh, cand, out, cap);
+        ns = qzo_parse_rep(pf, src, n, nh, cand, out, cap, (uint32_t)parseFrom);
         goto done;
     }
     while (p < nh) {

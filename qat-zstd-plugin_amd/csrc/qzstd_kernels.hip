@@ -386,6 +386,7 @@ struct RepState {
     uint32_t cur, anchor, nseq;
     uint32_t rep1, rep2; /* the last two distinct offsets */
     uint32_t tileSeq;    /* nseq when the parse entered the tile being parsed */
+    uint32_t seg;        /* the segment (profile.segLog) the repeat offsets were collected in */
 };
 constexpr uint32_t kRepCap = 32u, kRepMin = 3u;
 constexpr uint32_t kChosenBit = 0x80000000u; /* marks a parse-word slot rewritten into a chosen-match record */
@@ -428,7 +429,12 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
     const uint32_t tileLim = umin(base + kTile, nh), stop = umin(limit, nh);
     while (st.cur < stop) {
         const uint32_t W = umin(pf.repWin, tileLim - st.cur), V = umin(W + 2u, tileLim - st.cur);
+        const uint32_t segEnd = seg_end(pf, st.cur, n); /* windows never cross a tile edge, so never a segment's end */
         uint32_t wd = 0;
+        if (pf.segLog && (st.cur >> pf.segLog) != st.seg) { /* a new segment starts without repeat offsets */
+            st.rep1 = st.rep2 = 0u;
+            st.seg = st.cur >> pf.segLog;
+        }
         if (lane < V) wd = pvT[st.cur + lane - base]; /* the candidate of the window position: gain | offset << 10 */
         u64 M1, M2;
         if (st.rep1 <= kNear && st.rep2 <= kNear) { /* the usual case: both sources inside the ring */
@@ -438,12 +444,12 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
             oa = umin(oa, oa - kRing); o1 = umin(o1, o1 - kRing); o2 = umin(o2, o2 - kRing);
             const __attribute__((address_space(3))) uint8_t *rb = reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(src.ring);
             const uint32_t A = rb[oa], B1 = rb[o1], B2 = rb[o2]; /* three byte loads, one wait */
-            const bool inBlock = lane < n - st.cur;
+            const bool inBlock = lane < segEnd - st.cur; /* a repeat match never leaves its segment either */
             M1 = __ballot(inBlock && st.rep1 != 0u && A == B1);
             M2 = __ballot(inBlock && st.rep2 != 0u && A == B2);
         } else {
-            M1 = rep_bitmap(src, st.cur, st.rep1, n, lane);
-            M2 = rep_bitmap(src, st.cur, st.rep2, n, lane);
+            M1 = rep_bitmap(src, st.cur, st.rep1, segEnd, lane);
+            M2 = rep_bitmap(src, st.cur, st.rep2, segEnd, lane);
         }
         /* run of ones from bit `lane`, counted up to the cap: lanes < 18 always have 32 bits of look-ahead in the low
          * word of the shifted bitmap (funnel shift), ffbl of an all-ones word gives -1 -> the cap */
@@ -480,7 +486,7 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
             L = rdlane(rl1, ks);
             from = kRepCap;
         }
-        if (L == from) L = extend_match(src, q, off, from, umin(n, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
+        if (L == from) L = extend_match(src, q, off, from, umin(segEnd, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
         /* record, branch-free: the three parse-word slots at the start of the match (all behind the new cursor,
          * L >= 3) become {chosen | offset, length | index in tile, literal anchor} for the emitting wave */
         if (lane == 0u) {
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     const uint32_t nTiles = (nh + kTile - 1u) >> kTileLog;
     /* segment mode (qzstd_hip_block_t.parseFrom): tiles before the segment are only inserted into the tables */
     const uint32_t firstTile = blk.parseFrom >> kTileLog;
-    if (blk.parseFrom != 0u && (pf.segLog == 0u || REP || CHAIN || (blk.parseFrom & ((1u << pf.segLog) - 1u)) != 0u || blk.parseFrom >= n)) {
+    if (blk.parseFrom != 0u && (pf.segLog == 0u || (blk.parseFrom & ((1u << pf.segLog) - 1u)) != 0u || blk.parseFrom >= n)) {
         if (tid == 0u) args.nseq[blockIdx.x] = QZSTD_HIP_NSEQ_ERROR; /* not a segment boundary of this level: refused */
         return; /* uniform: before the first barrier */
     }
@@ -631,9 +637,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #endif
         uint32_t nseqEnd, anchorEnd;
         if (REP) {
-            RepState st = { 0u, 0u, 0u, 0u, 0u, 0u };
+            RepState st = { blk.parseFrom, blk.parseFrom, 0u, 0u, 0u, 0u, pf.segLog ? blk.parseFrom >> pf.segLog : 0u };
             for (uint32_t it = 0; it < nTiles + 2u; it++) {
-                const bool work = it >= 1u && it - 1u < nTiles && !QZ_ABLATED(1u);
+                const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u, base = k << kTileLog;
                 uint32_t *pvT = pv + (k & 1u) * kPvStride, *srecT = srec + (k & 1u) * kWin * kSrecWords;
                 if (work) {
@@ -841,8 +847,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             }
             /* the walk: chainDepth links, newest first; a link whose tag differs is a slot collision (skipped without
              * touching its bytes); the candidate with the highest gain stays, the nearer one on a tie */
-            const uint32_t cap = valid ? umin(pf.capLen, n - p) : 0u;
+            const uint32_t cap = valid ? umin(pf.capLen, seg_end(pf, p, n) - p) : 0u; /* a match never leaves its segment */
             uint32_t walked = 0;
+            if (history) E[0] = 0u; /* a tile before the segment (segment mode): inserted and linked, not matched */
             int bg = 0;
             while (__ballot(E[0] != 0u)) {
                 uint32_t N[4] = { 0u, 0u, 0u, 0u };
@@ -1229,7 +1236,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12 (optionally | QZSTD_HIP_LEVEL_REPCODES)");
     if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
         a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 16 || a.prof.chainDepth > 64 ||
-        a.prof.lazy > 4 || (a.prof.subTileLog != 0u && a.prof.subTileLog != 6u) || (a.prof.segLog != 0u && (a.prof.segLog < kTileLog || a.prof.segLog > 17u || a.prof.repWin || a.prof.chainDepth)) ||
+        a.prof.lazy > 4 || (a.prof.subTileLog != 0u && a.prof.subTileLog != 6u) || (a.prof.segLog != 0u && (a.prof.segLog < kTileLog || a.prof.segLog > 17u)) ||
         (a.prof.chainDepth && (a.prof.subTileLog != 6u || a.prof.longSize || a.prof.nearTab)) || (a.prof.longSize && a.prof.subTileLog))
         return fail_msg("qzstd_hip_find_sequences: unsupported profile");
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);

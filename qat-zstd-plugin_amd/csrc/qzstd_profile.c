@@ -55,9 +55,9 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
         /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
          * level 2, which buys its better ratio with them */
         out->subTileLog = (chains || level == 2) ? 6u : 0u;
-        /* levels 1-4 (plain parse): no match crosses a 32 KiB boundary, so that a lone block can be parsed as four
-         * segments in parallel with the same result (qzstd_hip_block_t.parseFrom) */
-        out->segLog = (!chains && !out->repWin) ? 15u : 0u;
+        /* no match crosses a 32 KiB boundary (and the repeat-aware parse forgets its offsets there), so that a lone block
+         * can be parsed as four segments in parallel with the same result (qzstd_hip_block_t.parseFrom) */
+        out->segLog = 15u;
     }
     return 0;
 }

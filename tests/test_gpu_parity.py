@@ -111,9 +111,9 @@ def test_randomised_blocks(gpu_plugin, oracle, level, seed):
     check_blocks(gpu_plugin, oracle, blocks, level)
 
 
-@pytest.mark.parametrize("level", [1, 2, 3, 4])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 6, 9, 12, 0x101, 0x105])
 def test_segment_work_items(gpu_plugin, oracle, level):
-    """qzstd_hip_block_t.parseFrom (levels 1-4): a work item that holds a block up to a segment's end and parses the
+    """qzstd_hip_block_t.parseFrom (every level): a work item that holds a block up to a segment's end and parses the
     segment only (what the per-block path submits, four items per 128 KiB block) — bit-exact against the oracle's
     qzo_find_sequences_from, ragged sizes included; a parseFrom that is no segment boundary is refused"""
     items, froms = [], []
@@ -130,5 +130,3 @@ def test_segment_work_items(gpu_plugin, oracle, level):
     blk = K.text(3, 70000)
     counts, _, _ = gpu_plugin.find_batch([blk, blk, blk], level, parse_from=[1000, 98304, 32768])
     assert counts[0] == B.NSEQ_ERROR and counts[1] == B.NSEQ_ERROR and counts[2] != B.NSEQ_ERROR
-    counts, _, _ = gpu_plugin.find_batch([blk], 6, parse_from=[32768])
-    assert counts[0] == B.NSEQ_ERROR

@@ -16,6 +16,10 @@ def bitlen(x):  # 31 - clz(x) for x >= 1
     return x.bit_length() - 1
 
 
+def seg_end(pf, p, n):
+    return min(n, ((p >> pf.segLog) + 1) << pf.segLog) if pf.segLog else n
+
+
 def candidates(pf, src):
     n = len(src)
     nh = n - 3 if n >= 4 else 0
@@ -23,12 +27,14 @@ def candidates(pf, src):
     chain = [0] * (n + 1)
     cand = [(0, 0)] * (n + 1)
     for p in range(nh):
+        if p + 4 > seg_end(pf, p, n):  # would hash bytes of the next segment: takes no part
+            continue
         v = src[p:p + 4]
         slot = ((int.from_bytes(v, "little") * P1 & 0xFFFFFFFF) * pf.tableSize) >> 32
         link = tbl.get(slot, 0)
         chain[p] = link
         tbl[slot] = p + 1
-        cap = min(pf.capLen, n - p)
+        cap = min(pf.capLen, seg_end(pf, p, n) - p)
         best, bg = (0, 0), 0
         for _ in range(pf.chainDepth):
             if link == 0:
@@ -55,7 +61,7 @@ def take(pf, c):
 
 
 def extend(pf, src, p, off, L):
-    lim = min(len(src), ((p >> pf.extLog) + 2) << pf.extLog)
+    lim = min(seg_end(pf, p, len(src)), ((p >> pf.extLog) + 2) << pf.extLog)
     while p + L < lim and src[p + L - off] == src[p + L]:
         L += 1
     return L
@@ -63,6 +69,8 @@ def extend(pf, src, p, off, L):
 
 def back(pf, src, q, off, anchor):
     b = 0
+    if pf.segLog:
+        anchor = max(anchor, (q >> pf.segLog) << pf.segLog)  # never backwards across the start of the segment
     while b < pf.backExt and q - b > anchor and q - off - b > 0 and src[q - b - 1] == src[q - off - b - 1]:
         b += 1
     return b
@@ -101,8 +109,10 @@ def parse_plain(pf, src, cand, nh):
 def parse_rep(pf, src, cand, nh):
     n = len(src)
     CAP, MIN = 32, 3
-    out, cur, anchor, rep = [], 0, 0, [0, 0]
+    out, cur, anchor, rep, rep_seg = [], 0, 0, [0, 0], 0
     while cur < nh:
+        if pf.segLog and (cur >> pf.segLog) != rep_seg:  # a new segment starts without repeat offsets
+            rep, rep_seg = [0, 0], cur >> pf.segLog
         lim = min(((cur >> pf.tileLog) + 1) << pf.tileLog, nh)
         W = min(pf.repWin, lim - cur)
         V = min(W + 2, lim - cur)
@@ -113,7 +123,7 @@ def parse_rep(pf, src, cand, nh):
             g, o = (4 * c[0] + 32 - bitlen(c[1] + 1), 0) if take(pf, c) else (0, 0)
             for r in range(2):
                 if rep[r]:
-                    mx, l = min(n - p, CAP), 0
+                    mx, l = min(seg_end(pf, p, n) - p, CAP), 0
                     while l < mx and src[p - rep[r] + l] == src[p + l]:
                         l += 1
                     rg = 0 if l < MIN else (1000 - r if l >= CAP else 4 * l + 36 - r)
@@ -133,7 +143,7 @@ def parse_rep(pf, src, cand, nh):
         q = cur + pick
         if opt[pick]:
             off = rep[opt[pick] - 1]
-            mx, L = min(n - q, CAP), 0
+            mx, L = min(seg_end(pf, q, n) - q, CAP), 0
             while L < mx and src[q - off + L] == src[q + L]:
                 L += 1
             if L == CAP:
@@ -158,6 +168,7 @@ def blocks():
     yield b"".join(b"record%05d;" % (i % 7) + bytes(53) for i in range(40))  # runs + a 65-byte period: long repeats, capped matches
     yield (b"abcdefgh" * 5 + b"X") * 50
     yield K.text(24, 700) + K.text(24, 700) + K.text(25, 300) + K.text(24, 700)  # far-ish repeats across a tile edge
+    yield K.weblog(26, 31000) + K.weblog(26, 4000)  # crosses the 32 KiB segment boundary with repeats on both sides
 
 
 @pytest.mark.parametrize("level", [5, 6, 9, 10, 12, 0x106])
