@@ -59,14 +59,14 @@ typedef struct {
                          * array in device memory: chain[p] = the slot's content before p's tile), n candidates deep */
     uint32_t subTileLog; /* 0 = the tables are updated once per tile; n = per 1<<n positions, in position order
                          * (GPU: the matcher waves take turns), so a position also sees the earlier sub-tiles of its tile */
-    uint32_t segLog;     /* 0 = none; n = no match crosses a multiple of 1<<n (levels 1-4: 15): one block may then be submitted as
+    uint32_t segLog;     /* 0 = none; n = no match crosses a multiple of 1<<n (15 at every level): one block may then be submitted as
                          * several work items that each parse one segment (qzstd_hip_block_t.parseFrom) — what the per-block
                          * path does to cut the latency of a lone request */
 } qzstd_hip_profile_t;
 
 /* One work item = one <=128 KiB block, parsed with no history
  * (reference contract: src/qatseqprod.h:103-105) — or one SEGMENT of such a block: parseFrom != 0 (a multiple of
- * 1 << profile.segLog, only at levels whose profile has segLog != 0) makes the workgroup insert [0, parseFrom) into its
+ * 1 << profile.segLog) makes the workgroup insert [0, parseFrom) into its
  * tables without parsing it and emit the sequences of [parseFrom, srcLen) only; srcLen is then the block up to the
  * segment's end.  The segments' sequence lists, concatenated with the trailing literals carried over, equal the
  * sequences of the whole block submitted as one item. */
