@@ -715,7 +715,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         const uint32_t stamp = (nTilesMax - 1u - (it & (nTilesMax - 1u))) << stampShift;
         uint32_t mix = 0, old = 0;
         /* a position takes part only if the bytes it hashes lie inside its segment (oracle: qzo_hashable) */
-        const bool valid = it < nTiles && p < nh && p + pf.hashBytes <= seg_end(pf, p, n);
+        const uint32_t segE = rdfirst(seg_end(pf, t0, n)); /* a tile lies inside one segment: uniform, kept in an SGPR */
+        const bool valid = it < nTiles && p < nh && p + pf.hashBytes <= segE;
         const bool history = it < firstTile; /* uniform: a tile before the segment (segment mode): inserted, not matched */
 
         /* ================= interval 1 ================= */
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                              offB, lenB, t0 - 2u * kTile + 64u * wave, lane, out, blk.seqCap,
                              REP ? srec[(it & 1u) * kWin * kSrecWords] : 0u);
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
-        const bool validL = HAS_LONG && valid && p + 8u <= seg_end(pf, p, n);
+        const bool validL = HAS_LONG && valid && p + 8u <= segE;
         uint32_t oa[4]; /* the position's first 16 bytes, byte-aligned: hashed now, compared against every candidate later */
 #pragma unroll
         for (int i = 0; i < 4; i++) oa[i] = __builtin_amdgcn_alignbyte(own[i + 1], own[i], p & 3u);
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             }
             /* the walk: chainDepth links, newest first; a link whose tag differs is a slot collision (skipped without
              * touching its bytes); the candidate with the highest gain stays, the nearer one on a tie */
-            const uint32_t cap = valid ? umin(pf.capLen, seg_end(pf, p, n) - p) : 0u; /* a match never leaves its segment */
+            const uint32_t cap = valid ? umin(pf.capLen, segE - p) : 0u; /* a match never leaves its segment */
             uint32_t walked = 0;
             if (history) E[0] = 0u; /* a tile before the segment (segment mode): inserted and linked, not matched */
             int bg = 0;
@@ -935,7 +936,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 if (validL) atomicMax(&tblL[slotL], ((p + 1u) << kTagBits) | tagL);
             }
             if (!history) {
-            const uint32_t cap = umin(pf.capLen, seg_end(pf, p, n) - p); /* a match never leaves its segment */
+            const uint32_t cap = umin(pf.capLen, segE - p); /* a match never leaves its segment */
             /* candidate 1: newest position of earlier tiles (known since interval 1: its bytes are fetched
              * while the near-table read is still in flight); candidate 2: earliest of this tile */
             uint32_t q1 = kNone, q2 = kNone;
