@@ -295,6 +295,29 @@ __device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val, uint32_t 
     return lane == l ? val : vec;
 }
 
+/* From cursor c (< 64) of a window: j = first start at/after it (>= 64: none, then jn = 64), the chase along the
+ * in-window successors (4 scalar instructions + 1 taken branch per sequence; every start passed is set in `chosen`),
+ * j = the last start taken, jn = where it leaves the window (64..191 = exit cursor, kNxCapped = extend first),
+ * pl = the payload of j (length, or the offset of a capped match) */
+#define QZ_CHASE(c)                                                                   \
+    asm volatile("v_readlane_b32 %[j], %[wd], %[cc]\n"                               \
+                 "s_movk_i32 %[jn], 64\n"                                            \
+                 "s_bfe_u32 %[j], %[j], 0x70008\n"                                   \
+                 "s_cmp_gt_u32 %[j], 63\n"                                           \
+                 "s_cbranch_scc1 2f\n"                                               \
+                 "1:\n"                                                              \
+                 "s_bitset1_b64 %[ch], %[j]\n"                                       \
+                 "v_readlane_b32 %[jn], %[nx], %[j]\n"                               \
+                 "s_cmp_lt_u32 %[jn], 64\n"                                          \
+                 "s_cselect_b32 %[j], %[jn], %[j]\n"                                 \
+                 "s_cbranch_scc1 1b\n"                                               \
+                 "v_readlane_b32 %[pl], %[wd], %[j]\n"                               \
+                 "s_lshr_b32 %[pl], %[pl], 15\n"                                     \
+                 "2:\n"                                                              \
+                 : [ch] "+s"(chosen), [j] "=&s"(j), [jn] "=&s"(jn), [pl] "=&s"(pl)    \
+                 : [nx] "v"(nx), [wd] "v"(word[w]), [cc] "s"(c)                       \
+                 : "scc");
+
 template <uint32_t W_BEGIN, uint32_t W_END>
 __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *pv,
                                            uint32_t *srecOut, uint32_t base, uint32_t n, uint32_t lane, ParseState &st)
@@ -313,47 +336,30 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
         const uint32_t anchorIn = st.anchor, seqBase = st.nseq;
         u64 chosen = 0;
         uint32_t ext0 = 0, ext1 = 0; /* (lane << 24 | extended length) of up to two taken capped matches */
-        if (st.cur < w0 + 64u) {
-            uint32_t c = rdfirst(st.cur - w0);
-            uint32_t j = (rdlane(word[w], c) >> 8) & 0x7Fu; /* first start at/after the cursor */
-            if (j < 64u) {
-                const uint32_t nx = word[w] & 0xFFu;
-                uint32_t e = 0;
+        const uint32_t c0 = st.cur - w0; /* the cursor never lies before the window */
+        if (c0 < 64u) {
+            const uint32_t nx = word[w] & 0xFFu;
+            uint32_t j, jn, pl;
+            QZ_CHASE(c0)
+            uint32_t cEnd = jn, eEnd = j < 64u ? j + pl : st.anchor - w0;
+            if (__builtin_expect(jn == kNxCapped, 0)) {
                 for (;;) {
-                    uint32_t jn;
-                    /* the chase: 4 scalar instructions + 1 taken branch per sequence */
-                    asm volatile(
-                        "1:\n"
-                        "s_bitset1_b64 %[ch], %[j]\n"
-                        "v_readlane_b32 %[jn], %[nx], %[j]\n"
-                        "s_cmp_lt_u32 %[jn], 64\n"
-                        "s_cselect_b32 %[j], %[jn], %[j]\n"
-                        "s_cbranch_scc1 1b\n"
-                        : [ch] "+s"(chosen), [j] "+s"(j), [jn] "=&s"(jn)
-                        : [nx] "v"(nx)
-                        : "scc");
-                    const uint32_t payload = rdlane(word[w], j) >> 15;
-                    if (jn != kNxCapped) {
-                        c = jn;
-                        e = j + payload;
-                        break;
-                    }
                     /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
                     const uint32_t pj = w0 + j;
                     const uint32_t lim = umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog);
-                    const uint32_t xl = extend_match(src, pj, payload, pf.capLen, lim, lane);
+                    const uint32_t xl = extend_match(src, pj, pl, pf.capLen, lim, lane);
                     if (!ext0) ext0 = (j << 24) | xl; else ext1 = (j << 24) | xl;
-                    c = e = j + xl;
-                    if (c >= 64u) break;
-                    j = (rdlane(word[w], c) >> 8) & 0x7Fu;
-                    if (j >= 64u) { c = 64u; break; }
+                    cEnd = eEnd = j + xl;
+                    if (cEnd >= 64u) break;
+                    QZ_CHASE(cEnd)
+                    if (j >= 64u) { cEnd = 64u; break; }
+                    cEnd = jn; eEnd = j + pl;
+                    if (jn != kNxCapped) break;
                 }
-                st.cur = w0 + c;
-                st.anchor = w0 + e;
-                st.nseq += (uint32_t)__popcll(chosen);
-            } else {
-                st.cur = w0 + 64u;
             }
+            st.nseq += (uint32_t)__popcll(chosen);
+            st.cur = w0 + cEnd;
+            st.anchor = w0 + eEnd;
         }
         r0 = wrlane(r0, (uint32_t)chosen, w, lane);
         r1 = wrlane(r1, (uint32_t)(chosen >> 32), w, lane);
@@ -945,6 +951,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 if (pf.window == 0u || p - q <= pf.window) q1 = q;
             }
             if (QZ_ABLATED(2u)) q1 = kNone;
+            if (QZ_ABLATED(64u) && q1 != kNone && p - q1 > kNear) q1 = kNone; /* profiling: what the HBM-side candidates cost */
             uint32_t l1 = 0, l2 = 0, l3 = 0;
             const bool far1 = q1 != kNone && p - q1 > kNear;
             if (q1 != kNone) l1 = head_len(src, oa, q1, ring_back(rp, p - q1), far1);
@@ -955,11 +962,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             if (q3 != kNone) l3 = head_len(src, oa, q3, ring_back(rp, p - q3), far3);
             if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
-                if (q < p && !QZ_ABLATED(2u)) q2 = q;
+                if (q < p && !QZ_ABLATED(2u | 256u)) q2 = q;
             }
             if (q2 != kNone) l2 = head_len(src, oa, q2, ring_back(rp, p - q2), false); /* same tile: always near */
             /* survivors of the 16-byte head: 32 more bytes per step, all candidates in one loop */
             bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u, need3 = HAS_LONG && l3 == 16u && cap > 16u;
+            if (QZ_ABLATED(128u)) need1 = need2 = need3 = false; /* profiling: what the extension past 16 bytes costs */
             while (need1 || need2 || need3) {
                 const int which = need1 ? 1 : (need3 ? 3 : 2);
                 const uint32_t q = which == 1 ? q1 : (which == 3 ? q3 : q2);
