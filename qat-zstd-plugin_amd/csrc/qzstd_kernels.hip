@@ -218,6 +218,21 @@ __device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&oa)[
     return B >> 3;
 }
 
+/* first mismatching byte (0..32) of 32 bytes already byte-aligned in `pa` and the 32 bytes at q */
+__device__ __forceinline__ uint32_t tail_len(const Src &s, const uint32_t (&pa)[8], uint32_t q, uint32_t rq, bool far)
+{
+    const uint32_t qs = q & 3u;
+    uint32_t Q[9];
+    load_dw_r<9>(s, q, rq, far, Q);
+    uint32_t B = 256u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t x = pa[i] ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
+        B = umin(B, first_diff_bit(x) | (32u * (uint32_t)i));
+    }
+    return B >> 3;
+}
+
 /* end of p's segment (profile.segLog: no match crosses a multiple of 1 << segLog), or n */
 __device__ __forceinline__ uint32_t seg_end(const qzstd_hip_profile_t &pf, uint32_t p, uint32_t n)
 {
@@ -965,10 +980,21 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                 if (q < p && !QZ_ABLATED(2u | 256u)) q2 = q;
             }
             if (q2 != kNone) l2 = head_len(src, oa, q2, ring_back(rp, p - q2), false); /* same tile: always near */
-            /* survivors of the 16-byte head: 32 more bytes per step, all candidates in one loop */
+            /* survivors of the 16-byte head: 32 more bytes per step.  The first step (the only one at the tile levels'
+             * cap of 48) shares the position's own side — fetched and byte-aligned once — between the candidates */
             bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u, need3 = HAS_LONG && l3 == 16u && cap > 16u;
             if (QZ_ABLATED(128u)) need1 = need2 = need3 = false; /* profiling: what the extension past 16 bytes costs */
-            while (need1 || need2 || need3) {
+            if (need1 || need2 || need3) {
+                const uint32_t rp16 = ring_fwd(rp, 16u);
+                uint32_t P[9], pa[8];
+                load_dw_r<9>(src, p + 16u, rp16, false, P);
+#pragma unroll
+                for (int i = 0; i < 8; i++) pa[i] = __builtin_amdgcn_alignbyte(P[i + 1], P[i], p & 3u);
+                if (need1) { const uint32_t l = tail_len(src, pa, q1 + 16u, ring_back(rp16, p - q1), far1); l1 = 16u + l; need1 = l == 32u && 48u < cap; }
+                if (HAS_LONG && need3) { const uint32_t l = tail_len(src, pa, q3 + 16u, ring_back(rp16, p - q3), far3); l3 = 16u + l; need3 = l == 32u && 48u < cap; }
+                if (need2) { const uint32_t l = tail_len(src, pa, q2 + 16u, ring_back(rp16, p - q2), false); l2 = 16u + l; need2 = l == 32u && 48u < cap; }
+            }
+            while (need1 || need2 || need3) { /* caps beyond 48: all candidates in one loop */
                 const int which = need1 ? 1 : (need3 ? 3 : 2);
                 const uint32_t q = which == 1 ? q1 : (which == 3 ? q3 : q2);
                 const uint32_t L = which == 1 ? l1 : (which == 3 ? l3 : l2);
