@@ -528,8 +528,8 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
 /* emission of one window's chosen matches by the wave that owns the window */
 template <bool REP>
 __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *srec,
-                                            const uint32_t *pvW, uint32_t off, uint32_t len, uint32_t w0, uint32_t lane,
-                                            uint4 *out, uint32_t seqCap, uint32_t tileSeq)
+                                            const uint32_t *pvW, uint32_t off, uint32_t len, uint32_t w0, uint32_t rpE,
+                                            uint32_t lane, uint4 *out, uint32_t seqCap, uint32_t tileSeq)
 {
     bool ch;
     uint32_t prevEnd, idx;
@@ -546,9 +546,13 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
         const uint4 rec = *reinterpret_cast<const uint4 *>(srec);
         const u64 chosen = (u64)rec.x | ((u64)rec.y << 32);
         if (!chosen) return;
-        const uint32_t anchorIn = rec.z, seqBase = rec.w, ext0 = srec[4], ext1 = srec[5];
-        if (ext0 && (ext0 >> 24) == lane) len = ext0 & 0xFFFFFFu; /* extended by the parse wave */
-        if (ext1 && (ext1 >> 24) == lane) len = ext1 & 0xFFFFFFu;
+        const uint32_t anchorIn = rec.z, seqBase = rec.w;
+        const uint32_t ext0 = rdfirst(srec[4]); /* uniform: a scalar branch skips the (rare) extended matches */
+        if (ext0) {
+            const uint32_t ext1 = srec[5];
+            if ((ext0 >> 24) == lane) len = ext0 & 0xFFFFFFu; /* extended by the parse wave */
+            if (ext1 && (ext1 >> 24) == lane) len = ext1 & 0xFFFFFFu;
+        }
         ch = (chosen >> lane) & 1ull;
         const u64 lower = chosen & below(lane);
         const uint32_t myEnd = w0 + lane + len;
@@ -563,10 +567,14 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
         const uint32_t maxb = umin(umin(umin(pf.backExt, lit), q), pf.segLog ? (p & ((1u << pf.segLog) - 1u)) : p);
         uint32_t b = 0;
         if (maxb) {
-            /* the 4 bytes before p and before q, top byte = nearest; count equal bytes from the top */
+            /* the 4 bytes before p and before q, top byte = nearest; count equal bytes from the top.  Through the ring the
+             * reads simply wrap below position 0: what they find there is never counted (maxb <= q) */
             const bool far = off > kNear;
-            const uint32_t pb = p >= 4u ? rd32u(src, p - 4u, false) : rd32u(src, 0u, false) << (8u * (4u - p));
-            const uint32_t qb = q >= 4u ? rd32u(src, q - 4u, far) : rd32u(src, 0u, far) << (8u * (4u - q));
+            const uint32_t rp4 = ring_back(rpE, 4u);
+            const uint32_t pb = rd32_r(src, p - 4u, rp4, false);
+            uint32_t qb;
+            if (far) qb = q >= 4u ? rd32u(src, q - 4u, true) : rd32u(src, 0u, true) << (8u * (4u - q));
+            else qb = rd32_r(src, q - 4u, ring_back(rp4, off), false);
             const uint32_t x = pb ^ qb;
             b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
         }
@@ -754,7 +762,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         if (refill) fresh = g128[fpos >> 4];
         if (it >= 2u + firstTile && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
             emit_window<REP>(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, pv + (it & 1u) * kPvStride + 64u * wave,
-                             offB, lenB, t0 - 2u * kTile + 64u * wave, lane, out, blk.seqCap,
+                             offB, lenB, t0 - 2u * kTile + 64u * wave, ring_back(rp, 2u * kTile), lane, out, blk.seqCap,
                              REP ? srec[(it & 1u) * kWin * kSrecWords] : 0u);
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
         const bool validL = HAS_LONG && valid && p + 8u <= segE;
