@@ -76,6 +76,7 @@ constexpr uint32_t kRing = 49152u;
 constexpr uint32_t kMirror = 128u;
 constexpr uint32_t kLook = 4608u;  /* bytes staged ahead of the current tile (covers the bounded extension) */
 constexpr uint32_t kNear = 40960u; /* kRing - kLook - 3 tiles of pipeline lag - slack */
+constexpr uint32_t kLdsBase = 16u; /* first LDS byte the kernel uses (csrc/qzstd_profile.c: QZ_LDS_CTRL covers it) */
 
 struct LaunchArgs {
     const uint8_t *src;
@@ -622,9 +623,14 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     }
 
     /* ---- LDS layout (81 600 B: two workgroups per CU) ---- */
-    uint32_t *ring32 = reinterpret_cast<uint32_t *>(smem);
-    uint4 *ring128 = reinterpret_cast<uint4 *>(smem);
-    uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + kRing + kMirror);
+    /* The workgroup's LDS is addressed from an integer constant, not from the `smem` symbol: the dynamic allocation starts at
+     * LDS address 0 (the kernel has no static LDS), but the compiler resolves the symbol too late to fold it and every LDS
+     * address would carry a dead `v_add 0`.  kLdsBase (16: never the null pointer) is part of qzstd_hip_lds_bytes(). */
+    uint8_t *smemI = (uint8_t *)(__attribute__((address_space(3))) uint8_t *)kLdsBase;
+    (void)smem;
+    uint32_t *ring32 = reinterpret_cast<uint32_t *>(smemI);
+    uint4 *ring128 = reinterpret_cast<uint4 *>(smemI);
+    uint32_t *tbl = reinterpret_cast<uint32_t *>(smemI + kRing + kMirror);
     uint32_t *tblL = tbl + pf.tableSize;               /* [longSize]    8-byte-key table (levels >= 3)    */
     uint32_t *nearTab = tblL + pf.longSize;
     uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */

@@ -16,7 +16,7 @@
 #include <string.h>
 
 #define QZ_LDS_MAX 163840u
-#define QZ_LDS_CTRL 64u
+#define QZ_LDS_CTRL (64u + 16u) /* control words + the 16 bytes below the kernel's first LDS address (kLdsBase) */
 
 
 int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t *out)
