@@ -305,10 +305,14 @@ __device__ __forceinline__ uint32_t pack_pos(uint32_t nx, uint32_t ns, uint32_t 
     return nx | (ns << 8) | (payload << 15);
 }
 
-/* vec with lane l replaced by the (uniform) val: the compiler turns this into v_writelane_b32 */
-__device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val, uint32_t l, uint32_t lane)
+/* vec with lane L replaced by the (uniform) val: ONE v_writelane_b32 (as `lane == L ? val : vec` the compiler emits a
+ * compare + select, and the parse wave's VALU instructions weigh on the SIMD it shares with two matcher waves).  The lane
+ * is an immediate: a second SGPR operand would break the constant-bus rule. */
+template <uint32_t L>
+__device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val)
 {
-    return lane == l ? val : vec;
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(val), "n"(L));
+    return vec;
 }
 
 /* From cursor c (< 64) of a window: j = first start at/after it (>= 64: none, then jn = 64), the chase along the
@@ -331,8 +335,68 @@ __device__ __forceinline__ uint32_t wrlane(uint32_t vec, uint32_t val, uint32_t 
                  "s_lshr_b32 %[pl], %[pl], 15\n"                                     \
                  "2:\n"                                                              \
                  : [ch] "+s"(chosen), [j] "=&s"(j), [jn] "=&s"(jn), [pl] "=&s"(pl)    \
-                 : [nx] "v"(nx), [wd] "v"(word[w]), [cc] "s"(c)                       \
+                 : [nx] "v"(nx), [wd] "v"(wordW), [cc] "s"(c)                         \
                  : "scc");
+
+/* the records of the windows a parse_tile call covers: lane w collects window w's */
+struct ParseRecs {
+    uint32_t r0, r1, r2, r3, r4, r5;
+};
+
+/* one window of the parse; W is a template parameter so that the record lanes are immediates */
+template <uint32_t W>
+__device__ __forceinline__ void parse_window(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t wordW,
+                                             uint32_t base, uint32_t n, uint32_t lane, ParseState &st, ParseRecs &r)
+{
+    constexpr uint32_t w = W;
+    const uint32_t w0 = base + 64u * w;
+    const uint32_t anchorIn = st.anchor, seqBase = st.nseq;
+    u64 chosen = 0;
+    uint32_t ext0 = 0, ext1 = 0; /* (lane << 24 | extended length) of up to two taken capped matches */
+    const uint32_t c0 = st.cur - w0; /* the cursor never lies before the window */
+    if (c0 < 64u) {
+        const uint32_t nx = wordW & 0xFFu;
+        uint32_t j, jn, pl;
+        QZ_CHASE(c0)
+        uint32_t cEnd = jn, eEnd = j < 64u ? j + pl : st.anchor - w0;
+        if (__builtin_expect(jn == kNxCapped, 0)) {
+            for (;;) {
+                /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
+                const uint32_t pj = w0 + j;
+                const uint32_t lim = umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog);
+                const uint32_t xl = extend_match(src, pj, pl, pf.capLen, lim, lane);
+                if (!ext0) ext0 = (j << 24) | xl; else ext1 = (j << 24) | xl;
+                cEnd = eEnd = j + xl;
+                if (cEnd >= 64u) break;
+                QZ_CHASE(cEnd)
+                if (j >= 64u) { cEnd = 64u; break; }
+                cEnd = jn; eEnd = j + pl;
+                if (jn != kNxCapped) break;
+            }
+        }
+        st.nseq += (uint32_t)__popcll(chosen);
+        st.cur = w0 + cEnd;
+        st.anchor = w0 + eEnd;
+    }
+    r.r0 = wrlane<W>(r.r0, (uint32_t)chosen);
+    r.r1 = wrlane<W>(r.r1, (uint32_t)(chosen >> 32));
+    r.r2 = wrlane<W>(r.r2, anchorIn);
+    r.r3 = wrlane<W>(r.r3, seqBase);
+    if (ext0) { /* rare */
+        r.r4 = wrlane<W>(r.r4, ext0);
+        r.r5 = wrlane<W>(r.r5, ext1);
+    }
+}
+
+template <uint32_t W, uint32_t W_END>
+__device__ __forceinline__ void parse_windows(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t (&word)[kWin],
+                                              uint32_t base, uint32_t n, uint32_t lane, ParseState &st, ParseRecs &r)
+{
+    if constexpr (W < W_END) {
+        parse_window<W>(pf, src, word[W], base, n, lane, st, r);
+        parse_windows<W + 1u, W_END>(pf, src, word, base, n, lane, st, r);
+    }
+}
 
 template <uint32_t W_BEGIN, uint32_t W_END>
 __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *pv,
@@ -345,49 +409,12 @@ __device__ __forceinline__ void parse_tile(const qzstd_hip_profile_t &pf, const 
      * latency once per window instead of once per call */
 #pragma unroll
     for (uint32_t w = W_BEGIN; w < W_END; w++) asm volatile("" : "+v"(word[w]));
-    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0; /* lane w collects window w's record */
-#pragma unroll
-    for (uint32_t w = W_BEGIN; w < W_END; w++) {
-        const uint32_t w0 = base + 64u * w;
-        const uint32_t anchorIn = st.anchor, seqBase = st.nseq;
-        u64 chosen = 0;
-        uint32_t ext0 = 0, ext1 = 0; /* (lane << 24 | extended length) of up to two taken capped matches */
-        const uint32_t c0 = st.cur - w0; /* the cursor never lies before the window */
-        if (c0 < 64u) {
-            const uint32_t nx = word[w] & 0xFFu;
-            uint32_t j, jn, pl;
-            QZ_CHASE(c0)
-            uint32_t cEnd = jn, eEnd = j < 64u ? j + pl : st.anchor - w0;
-            if (__builtin_expect(jn == kNxCapped, 0)) {
-                for (;;) {
-                    /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
-                    const uint32_t pj = w0 + j;
-                    const uint32_t lim = umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog);
-                    const uint32_t xl = extend_match(src, pj, pl, pf.capLen, lim, lane);
-                    if (!ext0) ext0 = (j << 24) | xl; else ext1 = (j << 24) | xl;
-                    cEnd = eEnd = j + xl;
-                    if (cEnd >= 64u) break;
-                    QZ_CHASE(cEnd)
-                    if (j >= 64u) { cEnd = 64u; break; }
-                    cEnd = jn; eEnd = j + pl;
-                    if (jn != kNxCapped) break;
-                }
-            }
-            st.nseq += (uint32_t)__popcll(chosen);
-            st.cur = w0 + cEnd;
-            st.anchor = w0 + eEnd;
-        }
-        r0 = wrlane(r0, (uint32_t)chosen, w, lane);
-        r1 = wrlane(r1, (uint32_t)(chosen >> 32), w, lane);
-        r2 = wrlane(r2, anchorIn, w, lane);
-        r3 = wrlane(r3, seqBase, w, lane);
-        r4 = wrlane(r4, ext0, w, lane);
-        r5 = wrlane(r5, ext1, w, lane);
-    }
+    ParseRecs r = { 0u, 0u, 0u, 0u, 0u, 0u };
+    parse_windows<W_BEGIN, W_END>(pf, src, word, base, n, lane, st, r);
     if (lane >= W_BEGIN && lane < W_END) {
-        *reinterpret_cast<uint4 *>(srecOut + lane * kSrecWords) = make_uint4(r0, r1, r2, r3);
-        srecOut[lane * kSrecWords + 4u] = r4;
-        srecOut[lane * kSrecWords + 5u] = r5;
+        *reinterpret_cast<uint4 *>(srecOut + lane * kSrecWords) = make_uint4(r.r0, r.r1, r.r2, r.r3);
+        srecOut[lane * kSrecWords + 4u] = r.r4;
+        srecOut[lane * kSrecWords + 5u] = r.r5;
     }
 }
 
@@ -717,6 +744,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         }
 #ifdef QZ_DEBUG_DUMP
         if (lane == 0) out[blk.seqCap - 2u] = make_uint4((uint32_t)pI1, (uint32_t)pW1, (uint32_t)pI2, (uint32_t)pW2);
+        if (lane == 0) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID: where the wave runs */
 #endif
         if (lane == 0) {
             /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
@@ -763,8 +791,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
          * registers -> ring after the barrier; the ring slots they replace left everyone's reach
          * three tiles ago) */
         uint4 fresh = make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t fpos = t0 + kLook + tid * 16u; /* iteration it stages [t0 + kLook, t0 + kLook + kTile) */
-        const bool refill = it >= 1u && tid < kTile / 16u && fpos < nPad;
+        /* done by half of wave 1: waves 0 and 4 share their SIMD with the parse wave and carry no extra chores */
+        const uint32_t fpos = t0 + kLook + (tid - 64u) * 16u; /* iteration it stages [t0 + kLook, t0 + kLook + kTile) */
+        const bool refill = wave == 1u && it >= 1u && lane < kTile / 16u && fpos < nPad;
         if (refill) fresh = g128[fpos >> 4];
         if (it >= 2u + firstTile && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
             emit_window<REP>(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, pv + (it & 1u) * kPvStride + 64u * wave,
@@ -1071,6 +1100,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     }
 #ifdef QZ_DEBUG_DUMP
     if (lane == 0) out[blk.seqCap - 3u - wave] = make_uint4((uint32_t)dI1, (uint32_t)dW1, (uint32_t)dI2, (uint32_t)dW2);
+    if (lane == 0) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID */
 #endif
 }
 

@@ -36,8 +36,8 @@ def main():
             for k in range(max(0, i - 2), min(m, i + 4)):
                 print("   %5d gpu %-22s oracle %-22s" % (k, g[k].tolist(), w[k].tolist()))
 def timing():
-    plug = B.Plugin(os.path.join(B.PKG_DIR, "lib", "libqatseqprod_dbg.so"))
-    data = K.system_corpus(256 * 131072)[0]
+    plug = B.Plugin(os.environ.get("QZ_PLUGIN_SO", os.path.join(B.PKG_DIR, "lib", "libqatseqprod_dbg.so")))
+    data = K.system_corpus(int(os.environ.get("QZ_BLOCKS", "256")) * 131072)[0]  # 256 = one workgroup per CU, 512 = two
     blocks = [data[o:o + 131072] for o in range(0, len(data), 131072)]
     counts, seqs, stride = plug.find_batch(blocks, int(os.environ.get("QZ_LEVEL", "1"), 0))
     a = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)
@@ -46,6 +46,16 @@ def timing():
     print("blocks %d  seq/block %.0f" % (len(blocks), c.mean()))
     rows2 = np.array([a[(i + 1) * stride - 2] for i in range(len(blocks))], dtype=np.float64)
     print("parse wave per tile: I1 %.0f waitB1 %.0f I2 %.0f waitB2 %.0f" % tuple(rows2.mean(axis=0) / 256))
+    if os.environ.get("QZ_HWID"):
+        # HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe [7:6], cu_id [11:8], sh [12], se [15:13]
+        hw = np.array([[a[(i + 1) * stride - 12 - wv][0] for wv in range(9)] for i in range(len(blocks))], dtype=np.int64)
+        simd = (hw >> 4) & 3
+        import collections
+        print("SIMD of waves 0..8 (matchers 0-7, parse wave 8), most common patterns:")
+        for pat, cnt in collections.Counter(tuple(r) for r in simd.tolist()).most_common(6):
+            print("   ", pat, cnt)
+        cu = ((hw[:, 0] >> 8) & 15) | (((hw[:, 0] >> 13) & 7) << 4) | (((hw[:, 0] >> 12) & 1) << 7)
+        print("parse-wave SIMD histogram:", np.bincount(simd[:, 8], minlength=4).tolist())
     for wv in range(8):
         rw = np.array([a[(i + 1) * stride - 3 - wv] for i in range(len(blocks))], dtype=np.float64)
         print("matcher wave %d per tile: I1 %.0f waitB1 %.0f I2 %.0f waitB2 %.0f" % ((wv,) + tuple(rw.mean(axis=0) / 256)))
