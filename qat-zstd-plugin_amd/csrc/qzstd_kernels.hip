@@ -843,7 +843,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         if (CHAIN) {
             /* Levels >= 5: exact hash chains (oracle: qzo_candidates_chain): every position gets its exact predecessor in
              * its slot, and walks chainDepth links from there.
-             *  - INSERT.  One wave (wave 0) updates the head table for the whole tile, window by window: read the slot,
+             *  - INSERT.  One wave (wave 2) updates the head table for the whole tile, window by window: read the slot,
              *    ds_max the own entry, read the slot back.  LDS operations of one wave execute in order, so the eight
              *    windows are pipelined back to back and still see each other exactly as sequential inserts would; no
              *    hand-over between waves.  Positions of one window that share a slot are ordered with ballots (the
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             uint4 *chainB = args.chain + (size_t)blockIdx.x * args.chainStride;
             uint32_t *P1T = nearTab; /* [kTile] */
             const uint32_t tag = (mix >> 3) & kTagMask;
-            if (wave == 0u) {
+            if (wave == 2u) { /* not wave 0 or 4: those share their SIMD with the parse wave */
                 uint32_t stv[kWin], prd[kWin], fin[kWin];
 #pragma unroll
                 for (uint32_t k = 0; k < kWin; k++) stv[k] = slotTag[64u * k + lane];
