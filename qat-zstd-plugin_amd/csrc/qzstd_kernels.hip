@@ -587,7 +587,7 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
         const int jprev = lower ? 63 - __builtin_clzll(lower) : 0;
         prevEnd = __shfl(myEnd, jprev);
         if (!lower) prevEnd = anchorIn;
-        idx = seqBase + (uint32_t)__popcll(lower);
+        idx = seqBase + __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u)); /* chosen lanes below this one */
     }
     if (ch) {
         const uint32_t p = w0 + lane, q = p - off;
@@ -1084,8 +1084,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             const uint32_t ns = here ? lane + (uint32_t)__builtin_ctzll(here) : 64u;
             const bool capped = cl == pf.capLen;
             const uint32_t endj = lane + cl;
-            const u64 rest = endj < 64u ? startMask >> endj : 0ull;
-            uint32_t nx = endj >= 64u ? endj : (rest ? endj + (uint32_t)__builtin_ctzll(rest) : 64u);
+            /* the next start at/after the match end is that position's `ns`: one ds_bpermute instead of a second 64-bit shift + count */
+            const uint32_t nsEnd = (uint32_t)__shfl((int)ns, (int)(endj & 63u));
+            uint32_t nx = endj >= 64u ? endj : nsEnd;
             nx = capped ? kNxCapped : nx;
             /* REP: the hash gain (0 = no usable candidate; 4 len + 32 - bits(offset) < 1024) | offset << 10; bit 31 stays clear */
             const uint32_t gRep = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
