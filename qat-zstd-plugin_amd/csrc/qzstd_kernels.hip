@@ -654,7 +654,12 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
      * LDS address 0 (the kernel has no static LDS), but the compiler resolves the symbol too late to fold it and every LDS
      * address would carry a dead `v_add 0`.  kLdsBase (16: never the null pointer) is part of qzstd_hip_lds_bytes(). */
     uint8_t *smemI = (uint8_t *)(__attribute__((address_space(3))) uint8_t *)kLdsBase;
-    (void)smem;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) {
+        /* the dynamic allocation does not start at LDS address 0 after all: refuse loudly (every block an error, the host
+         * falls back) rather than touch memory that is not ours */
+        if (tid == 0u) args.nseq[blockIdx.x] = QZSTD_HIP_NSEQ_ERROR;
+        return; /* uniform: before the first barrier */
+    }
     uint32_t *ring32 = reinterpret_cast<uint32_t *>(smemI);
     uint4 *ring128 = reinterpret_cast<uint4 *>(smemI);
     uint32_t *tbl = reinterpret_cast<uint32_t *>(smemI + kRing + kMirror);
