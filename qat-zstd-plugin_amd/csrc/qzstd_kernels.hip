@@ -86,6 +86,8 @@ struct LaunchArgs {
     qzstd_hip_profile_t prof; /* the level's search profile (block-size independent) */
     uint4 *chain;             /* levels >= 5: per-block chain entries (four links each), chainStride entries per block */
     uint32_t chainStride;
+    uint32_t orderedLds;      /* this device's LDS returns from ds_max_rtn, to lanes of one instruction that hit the same address, the
+                               * values in lane order (probed once per device, probe_lds_order) */
 #ifdef QZ_DEBUG_DUMP
     uint32_t dbg; /* profiling build only: ablation switches (QZSTD_HIP_ABLATE) */
 #endif
@@ -863,39 +865,54 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             uint32_t *P1T = nearTab; /* [kTile] */
             const uint32_t tag = (mix >> 3) & kTagMask;
             if (wave == 2u) { /* not wave 0 or 4: those share their SIMD with the parse wave */
-                uint32_t stv[kWin], prd[kWin], fin[kWin];
+                uint32_t stv[kWin];
 #pragma unroll
                 for (uint32_t k = 0; k < kWin; k++) stv[k] = slotTag[64u * k + lane];
+                if (args.orderedLds) {
+                    /* ONE returning ds_max per window: the LDS serves the lanes of an instruction that hit the same address in
+                     * lane order, so what a lane gets back — the slot before its own insert — is exactly its predecessor: the
+                     * nearest lower lane of its slot in this window, else the newest earlier position (or 0).  Not an
+                     * architectural promise: probe_lds_order() checks it on every device before this path is used. */
 #pragma unroll
-                for (uint32_t k = 0; k < kWin; k++) {
-                    const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
-                    prd[k] = 0u;
-                    fin[k] = mineK;
-                    if (stv[k] != kNone) {
-                        uint32_t *e = &tbl[stv[k] & 0xFFFFu];
-                        prd[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        atomicMax(e, mineK);
-                        fin[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (uint32_t k = 0; k < kWin; k++) {
+                        const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
+                        uint32_t pred = 0u;
+                        if (stv[k] != kNone) pred = atomicMax(&tbl[stv[k] & 0xFFFFu], mineK);
+                        P1T[64u * k + lane] = pred;
                     }
-                }
+                } else {
+                    uint32_t prd[kWin], fin[kWin];
 #pragma unroll
-                for (uint32_t k = 0; k < kWin; k++) {
-                    const bool vk = stv[k] != kNone;
-                    const uint32_t slotK = stv[k] & 0xFFFFu;
-                    const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
-                    /* lanes that are not the newest of their slot in this window have a same-slot lane above them */
-                    u64 rem = __ballot(fin[k] != mineK);
-                    uint32_t predLane = lane;
-                    while (rem) {
-                        const uint32_t s0 = rdlane(slotK, (uint32_t)__builtin_ctzll(rem));
-                        const bool in = vk && slotK == s0;
-                        const u64 grp = __ballot(in);
-                        const u64 lower = grp & below(lane);
-                        if (in && lower) predLane = 63u - (uint32_t)__builtin_clzll(lower); /* the nearest lower lane of the group */
-                        rem &= ~grp;
+                    for (uint32_t k = 0; k < kWin; k++) {
+                        const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
+                        prd[k] = 0u;
+                        fin[k] = mineK;
+                        if (stv[k] != kNone) {
+                            uint32_t *e = &tbl[stv[k] & 0xFFFFu];
+                            prd[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            atomicMax(e, mineK);
+                            fin[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
-                    const uint32_t fromLane = (uint32_t)__shfl((int)mineK, (int)predLane);
-                    P1T[64u * k + lane] = vk ? (predLane != lane ? fromLane : prd[k]) : 0u;
+#pragma unroll
+                    for (uint32_t k = 0; k < kWin; k++) {
+                        const bool vk = stv[k] != kNone;
+                        const uint32_t slotK = stv[k] & 0xFFFFu;
+                        const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
+                        /* lanes that are not the newest of their slot in this window have a same-slot lane above them */
+                        u64 rem = __ballot(fin[k] != mineK);
+                        uint32_t predLane = lane;
+                        while (rem) {
+                            const uint32_t s0 = rdlane(slotK, (uint32_t)__builtin_ctzll(rem));
+                            const bool in = vk && slotK == s0;
+                            const u64 grp = __ballot(in);
+                            const u64 lower = grp & below(lane);
+                            if (in && lower) predLane = 63u - (uint32_t)__builtin_clzll(lower); /* the nearest lower lane of the group */
+                            rem &= ~grp;
+                        }
+                        const uint32_t fromLane = (uint32_t)__shfl((int)mineK, (int)predLane);
+                        P1T[64u * k + lane] = vk ? (predLane != lane ? fromLane : prd[k]) : 0u;
+                    }
                 }
             }
             __syncthreads(); /* B1b */
@@ -1110,6 +1127,41 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #endif
 }
 
+/* Does the LDS hand the lanes of ONE ds_max_rtn instruction that hit the same address their values in lane order?  Every
+ * lane inserts an increasing value into the slot a pattern gives it and must get back the value of the nearest lower
+ * lane with the same slot (0 if none); several patterns, among them "all lanes one slot" and runs. */
+__global__ void qzstd_probe_lds_order(uint32_t *bad)
+{
+    __shared__ uint32_t slots[64];
+    const uint32_t lane = threadIdx.x;
+    uint32_t wrong = 0;
+    for (uint32_t round = 0; round < 64u; round++) {
+        slots[lane] = 0u;
+        __syncthreads();
+        uint32_t slot;
+        switch (round & 7u) {
+        case 0: slot = 0u; break;
+        case 1: slot = lane & 1u; break;
+        case 2: slot = lane >> 3; break;
+        case 3: slot = lane % 7u; break;
+        case 4: slot = (lane * 2654435761u + round) >> 28; break;
+        case 5: slot = (lane * 0x85EBCA77u + round) >> 26; break;
+        case 6: slot = lane < 32u ? 5u : lane & 3u; break;
+        default: slot = (lane ^ (lane >> 2)) & 31u; break;
+        }
+        const uint32_t mine = (round << 8) + lane + 1u;
+        const uint32_t got = atomicMax(&slots[slot], mine);
+        uint32_t want = 0u;
+        for (uint32_t l = 0; l < 64u; l++) {
+            const uint32_t sl = (uint32_t)__shfl((int)slot, (int)l);
+            if (l < lane && sl == slot) want = (round << 8) + l + 1u;
+        }
+        if (got != want) wrong++;
+        __syncthreads();
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
 thread_local char g_err[256] = "";
 
 int fail(const char *what, hipError_t e)
@@ -1141,6 +1193,29 @@ const char *qzstd_hip_last_error(void) { return g_err; }
 static std::once_flag g_devOnce;
 static int g_devCount = -1;
 static int g_devMap[64];
+static int g_ldsOrdered[64]; /* per device: -1 not probed yet, 0 no, 1 yes (probe_lds_order) */
+static std::mutex g_probeMu;
+
+/* runs qzstd_probe_lds_order once per device; any failure of the probe itself counts as "no" (the ballot path needs nothing) */
+static int probe_lds_order(int device, int physDev)
+{
+    std::lock_guard<std::mutex> g(g_probeMu);
+    if (g_ldsOrdered[device] >= 0) return g_ldsOrdered[device];
+    int verdict = 0;
+    const char *force = getenv("QZSTD_HIP_ORDERED_LDS"); /* 0 = never use the single-instruction insert */
+    uint32_t *dBad = nullptr, hBad = 1u;
+    if (!(force && atoi(force) == 0) && hipSetDevice(physDev) == hipSuccess && hipMalloc(&dBad, sizeof(uint32_t)) == hipSuccess) {
+        if (hipMemset(dBad, 0, sizeof(uint32_t)) == hipSuccess) {
+            hipLaunchKernelGGL(qzstd_probe_lds_order, dim3(64), dim3(64), 0, 0, dBad);
+            if (hipGetLastError() == hipSuccess && hipMemcpy(&hBad, dBad, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess)
+                verdict = hBad == 0u;
+        }
+        (void)hipFree(dBad);
+    }
+    (void)hipGetLastError();
+    g_ldsOrdered[device] = verdict;
+    return verdict;
+}
 
 static void probe_devices()
 {
@@ -1148,6 +1223,7 @@ static void probe_devices()
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { fail("hipGetDeviceCount", e); (void)hipGetLastError(); g_devCount = -1; return; }
     g_devCount = 0;
+    for (int d = 0; d < 64; d++) g_ldsOrdered[d] = -1;
     for (int d = 0; d < n && g_devCount < 64; d++) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, d) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -1360,7 +1436,9 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     }
     a.chain = nullptr;
     a.chainStride = 0;
+    a.orderedLds = 0;
     if (a.prof.chainDepth) {
+        a.orderedLds = (uint32_t)probe_lds_order(device, phys(device));
         const size_t need = qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen);
         if (!d_work || workBytes < need) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
         a.chain = static_cast<uint4 *>(d_work);
