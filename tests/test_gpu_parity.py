@@ -130,3 +130,35 @@ def test_segment_work_items(gpu_plugin, oracle, level):
     blk = K.text(3, 70000)
     counts, _, _ = gpu_plugin.find_batch([blk, blk, blk], level, parse_from=[1000, 98304, 32768])
     assert counts[0] == B.NSEQ_ERROR and counts[1] == B.NSEQ_ERROR and counts[2] != B.NSEQ_ERROR
+
+
+def test_chain_insert_ballot_path_in_a_child_process():
+    """The chain levels insert a tile with one returning ds_max per window where the device's LDS serves same-address lanes in
+    lane order (probed once per device).  The ballot path it replaces stays as the fallback: force it in a fresh process
+    (QZSTD_HIP_ORDERED_LDS=0 is read at the first launch) and compare with the oracle there too — degenerate blocks included,
+    where every lane of a window hits one slot."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tools"))
+import numpy as np
+import qz_bind as B, qz_corpus as K
+plug, orc = B.Plugin(B.PLUGIN_SO), B.Oracle()
+data = K.by_name("system", 6 * 131072, seed=3)
+blocks = [data[o:o + 131072] for o in range(0, len(data), 131072)] + [bytes(131072), b"ab" * 50000, (b"abcdefgh" * 5 + b"X") * 3000,
+          K.by_name("weblog", 32768, seed=5)]
+for level in (5, 6, 9, 12):
+    counts, seqs, stride = plug.find_batch(blocks, level)
+    a = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)
+    for i, blk in enumerate(blocks):
+        n, want = orc.find(orc.profile(level, len(blk)), blk, cap=stride)
+        assert counts[i] == n, (level, i, counts[i], n)
+        w = np.frombuffer(want, dtype=np.uint32).reshape(-1, 4)[:n, :3]
+        assert np.array_equal(a[i * stride:i * stride + n, :3], w), (level, i)
+print("ballot path ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, QZSTD_HIP_ORDERED_LDS="0"))
+    assert out.returncode == 0 and "ballot path ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
