@@ -33,3 +33,26 @@ def test_reference_caller_builds_unchanged_and_runs(tmp_path, plugin, prog, args
     assert out.returncode == 0, (out.stdout + out.stderr)[-800:]
     text = out.stdout + out.stderr
     assert "FAIL" not in text and "failed" not in text.lower() and ("PASS" in text or "successful" in text), text[-800:]
+
+
+def test_install_tree_is_self_contained(tmp_path, plugin):
+    """`make install DESTDIR=...` lays down the reference's artefacts under the reference's names (src/Makefile:89-103) and a
+    program builds against nothing but that tree (+ libzstd); `make uninstall` removes them again."""
+    dest = tmp_path / "root"
+    subprocess.check_call(["make", "-C", B.PKG_DIR, "install", "DESTDIR=" + str(dest)], stdout=subprocess.DEVNULL)
+    lib, inc = dest / "usr/local/lib", dest / "usr/local/include"
+    for f in (lib / "libqatseqprod.so", lib / "libqatseqprod.a", inc / "qatseqprod.h"):
+        assert f.is_file(), f
+    src = tmp_path / "use.c"
+    src.write_text('#include <stdio.h>\n#include "qatseqprod.h"\n'
+                   'int main(void) { int rc = QZSTD_startQatDevice(); void *s = QZSTD_createSeqProdState();\n'
+                   '  printf("version %s start %d state %s\\n", QZSTD_VERSION, rc, s ? "ok" : "null");\n'
+                   '  QZSTD_freeSeqProdState(s); QZSTD_stopQatDevice(); return s ? 0 : 1; }\n')
+    zlib = B.find_libzstd()
+    exe = str(tmp_path / "use")
+    subprocess.check_call(["gcc", "-O1", "-o", exe, str(src), "-I" + str(inc), "-L" + str(lib), "-lqatseqprod", zlib,
+                           "-Wl,-rpath," + str(lib), "-Wl,-rpath," + os.path.dirname(zlib), "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "state ok" in out.stdout, out.stdout + out.stderr
+    subprocess.check_call(["make", "-C", B.PKG_DIR, "uninstall", "DESTDIR=" + str(dest)], stdout=subprocess.DEVNULL)
+    assert not (lib / "libqatseqprod.so").exists() and not (inc / "qatseqprod.h").exists()
