@@ -129,7 +129,7 @@ def build_tools():
     tdir = os.path.join(B.PKG_DIR, "test")
     zpath = B.find_libzstd()
     subprocess.call(["make", "-C", B.PKG_DIR, "ZSTDLIB=" + zpath], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    for tgt in ("benchmark", "benchmark_sw", "frontbench"):
+    for tgt in ("benchmark", "benchmark_sw", "frontbench", "replaybench"):
         subprocess.call(["make", "-C", tdir, tgt, "ZSTDLIB=" + zpath], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return tdir
 
@@ -185,6 +185,27 @@ def frontbench(sample_file: str, block: int, level: int, threads: int, mode: int
         return {"MBps_wall": float(m.group(3)), "MBps_wall_best_pass": float(m.group(4)), "threads": threads, "bytes": int(m.group(1)),
                 "csize": int(m.group(2)), "blocks_from_announcements": int(m.group(5)), "blocks_per_block_path": int(m.group(6)),
                 "roundtrip": m.group(7), "tool": "qat-zstd-plugin_amd/test/frontbench " + " ".join(cmd[1:-1])}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
+def replaybench(sample_file: str, block: int, level: int, threads: int, loops: int = 3):
+    """qat-zstd-plugin_amd/test/replaybench: ZSTD_compress2 with the plugin's own sequences recorded once and replayed by a producer
+    that costs one memcpy per block — the ceiling of ANY external sequence producer with this libzstd on these cores"""
+    import re
+    import subprocess
+    exe = os.path.join(B.PKG_DIR, "test", "replaybench")
+    try:
+        if not os.path.isfile(exe):
+            return {"error": "replaybench not built"}
+        cmd = [exe, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level, sample_file]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        m = re.search(r"(\d+) of (\d+) blocks recorded, csize (\d+), ([0-9.]+) MB/s wall \(best pass ([0-9.]+)\), round trip (PASS|FAIL)", out.stdout)
+        if out.returncode != 0 or not m:
+            return {"error": (out.stdout + out.stderr)[-300:]}
+        return {"MBps_wall": float(m.group(4)), "MBps_wall_best_pass": float(m.group(5)), "threads": threads, "blocks_recorded": int(m.group(1)),
+                "blocks": int(m.group(2)), "csize": int(m.group(3)), "roundtrip": m.group(6),
+                "tool": "qat-zstd-plugin_amd/test/replaybench " + " ".join(cmd[1:-1])}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
 
@@ -473,6 +494,16 @@ def main():
             out["frontend"] = {"gpu": frontbench(fbig, block, level, base_t, 1, seg_mib=2),
                                "gpu_more_threads": frontbench(fbig, block, level, t_more, 1, seg_mib=2),
                                "software_libzstd_1_5": frontbench(fbig, block, level, base_t, 0, loops=1, seg_mib=2)}
+            # the ceiling: the same caller shape with a producer that costs nothing (the plugin's own sequences, recorded, replayed by
+            # memcpy) — what the host's cores and this libzstd's entropy stage allow ANY external producer; a quarter of the buffer
+            with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+                f.write(shard[:min(len(shard), 1024 * block)])
+                fq = f.name
+            out["e2e_ceiling_replay"] = {"threads_%d" % base_t: replaybench(fq, block, level, base_t),
+                                         "threads_%d" % t_more: replaybench(fq, block, level, t_more),
+                                         "what": "ZSTD_compress2, recorded plugin sequences replayed by a memcpy-only producer: the Amdahl ceiling "
+                                                 "of any external sequence producer on these cores with this libzstd"}
+            os.unlink(fq)
             os.unlink(fbig)
             cands = [(row[n]["MBps_wall"], row["threads"], n) for row in sweep for n in ("announced", "plain", "lookahead") if row[n].get("MBps_wall")]
             cands += [(r["MBps_wall"], r["threads"], "batch front-end") for r in out["frontend"].values()
@@ -485,6 +516,9 @@ def main():
                                     "vs_cpu_libzstd_1_4": round(v / sw14["MBps_wall"], 3) if sw14.get("MBps_wall") else None,
                                     "ratio_within_2pct": all(row[n2].get("csize_vs_sw", 1.0) <= 1.02 for row in sweep for n2 in ("announced", "plain")),
                                     "how": "best of e2e_sweep (C benchmark tool, one buffer per thread) and frontend (one shared buffer, include/qzstd_frontend.h)"}
+                ceil = max([r.get("MBps_wall", 0.0) for r in out["e2e_ceiling_replay"].values() if isinstance(r, dict)] + [0.0])
+                if ceil:
+                    out["value_e2e"]["frac_of_replay_ceiling"] = round(v / ceil, 3)
             # ... the announced path with ZSTD_c_searchForExternalRepcodes on (-E1) and the repeat-offset aware parse
             rep = c_benchmark(fname, block, level, base_t, mode=1, hint=16, ext_rep=1, loops=4, env={"QZSTD_HIP_EXT_REPCODES": "1"})
             if "csize" in rep and "csize" in sw:

@@ -456,3 +456,20 @@ def test_streaming_caller_is_served_from_an_announcement_by_content(mock, zstd, 
     mock.lib.QZSTD_freeSeqProdState(st)
     assert zstd.decompress(dst.raw[:out.pos], len(data)) == data
     assert stats[0] >= 9 and stats[0] + stats[1] == 10, stats  # the nine full blocks (and maybe the tail) by content
+
+
+def test_replay_ceiling_tool_over_the_mock(mock, zstd, tmp_path):
+    """test/replaybench.c (the ceiling of any external producer: recorded sequences replayed by memcpy): over the mock every
+    block is recorded from the real producer path, replayed from several threads, and the frames round-trip — same size as
+    the producer path itself gives."""
+    exe = str(tmp_path / "replaybench")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(B.PKG_DIR, "test", "replaybench.c"), MOCK_SO, zstd.path,
+                           "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path), "-lpthread"])
+    f = tmp_path / "in.bin"
+    data = K.by_name("system", 20 * 131072 + 777, seed=2)
+    f.write_bytes(data)
+    for args, nrec in ((["-t3", "-l1", "-c128K", "-L1"], 21), (["-t2", "-l1", "-c256K", "-L6"], 21), (["-t2", "-l1", "-c32K", "-L12"], 81)):
+        out = subprocess.run([exe] + args + [str(f)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "round trip PASS" in out.stdout, out.stdout + out.stderr
+        assert "%d of %d blocks recorded" % (nrec, nrec) in out.stdout, out.stdout
