@@ -478,26 +478,30 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
                                                RepState &st)
 {
     const uint32_t tileLim = umin(base + kTile, nh), stop = umin(limit, nh);
+    if (st.cur >= stop) return;
+    /* the span lies inside one tile, a tile inside one segment: both are fixed for the call */
+    const uint32_t segEnd = seg_end(pf, base, n);
+    if (pf.segLog && (base >> pf.segLog) != st.seg) { /* a new segment starts without repeat offsets */
+        st.rep1 = st.rep2 = 0u;
+        st.seg = base >> pf.segLog;
+    }
+    uint32_t rc = rdfirst(ring_off_s(st.cur)); /* ring offset of the cursor, kept incrementally */
+    const __attribute__((address_space(3))) uint8_t *rb = reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(src.ring);
     while (st.cur < stop) {
-        const uint32_t W = umin(pf.repWin, tileLim - st.cur), V = umin(W + 2u, tileLim - st.cur);
-        const uint32_t segEnd = seg_end(pf, st.cur, n); /* windows never cross a tile edge, so never a segment's end */
+        const uint32_t rem = tileLim - st.cur;
+        const uint32_t W = umin(pf.repWin, rem), V = umin(W + 2u, rem);
+        const uint32_t curIn = st.cur;
         uint32_t wd = 0;
-        if (pf.segLog && (st.cur >> pf.segLog) != st.seg) { /* a new segment starts without repeat offsets */
-            st.rep1 = st.rep2 = 0u;
-            st.seg = st.cur >> pf.segLog;
-        }
         if (lane < V) wd = pvT[st.cur + lane - base]; /* the candidate of the window position: gain | offset << 10 */
         u64 M1, M2;
         if (st.rep1 <= kNear && st.rep2 <= kNear) { /* the usual case: both sources inside the ring */
-            const uint32_t rc = rdfirst(ring_off_s(st.cur));
-            const uint32_t r1 = rdfirst(ring_off_s(st.cur - st.rep1)), r2 = rdfirst(ring_off_s(st.cur - st.rep2)); /* offsets never reach before the block */
-            uint32_t oa = rc + lane, o1 = r1 + lane, o2 = r2 + lane;
-            oa = umin(oa, oa - kRing); o1 = umin(o1, o1 - kRing); o2 = umin(o2, o2 - kRing);
-            const __attribute__((address_space(3))) uint8_t *rb = reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(src.ring);
-            const uint32_t A = rb[oa], B1 = rb[o1], B2 = rb[o2]; /* three byte loads, one wait */
-            const bool inBlock = lane < segEnd - st.cur; /* a repeat match never leaves its segment either */
-            M1 = __ballot(inBlock && st.rep1 != 0u && A == B1);
-            M2 = __ballot(inBlock && st.rep2 != 0u && A == B2);
+            /* 64 bytes from each of the three ring offsets: what runs over the ring's end is in the mirror (kMirror >= 64) */
+            const uint32_t t1 = rc - st.rep1, t2 = rc - st.rep2; /* offsets never reach before the block */
+            const uint32_t r1 = umin(t1, t1 + kRing), r2 = umin(t2, t2 + kRing);
+            const uint32_t A = rb[rc + lane], B1 = rb[r1 + lane], B2 = rb[r2 + lane]; /* three byte loads, one wait */
+            const u64 in = below(segEnd - st.cur); /* a repeat match never leaves its segment either */
+            M1 = st.rep1 ? __ballot(A == B1) & in : 0ull;
+            M2 = st.rep2 ? __ballot(A == B2) & in : 0ull;
         } else {
             M1 = rep_bitmap(src, st.cur, st.rep1, segEnd, lane);
             M2 = rep_bitmap(src, st.cur, st.rep2, segEnd, lane);
@@ -518,6 +522,7 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
         const u64 m = __ballot(ok);
         if (!m) { /* nothing on offer in this window */
             st.cur += W;
+            rc = ring_fwd(rc, W);
             continue;
         }
         const uint32_t ks = (uint32_t)__builtin_ctzll(m);
@@ -552,6 +557,8 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
             st.rep1 = off;
         }
         st.cur = st.anchor = q + L;
+        rc = rdfirst(ring_off_s(st.cur)); /* a match may be long: recompute */
+        (void)curIn;
     }
 }
 
