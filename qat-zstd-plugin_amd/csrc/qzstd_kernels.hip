@@ -685,17 +685,60 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     src.g = (HbmWords)reinterpret_cast<const uint32_t *>(gsrc);
     const uint32_t nPad = (n + 15u) & ~15u; /* the caller keeps the buffer readable up to here */
 
-    /* ---- prefill the ring with the first kTile + kLook bytes (16 B per lane, coalesced), clear the tables ---- */
+    /* ---- clear the tables; segment mode below the chain levels: fast-forward over the tiles before the segment ---- */
+    /* A segment item only INSERTS the positions before its segment.  Where the tables hold "the newest position of a slot"
+     * and nothing else (levels 1-4: ds_max, no chains to link), the order of those inserts does not matter: all 576 threads
+     * hash them straight from HBM, no ring, no barriers, and the tile loop starts at the segment's first tile — the state it
+     * finds (tables, ring) is exactly what iterating over the history tiles would have left.  itBegin = that first tile. */
+    const uint32_t itBegin = CHAIN ? 0u : firstTile;
     {
-        const uint32_t first = umin(nPad, kTile + kLook);
-        for (uint32_t o = tid * 16u; o < kTile + kLook; o += kThreads * 16u) {
-            const uint4 v = o < first ? g128[o >> 4] : make_uint4(0u, 0u, 0u, 0u);
-            ring128[o >> 4] = v;
-            if (o < kMirror) ring128[(kRing + o) >> 4] = v;
-        }
         for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
         for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
+    }
+    if (itBegin != 0u) {
+        __syncthreads(); /* the cleared tables */
+        const uint32_t hiMaskH = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
+        const uint32_t histEnd = itBegin << kTileLog; /* = parseFrom: a segment boundary, so every position before it hashes bytes before it */
+        /* 16 positions per thread and step: two coalesced 16-byte loads, the hashes from registers (a 16-byte chunk never
+         * straddles a segment boundary; the bytes behind it exist: parseFrom < n) */
+        for (uint32_t c = tid * 16u; c < histEnd; c += kThreads * 16u) {
+            const uint4 a4 = g128[c >> 4], b4 = g128[(c >> 4) + 1u];
+            const uint32_t W[6] = { a4.x, a4.y, a4.z, a4.w, b4.x, b4.y };
+            const uint32_t segEc = seg_end(pf, c, n);
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) {
+                const uint32_t p = c + k;
+                if (p + pf.hashBytes <= segEc) { /* oracle: qzo_hashable */
+                    const uint32_t v = __builtin_amdgcn_alignbyte(W[(k >> 2) + 1u], W[k >> 2], k & 3u);
+                    const uint32_t w = __builtin_amdgcn_alignbyte(W[(k >> 2) + 2u], W[(k >> 2) + 1u], k & 3u);
+                    const uint32_t mixH = (v * kPrime1) ^ ((pf.hashBytes > 4 ? w & hiMaskH : 0u) * kPrime2);
+                    atomicMax(&tbl[__umulhi(mixH, pf.tableSize)], ((p + 1u) << kTagBits) | ((mixH >> 3) & kTagMask));
+                    if (HAS_LONG && p + 8u <= segEc) {
+                        const uint32_t m8 = (v * kPrime1) ^ (w * kPrime2);
+                        atomicMax(&tblL[__umulhi(m8, pf.longSize)], ((p + 1u) << kTagBits) | ((m8 >> 3) & kTagMask));
+                    }
+                }
+            }
+        }
+        if (TURNS && tid == 0u) *turnCtr = itBegin * (uint32_t)kMatchWaves; /* the turn the first tile's wave 0 waits for */
+    }
+    /* ---- prefill the ring with what the loop expects at its first iteration: everything up to itBegin * kTile + kLook (one
+     * tile more when the loop starts at tile 0, whose iteration stages nothing), at most kRing bytes back ---- */
+    {
+        const uint32_t hi = umin(nPad, (itBegin << kTileLog) + kLook + (itBegin ? 0u : kTile));
+        const uint32_t lo = hi > kRing ? (hi - kRing + 15u) & ~15u : 0u;
+        for (uint32_t o = lo + tid * 16u; o < hi; o += kThreads * 16u) {
+            const uint4 v = g128[o >> 4];
+            const uint32_t r = ring_dw(o) << 2;
+            ring128[r >> 4] = v;
+            if (r < kMirror) ring128[(kRing + r) >> 4] = v;
+        }
+        if (itBegin == 0u) /* short blocks: zeros behind the end, as before */
+            for (uint32_t o = hi + tid * 16u; o < kTile + kLook; o += kThreads * 16u) {
+                ring128[o >> 4] = make_uint4(0u, 0u, 0u, 0u);
+                if (o < kMirror) ring128[(kRing + o) >> 4] = make_uint4(0u, 0u, 0u, 0u);
+            }
     }
     __syncthreads();
 
@@ -714,7 +757,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         uint32_t nseqEnd, anchorEnd;
         if (REP) {
             RepState st = { blk.parseFrom, blk.parseFrom, 0u, 0u, 0u, 0u, pf.segLog ? blk.parseFrom >> pf.segLog : 0u };
-            for (uint32_t it = 0; it < nTiles + 2u; it++) {
+            for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u, base = k << kTileLog;
                 uint32_t *pvT = pv + (k & 1u) * kPvStride, *srecT = srec + (k & 1u) * kWin * kSrecWords;
@@ -736,7 +779,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             anchorEnd = st.anchor;
         } else {
             ParseState st = { blk.parseFrom, blk.parseFrom, 0u };
-            for (uint32_t it = 0; it < nTiles + 2u; it++) {
+            for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u;
                 if (work)
@@ -778,7 +821,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 
     /* (offset, jump length) of this thread's position in tiles it-1 and it-2 */
     uint32_t offA = 0, lenA = 0, offB = 0, lenB = 0;
-    uint32_t rp = tid; /* ring offset of the own position, advanced by one tile per iteration */
+    uint32_t rp = ring_dw((itBegin << kTileLog) + tid) << 2 | (tid & 3u); /* ring offset of the own position, advanced by one tile per iteration */
 #ifdef QZ_DEBUG_DUMP
     u64 dI1 = 0, dW1 = 0, dI2 = 0, dW2 = 0, tP = __builtin_amdgcn_s_memtime();
 #define QZ_LAP(acc) { const u64 tN = __builtin_amdgcn_s_memtime(); acc += tN - tP; tP = tN; }
@@ -786,7 +829,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 #define QZ_LAP(acc)
 #endif
 
-    for (uint32_t it = 0; it < nTiles + 2u; it++) {
+    for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
         const uint32_t t0 = it << kTileLog;
         const uint32_t p = t0 + tid; /* own position in tile it */
         const uint32_t stamp = (nTilesMax - 1u - (it & (nTilesMax - 1u))) << stampShift;
