@@ -39,7 +39,8 @@ def timing():
     plug = B.Plugin(os.environ.get("QZ_PLUGIN_SO", os.path.join(B.PKG_DIR, "lib", "libqatseqprod_dbg.so")))
     data = K.system_corpus(int(os.environ.get("QZ_BLOCKS", "256")) * 131072)[0]  # 256 = one workgroup per CU, 512 = two
     blocks = [data[o:o + 131072] for o in range(0, len(data), 131072)]
-    counts, seqs, stride = plug.find_batch(blocks, int(os.environ.get("QZ_LEVEL", "1"), 0))
+    pf = int(os.environ.get("QZ_PARSE_FROM", "0"))  # segment items: the tiles before this position are history
+    counts, seqs, stride = plug.find_batch(blocks, int(os.environ.get("QZ_LEVEL", "1"), 0), parse_from=[pf] * len(blocks) if pf else None)
     a = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)
     rows = np.array([a[(i + 1) * stride - 1] for i in range(len(blocks))], dtype=np.float64)
     c = np.array(counts, dtype=np.float64)
