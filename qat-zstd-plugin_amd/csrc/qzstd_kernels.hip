@@ -1015,8 +1015,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
                         if (linkE != 0u && walked + (uint32_t)k < pf.chainDepth) {
                             const uint32_t q = (linkE >> kTagBits) - 1u;
                             const bool hit = (linkE & kTagMask) == tag && (pf.window == 0u || p - q <= pf.window);
-                            bool maybe = hit && !QZ_ABLATED(2u);
                             const bool far = p - q > kNear;
+                            bool maybe = hit && !QZ_ABLATED(2u) && !(QZ_ABLATED(64u) && far); /* profiling: 64 = what the HBM-side candidates cost */
                             if (maybe && cl != 0u) {
                                 /* links come nearest first, so a later one can only win with MORE matching bytes than the best so
                                  * far (its offset costs at least as much): it has to match at byte cl, in particular.  Four bytes
