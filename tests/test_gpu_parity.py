@@ -122,6 +122,17 @@ def test_segment_work_items(gpu_plugin, oracle, level):
         for s0 in range(0, len(blk), 32768):
             items.append(blk[:min(len(blk), s0 + 32768)])
             froms.append(s0)
+    # items that end right behind a segment boundary (the fast-forward over the history reads 16 bytes past parseFrom - 16;
+    # the tile loop starts with a ring prefilled from the middle of the block), degenerate content included
+    base = K.by_name("system", 131072, seed=31)
+    for s0 in (32768, 65536, 98304):
+        for extra in (1, 2, 7, 15, 16, 17, 31, 511, 512, 513, 4607, 4608, 4609):
+            items.append(base[:s0 + extra])
+            froms.append(s0)
+    for blk in (bytes(131072), b"ab" * 65536, (b"abcdefgh" * 5 + b"X") * 3197):
+        for s0 in (32768, 98304):
+            items.append(blk[:min(len(blk), s0 + 32768)])
+            froms.append(s0)
     counts, seqs, stride = gpu_plugin.find_batch(items, level, parse_from=froms)
     for i, (blk, s0) in enumerate(zip(items, froms)):
         want_n, want = oracle.find(oracle.profile(level, len(blk)), blk, cap=stride, parse_from=s0)
