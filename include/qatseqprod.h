@@ -132,6 +132,15 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
  * the per-block path, [2] = announcements accepted, [3] = microseconds spent waiting for the GPU. */
 void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4]);
 
+/* Callbacks of this state that returned ZSTD_SEQUENCE_PRODUCER_ERROR, by cause — with ZSTD_c_enableSeqProducerFallback = 1
+ * libzstd compresses such a block with its own match-finder and says nothing, so this is the only place they show (the
+ * reference counts one cause only: failOffloadCnt, src/qatseqprod.c:122,:1141):
+ *   stats[0] all of them = [1] argument guards (window, dictionary, level; reference :1123-1137) + [2] device not started
+ *   + [3] time-outs (QZSTD_HIP_TIMEOUT_MS) + [4] capacity rule (count >= capacity - 1, reference :1318) + [5] runtime errors
+ *   (allocation, launch, no free slot);  stats[6] = blocks too dense for a batch's result area that were redone alone
+ *   (served, not errors);  stats[7] = blocks served by the resident service (a subset of QZSTD_hintStats' [1]). */
+void QZSTD_failStats(void *sequenceProducerState, unsigned long stats[8]);
+
 #if defined(__cplusplus)
 }
 #endif

@@ -53,6 +53,11 @@ size_t QZSTD_frontCompact(const QZSTD_Front *f, void *dst, const size_t *frameSi
 /* blocks served from an announcement / per block, summed over the workers' states, since creation */
 void QZSTD_frontStats(QZSTD_Front *f, unsigned long stats[2]);
 
+/* producer callbacks that returned the error code — those blocks were compressed by libzstd's own match-finder (the
+ * front-end switches ZSTD_c_enableSeqProducerFallback on) — summed over the workers' states, by cause: the layout of
+ * QZSTD_failStats() in qatseqprod.h.  A run whose stats[0] is not 0 was not served by the GPU alone. */
+void QZSTD_frontFailStats(QZSTD_Front *f, unsigned long stats[8]);
+
 void QZSTD_freeFront(QZSTD_Front *f);
 
 #if defined(__cplusplus)

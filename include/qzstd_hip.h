@@ -59,16 +59,16 @@ typedef struct {
                          * array in device memory: chain[p] = the slot's content before p's tile), n candidates deep */
     uint32_t subTileLog; /* 0 = the tables are updated once per tile; n = per 1<<n positions, in position order
                          * (GPU: the matcher waves take turns), so a position also sees the earlier sub-tiles of its tile */
-    uint32_t segLog;     /* 0 = none; n = no match crosses a multiple of 1<<n (15 at every level): one block may then be submitted as
-                         * several work items that each parse one segment (qzstd_hip_block_t.parseFrom) — what the per-block
-                         * path does to cut the latency of a lone request */
+    uint32_t segLog;     /* 0 = none; n = no match crosses a multiple of 1<<n (12 at every level): one block may then be submitted as
+                         * several work items that each parse a run of whole segments (qzstd_hip_block_t.parseFrom) — what the
+                         * per-block paths do to cut the latency of a lone request */
 } qzstd_hip_profile_t;
 
 /* One work item = one <=128 KiB block, parsed with no history
- * (reference contract: src/qatseqprod.h:103-105) — or one SEGMENT of such a block: parseFrom != 0 (a multiple of
+ * (reference contract: src/qatseqprod.h:103-105) — or a run of whole SEGMENTS of such a block: parseFrom != 0 (a multiple of
  * 1 << profile.segLog) makes the workgroup insert [0, parseFrom) into its
  * tables without parsing it and emit the sequences of [parseFrom, srcLen) only; srcLen is then the block up to the
- * segment's end.  The segments' sequence lists, concatenated with the trailing literals carried over, equal the
+ * end of the item's last segment.  The items' sequence lists, concatenated with the trailing literals carried over, equal the
  * sequences of the whole block submitted as one item. */
 typedef struct {
     uint64_t srcOff;  /* byte offset of the block inside d_src, multiple of QZSTD_HIP_SRC_ALIGN */
@@ -140,6 +140,47 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
                              const qzstd_hip_block_t *d_blocks, uint32_t nBlocks,
                              uint32_t maxBlockLen, void *d_seqs, uint32_t *d_nseq,
                              void *d_work, size_t workBytes);
+
+/*
+ * The resident service: one block per request WITHOUT a launch (reference: the synchronous submit + poll of one
+ * request on a DC instance, src/qatseqprod.c:1243-1272; many instances per device :905-928).  A request names the caller's
+ * own buffers: the block staged in pinned host memory, a device staging buffer of the same size, a pinned result area and
+ * one pinned count word per work item.  The block is cut into nItems work items of itemBytes (a multiple of the level's
+ * segment size, 1 << profile.segLog; the last item takes the rest); item k parses [k * itemBytes, min(srcLen, (k + 1) *
+ * itemBytes)), writes its sequences to hSeqs + k * seqCapPerItem and then — last, with a system-scope release — its count
+ * (sequences including the item's delimiter, QZSTD_HIP_NSEQ_ERROR, or QZSTD_HIP_NSEQ_REJECTED) to hCount[k], which the
+ * caller has zeroed and polls: the count is the completion flag, no stream, no query.  The items' lists, joined with
+ * the trailing literals carried over, are the sequences of the block.
+ *
+ * Resident kernels (one worker workgroup per CU + a one-wave dispatcher) are launched by the first request and leave
+ * after QZSTD_HIP_SERVICE_IDLE_US (default 20000) without work, when memory is freed, or on qzstd_hip_service_stop().
+ * Served: the levels whose workgroups leave half of a CU's LDS free (1, 2 and their | QZSTD_HIP_LEVEL_REPCODES forms).
+ *
+ *   qzstd_hip_service_submit   0 = queued;  1 = not served (level, QZSTD_HIP_SERVICE=0, another level is resident, the
+ *                              service is down): the caller takes the launch path;  < 0 = error
+ */
+#define QZSTD_HIP_NSEQ_REJECTED 0xFFFFFFFEu
+#define QZSTD_HIP_SVC_MAX_ITEMS 32u
+#define QZSTD_HIP_SVC_MAX_SLOTS 1024u
+typedef struct {
+    const void *hSrc;   /* pinned host memory: the block, readable up to the next multiple of 16 */
+    void *dSrc;         /* device memory, same size: the items copy their slices there */
+    void *hSeqs;        /* pinned: nItems x seqCapPerItem ZSTD_Sequence entries */
+    uint32_t *hCount;   /* pinned: nItems words, zeroed by the caller before the call */
+    uint32_t srcLen, itemBytes, nItems, seqCapPerItem;
+    uint32_t slot;      /* < QZSTD_HIP_SVC_MAX_SLOTS: one request in flight per slot (its slices' flags) */
+    uint32_t epoch;     /* 1 .. 0xFFFFFF, different from the slot's previous request */
+} qzstd_hip_svc_req_t;
+int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *req);
+int qzstd_hip_service_stop(int device);          /* asks the resident kernels to leave and waits for them; 0 = stopped */
+void qzstd_hip_service_mark_broken(int device);  /* a request timed out: stop and do not use the service again */
+/* out[0] launches of the service, [1] requests queued, [2] requests refused (another level resident), [3] broken,
+ * [4] state (0 stopped, 1 running), [5] items finished, [6] items that gave up waiting for a slice, [7] workers */
+int qzstd_hip_service_info(int device, unsigned long out[8]);
+/* diagnostics the dispatcher refreshes while it runs: [0] its polls of the ring, [1] requests taken, [2] items queued, [3] worker
+ * workgroups that have started, [4] items picked up, [5] items finished, [6] requests consumed over all launches, [7] 0 */
+int qzstd_hip_service_debug(int device, unsigned long out[8]);
+void *qzstd_hip_host_alloc_coherent(size_t bytes); /* pinned + mapped + fine-grained: what the host polls while a kernel writes it */
 
 #if defined(__cplusplus)
 }

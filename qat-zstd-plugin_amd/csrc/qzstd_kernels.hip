@@ -48,6 +48,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <sched.h>
 #include <time.h>
@@ -477,10 +478,14 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
                                                uint32_t base, uint32_t limit, uint32_t n, uint32_t nh, uint32_t lane,
                                                RepState &st)
 {
-    const uint32_t tileLim = umin(base + kTile, nh), stop = umin(limit, nh);
-    if (st.cur >= stop) return;
-    /* the span lies inside one tile, a tile inside one segment: both are fixed for the call */
+    /* the span lies inside one tile, a tile inside one segment: both are fixed for the call.  No match — a repeat neither —
+     * starts in the last hashBytes - 1 positions of a segment (oracle: qzo_parse_rep, startEnd): the cursor a segment leaves
+     * there moves on to the next segment's first position */
     const uint32_t segEnd = seg_end(pf, base, n);
+    const uint32_t startEnd = segEnd - pf.hashBytes + 1u; /* <= nh */
+    const uint32_t tileLim = umin(base + kTile, startEnd), stop = umin(limit, startEnd);
+    if (st.cur < base) st.cur = base;
+    if (st.cur >= stop) return;
     if (pf.segLog && (base >> pf.segLog) != st.seg) { /* a new segment starts without repeat offsets */
         st.rep1 = st.rep2 = 0u;
         st.seg = base >> pf.segLog;
@@ -636,8 +641,14 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
  * parse, CHAIN (levels >= 5) the walk along the main table's predecessor chain in device memory, TURNS (level 2 and
  * levels >= 5) the per-wave ordered table updates.
  */
+/* One work item (a block, or a run of whole segments of one): `blk` describes it, gsrc = the block's bytes in device memory,
+ * out = the item's result region, chainB = its chain entries (CHAIN).  Returns, in the parse wave, the item's sequence
+ * count including the delimiter or QZSTD_HIP_NSEQ_ERROR (every thread returns that for an item that is refused); the matcher
+ * waves return 0.  Both kernels below are thin shells around it: one launch = one item per workgroup
+ * (qzstd_find_sequences_kernel), or a resident worker that takes items from a queue (qzstd_service_worker). */
 template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
-__global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
+__device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_hip_block_t &blk, const uint8_t *gsrc, uint4 *out,
+                                            uint4 *chainB)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -646,7 +657,6 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
      * scalar branch and the parse wave's chain state lives in SGPRs instead of exec-masked VGPRs */
     const uint32_t wave = rdfirst(tid >> 6);
     const bool matcher = wave < (uint32_t)kMatchWaves;
-    const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     const uint32_t n = blk.srcLen;
     const qzstd_hip_profile_t pf = args.prof;
     const uint32_t nh = n >= pf.hashBytes ? n - pf.hashBytes + 1u : 0u; /* hashable positions */
@@ -654,8 +664,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     /* segment mode (qzstd_hip_block_t.parseFrom): tiles before the segment are only inserted into the tables */
     const uint32_t firstTile = blk.parseFrom >> kTileLog;
     if (blk.parseFrom != 0u && (pf.segLog == 0u || (blk.parseFrom & ((1u << pf.segLog) - 1u)) != 0u || blk.parseFrom >= n)) {
-        if (tid == 0u) args.nseq[blockIdx.x] = QZSTD_HIP_NSEQ_ERROR; /* not a segment boundary of this level: refused */
-        return; /* uniform: before the first barrier */
+        return QZSTD_HIP_NSEQ_ERROR; /* not a segment boundary of this level: refused (uniform: before the first barrier) */
     }
 
     /* ---- LDS layout (81 600 B: two workgroups per CU) ---- */
@@ -666,8 +675,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) {
         /* the dynamic allocation does not start at LDS address 0 after all: refuse loudly (every block an error, the host
          * falls back) rather than touch memory that is not ours */
-        if (tid == 0u) args.nseq[blockIdx.x] = QZSTD_HIP_NSEQ_ERROR;
-        return; /* uniform: before the first barrier */
+        return QZSTD_HIP_NSEQ_ERROR; /* uniform: before the first barrier */
     }
     uint32_t *ring32 = reinterpret_cast<uint32_t *>(smemI);
     uint4 *ring128 = reinterpret_cast<uint4 *>(smemI);
@@ -678,7 +686,6 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kPvStride] per-position parse words         */
     uint32_t *turnCtr = pv + 2u * kPvStride;           /* whose turn it is to update the tables (TURNS)   */
     uint32_t *slotTag = turnCtr + 16u;                 /* [kTile] (CHAIN) slot | tag << 16 of the tile's positions, for the insert wave */
-    const uint8_t *gsrc = args.src + blk.srcOff;
     const uint4 *g128 = reinterpret_cast<const uint4 *>(gsrc);
     Src src;
     src.ring = (LdsWords)ring32;
@@ -691,49 +698,64 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
      * hash them straight from HBM, no ring, no barriers, and the tile loop starts at the segment's first tile — the state it
      * finds (tables, ring) is exactly what iterating over the history tiles would have left.  itBegin = that first tile. */
     const uint32_t itBegin = CHAIN ? 0u : firstTile;
+    /* One pass over [0, hi) does both jobs, 16 bytes per thread and step, the loads running two steps ahead of their use (a
+     * segment item spends most of its start-up here: 120 KiB of history in front of the last item of a block):
+     *   - chunks below histEnd (= parseFrom: a segment boundary, so every position before it hashes bytes before it) are
+     *     HASHED and inserted — 16 positions from two coalesced 16-byte loads (a chunk never straddles a segment boundary;
+     *     the bytes behind it exist: parseFrom < n);
+     *   - chunks from `lo` on are what the tile loop expects in the RING at its first iteration: everything up to
+     *     itBegin * kTile + kLook (one tile more when the loop starts at tile 0, whose iteration stages nothing), at most
+     *     kRing bytes back. */
+    const uint32_t histEnd = itBegin << kTileLog;
+    const uint32_t hi = umin(nPad, histEnd + kLook + (itBegin ? 0u : kTile));
+    const uint32_t lo = hi > kRing ? (hi - kRing + 15u) & ~15u : 0u;
+    constexpr uint32_t kStep = (uint32_t)kThreads * 16u;
+    uint32_t fo = (itBegin ? 0u : lo) + tid * 16u;
+    uint4 fa0 = make_uint4(0u, 0u, 0u, 0u), fb0 = fa0, fa1 = fa0, fb1 = fa0;
+    if (fo < hi) { fa0 = g128[fo >> 4]; if (fo < histEnd) fb0 = g128[(fo >> 4) + 1u]; }
+    if (fo + kStep < hi) { fa1 = g128[(fo + kStep) >> 4]; if (fo + kStep < histEnd) fb1 = g128[((fo + kStep) >> 4) + 1u]; }
     {
         for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
         for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
     }
-    if (itBegin != 0u) {
-        __syncthreads(); /* the cleared tables */
+    if (itBegin != 0u) __syncthreads(); /* the cleared tables, before the first insert */
+    {
         const uint32_t hiMaskH = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
-        const uint32_t histEnd = itBegin << kTileLog; /* = parseFrom: a segment boundary, so every position before it hashes bytes before it */
-        /* 16 positions per thread and step: two coalesced 16-byte loads, the hashes from registers (a 16-byte chunk never
-         * straddles a segment boundary; the bytes behind it exist: parseFrom < n) */
-        for (uint32_t c = tid * 16u; c < histEnd; c += kThreads * 16u) {
-            const uint4 a4 = g128[c >> 4], b4 = g128[(c >> 4) + 1u];
-            const uint32_t W[6] = { a4.x, a4.y, a4.z, a4.w, b4.x, b4.y };
-            const uint32_t segEc = seg_end(pf, c, n);
+        for (; fo < hi; fo += kStep) {
+            uint4 fa2 = make_uint4(0u, 0u, 0u, 0u), fb2 = fa2;
+            const uint32_t o2 = fo + 2u * kStep;
+            if (o2 < hi) { fa2 = g128[o2 >> 4]; if (o2 < histEnd) fb2 = g128[(o2 >> 4) + 1u]; }
+            if (fo >= lo) {
+                const uint32_t r = ring_dw(fo) << 2;
+                ring128[r >> 4] = fa0;
+                if (r < kMirror) ring128[(kRing + r) >> 4] = fa0;
+            }
+            if (fo < histEnd) {
+                /* segment mode below the chain levels: where the tables hold "the newest position of a slot" and nothing else
+                 * (ds_max, no chains to link), the order of the inserts does not matter, so the history is inserted here — no
+                 * ring, no barriers — and the tile loop starts at the segment's first tile: the state it finds (tables, ring)
+                 * is exactly what iterating over the history tiles would have left */
+                const uint32_t W[6] = { fa0.x, fa0.y, fa0.z, fa0.w, fb0.x, fb0.y };
+                const uint32_t segEc = seg_end(pf, fo, n);
 #pragma unroll
-            for (uint32_t k = 0; k < 16u; k++) {
-                const uint32_t p = c + k;
-                if (p + pf.hashBytes <= segEc) { /* oracle: qzo_hashable */
-                    const uint32_t v = __builtin_amdgcn_alignbyte(W[(k >> 2) + 1u], W[k >> 2], k & 3u);
-                    const uint32_t w = __builtin_amdgcn_alignbyte(W[(k >> 2) + 2u], W[(k >> 2) + 1u], k & 3u);
-                    const uint32_t mixH = (v * kPrime1) ^ ((pf.hashBytes > 4 ? w & hiMaskH : 0u) * kPrime2);
-                    atomicMax(&tbl[__umulhi(mixH, pf.tableSize)], ((p + 1u) << kTagBits) | ((mixH >> 3) & kTagMask));
-                    if (HAS_LONG && p + 8u <= segEc) {
-                        const uint32_t m8 = (v * kPrime1) ^ (w * kPrime2);
-                        atomicMax(&tblL[__umulhi(m8, pf.longSize)], ((p + 1u) << kTagBits) | ((m8 >> 3) & kTagMask));
+                for (uint32_t k = 0; k < 16u; k++) {
+                    const uint32_t p = fo + k;
+                    if (p + pf.hashBytes <= segEc) { /* oracle: qzo_hashable */
+                        const uint32_t v = __builtin_amdgcn_alignbyte(W[(k >> 2) + 1u], W[k >> 2], k & 3u);
+                        const uint32_t w = __builtin_amdgcn_alignbyte(W[(k >> 2) + 2u], W[(k >> 2) + 1u], k & 3u);
+                        const uint32_t mixH = (v * kPrime1) ^ ((pf.hashBytes > 4 ? w & hiMaskH : 0u) * kPrime2);
+                        atomicMax(&tbl[__umulhi(mixH, pf.tableSize)], ((p + 1u) << kTagBits) | ((mixH >> 3) & kTagMask));
+                        if (HAS_LONG && p + 8u <= segEc) {
+                            const uint32_t m8 = (v * kPrime1) ^ (w * kPrime2);
+                            atomicMax(&tblL[__umulhi(m8, pf.longSize)], ((p + 1u) << kTagBits) | ((m8 >> 3) & kTagMask));
+                        }
                     }
                 }
             }
+            fa0 = fa1; fb0 = fb1; fa1 = fa2; fb1 = fb2;
         }
-        if (TURNS && tid == 0u) *turnCtr = itBegin * (uint32_t)kMatchWaves; /* the turn the first tile's wave 0 waits for */
-    }
-    /* ---- prefill the ring with what the loop expects at its first iteration: everything up to itBegin * kTile + kLook (one
-     * tile more when the loop starts at tile 0, whose iteration stages nothing), at most kRing bytes back ---- */
-    {
-        const uint32_t hi = umin(nPad, (itBegin << kTileLog) + kLook + (itBegin ? 0u : kTile));
-        const uint32_t lo = hi > kRing ? (hi - kRing + 15u) & ~15u : 0u;
-        for (uint32_t o = lo + tid * 16u; o < hi; o += kThreads * 16u) {
-            const uint4 v = g128[o >> 4];
-            const uint32_t r = ring_dw(o) << 2;
-            ring128[r >> 4] = v;
-            if (r < kMirror) ring128[(kRing + r) >> 4] = v;
-        }
+        if (itBegin != 0u && TURNS && tid == 0u) *turnCtr = itBegin * (uint32_t)kMatchWaves; /* the turn the first tile's wave 0 waits for */
         if (itBegin == 0u) /* short blocks: zeros behind the end, as before */
             for (uint32_t o = hi + tid * 16u; o < kTile + kLook; o += kThreads * 16u) {
                 ring128[o >> 4] = make_uint4(0u, 0u, 0u, 0u);
@@ -741,8 +763,6 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
             }
     }
     __syncthreads();
-
-    uint4 *out = args.seqs + blk.seqOff;
 
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
@@ -803,14 +823,11 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         if (lane == 0) out[blk.seqCap - 2u] = make_uint4((uint32_t)pI1, (uint32_t)pW1, (uint32_t)pI2, (uint32_t)pW2);
         if (lane == 0) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID: where the wave runs */
 #endif
-        if (lane == 0) {
-            /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
-            uint32_t count = nseqEnd + 1u;
-            if (nseqEnd < blk.seqCap) out[nseqEnd] = make_uint4(0u, n - anchorEnd, 0u, 0u);
-            if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
-            args.nseq[blockIdx.x] = count;
-        }
-        return;
+        /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
+        uint32_t count = nseqEnd + 1u;
+        if (lane == 0 && nseqEnd < blk.seqCap) out[nseqEnd] = make_uint4(0u, n - anchorEnd, 0u, 0u);
+        if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
+        return count;
     }
 
     /* ---------------- the 8 matcher waves ---------------- */
@@ -882,7 +899,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
         if (CHAIN) {
             /* the chain entry of that probable predecessor, fetched now so that it is there when the inserts are done (a
              * position of an earlier tile: its entry was stored at least one barrier ago) */
-            if (valid && old != 0u) pre = (args.chain + (size_t)blockIdx.x * args.chainStride)[(old >> kTagBits) - 1u];
+            if (valid && old != 0u) pre = chainB[(old >> kTagBits) - 1u];
             slotTag[tid] = valid ? (slot | (((mix >> 3) & kTagMask) << 16)) : kNone;
         }
         QZ_LAP(dI1)
@@ -911,7 +928,6 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
              *    interval 1 when P1 lies in an earlier tile; hopped together from P1T when it lies in this tile (an
              *    entry may then be shorter than four — the walk simply continues from its last link).  Entries go to
              *    device memory (args.chain, 16 B per position); later tiles find them there. */
-            uint4 *chainB = args.chain + (size_t)blockIdx.x * args.chainStride;
             uint32_t *P1T = nearTab; /* [kTile] */
             const uint32_t tag = (mix >> 3) & kTagMask;
             if (wave == 2u) { /* not wave 0 or 4: those share their SIMD with the parse wave */
@@ -1175,6 +1191,262 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     if (lane == 0) out[blk.seqCap - 3u - wave] = make_uint4((uint32_t)dI1, (uint32_t)dW1, (uint32_t)dI2, (uint32_t)dW2);
     if (lane == 0) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID */
 #endif
+    return 0u;
+}
+
+/* one launch, one work item per workgroup (the batch paths) */
+template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
+__global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
+{
+    const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
+    const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
+                                                                CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr);
+    if (threadIdx.x == (uint32_t)kMatchThreads) args.nseq[blockIdx.x] = count; /* lane 0 of the parse wave */
+}
+
+/* ======================================================================================================================
+ * The resident service: per-block requests without a launch.
+ *
+ * A caller that hands over ONE block and waits (libzstd's producer contract; reference: synchronous submit + poll per block,
+ * /root/reference/src/qatseqprod.c:1243-1272, many instances per device :905-928) pays, on the launch path, a copy, one or more
+ * kernel launches, a stream poll — and the walk of one workgroup over the whole block.  Here the block is cut into up to 32
+ * work items (runs of whole segments, profile.segLog), and the items go to workgroups that are ALREADY RESIDENT:
+ *
+ *   host thread     writes one 64-byte request into a ring in pinned host memory (8 self-certifying granules:
+ *                   tag << 56 | payload, so the reader needs no second look), then polls the request's count words in ITS
+ *                   OWN pinned memory;
+ *   dispatcher      one wave (qzstd_service_dispatcher) polls the ring over PCIe — one reader, not one per CU — and expands
+ *                   a request into work items in a DEVICE-memory queue (granules again, written through);
+ *   workers         qzstd_service_worker: one workgroup per CU, each holds a ticket (one returning atomic) and polls ITS
+ *                   OWN queue entry; an item = copy the item's slice of the block from pinned host memory into the
+ *                   request's device staging buffer (write-through + flag), wait for the slices before it (they are copied
+ *                   by the items before it, which were handed out earlier and wait for nothing: no deadlock), one agent-scope
+ *                   acquire, then qz_item() as on the launch path; results go straight to pinned host memory, the item's
+ *                   count is stored LAST with a system-scope release: the count is the completion flag.
+ *
+ * The kernels leave when the host asks (QZSTD_stopQatDevice, a free, a launch that needs the CUs' whole LDS) or after
+ * idleUs without work (the next request launches them again); every spin is bounded.
+ * ====================================================================================================================== */
+constexpr uint32_t kSvcQueue = 4096u;  /* entries of the device work queue */
+constexpr uint32_t kSvcRing = 256u;    /* entries of the host request ring */
+constexpr uint32_t kSvcMaxItems = 32u; /* work items per request */
+constexpr uint32_t kSvcSlots = 1024u;  /* request slots (one per caller in flight): slice flags */
+constexpr uint32_t kSvcRejected = 0xFFFFFFFEu; /* count word: the service does not serve this request (other level): launch path */
+
+struct SvcDev { /* device memory, zeroed before every launch of the service */
+    u64 items[kSvcQueue][8];
+    uint32_t head;      /* tickets handed out */
+    uint32_t done;      /* items finished */
+    uint32_t quit;      /* set by the dispatcher */
+    uint32_t spinFails; /* items that gave up waiting for a slice */
+    uint32_t started;   /* worker workgroups that have begun (diagnostics) */
+    uint32_t taken;     /* items a worker has picked up (diagnostics) */
+    uint32_t pad[2];
+    uint32_t sliceFlag[kSvcSlots][kSvcMaxItems]; /* epoch of the request whose slice k is in the slot's staging buffer */
+};
+
+struct SvcHost { /* pinned host memory */
+    u64 ring[kSvcRing][8];
+    uint32_t state;    /* 0 stopped, 1 running, 2 the dispatcher is deciding whether to stop */
+    uint32_t quitReq;  /* the host asks the service to leave */
+    u64 consumed;      /* requests taken from the ring, over all launches */
+    u64 itemsDone;     /* statistics, written when the dispatcher leaves */
+    uint32_t spinFails;
+    uint32_t pad;
+    u64 dbg[8];        /* diagnostics, refreshed by the dispatcher: polls, requests seen, items queued, workers started, items taken, items done */
+};
+
+typedef __attribute__((address_space(1))) u64 *gu64p;
+typedef __attribute__((address_space(1))) uint32_t *gu32p;
+#define QZ_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define QZ_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+
+__device__ __forceinline__ u64 svc_tag(u64 n, uint32_t entries) { return (n / entries) % 255ull + 1ull; }
+__device__ __forceinline__ u64 svc_payload(u64 g) { return g & 0x00FFFFFFFFFFFFFFull; }
+
+/* request granules (host -> dispatcher):
+ *   0 hSrc   1 dSrc   2 hSeqs   3 hCount   (pointers, 56 bits)
+ *   4 srcLen (18) | itemBytes (18) << 18 | nItems (6) << 36 | slot (10) << 42
+ *   5 seqCapPerItem (24)        6 epoch (24) | level (8) << 24        7 spare
+ *   (one field per word where a word is multiplied: hipcc 7.2 folded the mask of a packed seqCap away in the dispatcher's
+ *   64-bit multiply and the items' result regions landed 256 MiB apart)
+ * item granules (dispatcher -> worker):
+ *   0 hSrc   1 dSrc   2 the item's result region   3 the item's count word
+ *   4 srcLen (18: the block up to the item's end) | parseFrom (18) << 18 | item index (6) << 36 | slot (10) << 42
+ *   5 seqCap (24)               6 epoch (24)                          7 spare */
+
+template <bool HAS_LONG, bool REP, bool TURNS>
+__global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args, SvcDev *sv, uint32_t ctlOff, uint32_t spinLimit)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = rdfirst(tid >> 6);
+    /* 24 words at the end of the workgroup's LDS (qzstd_hip_lds_bytes counts them): the item's granules + got / ticket */
+    uint32_t *ctl = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(size_t)(kLdsBase + ctlOff);
+    if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->started, 1u, QZ_RLX_AGENT);
+    for (;;) {
+        if (wave == 0u) {
+            uint32_t t = 0u;
+            if (lane == 0u) t = __hip_atomic_fetch_add(&sv->head, 1u, QZ_RLX_AGENT);
+            t = rdfirst(t);
+            const u64 want = svc_tag(t, kSvcQueue);
+            const u64 *slot = sv->items[t & (kSvcQueue - 1u)];
+            u64 g = 0;
+            uint32_t got = 0u;
+            for (;;) { /* ends with the item or with the dispatcher's quit: the dispatcher is resident and bounded itself */
+                if (lane < 8u) g = __hip_atomic_load(slot + lane, QZ_RLX_AGENT);
+                else if (lane == 8u) g = (u64)__hip_atomic_load(&sv->quit, QZ_RLX_AGENT);
+                const bool mine = lane >= 8u || (g >> 56) == want;
+                if (__all(mine)) { got = 1u; break; }
+                if (rdlane((uint32_t)g, 8u) != 0u) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (lane < 8u) { ctl[2u * lane] = (uint32_t)g; ctl[2u * lane + 1u] = (uint32_t)(svc_payload(g) >> 32); }
+            if (lane == 8u) ctl[16] = got;
+            if (lane == 0u && got) (void)__hip_atomic_fetch_add(&sv->taken, 1u, QZ_RLX_AGENT);
+        }
+        __syncthreads();
+        if (rdfirst(ctl[16]) == 0u) return;
+        /* the item's words are the same in every lane: say so (v_readfirstlane), as the launch kernel's descriptor — a kernel
+         * argument load — is for the compiler: the loops and branches of qz_item() stay scalar, its parse state in SGPRs */
+        const u64 q0 = rdfirst(ctl[0]) | ((u64)rdfirst(ctl[1]) << 32), q1 = rdfirst(ctl[2]) | ((u64)rdfirst(ctl[3]) << 32),
+                  q2 = rdfirst(ctl[4]) | ((u64)rdfirst(ctl[5]) << 32), q3 = rdfirst(ctl[6]) | ((u64)rdfirst(ctl[7]) << 32),
+                  q4 = rdfirst(ctl[8]) | ((u64)rdfirst(ctl[9]) << 32), q5 = rdfirst(ctl[10]), q6 = rdfirst(ctl[12]);
+        const uint8_t *hSrc = (const uint8_t *)q0;
+        uint8_t *dSrc = (uint8_t *)q1;
+        uint4 *out = (uint4 *)q2;
+        uint32_t *countWord = (uint32_t *)q3;
+        qzstd_hip_block_t blk;
+        blk.srcOff = 0; blk.seqOff = 0; blk.reserved = 0;
+        blk.srcLen = (uint32_t)q4 & 0x3FFFFu;
+        blk.parseFrom = (uint32_t)(q4 >> 18) & 0x3FFFFu;
+        blk.seqCap = (uint32_t)q5 & 0xFFFFFFu;
+        const uint32_t k = (uint32_t)(q4 >> 36) & 63u, slotIdx = (uint32_t)(q4 >> 42) & (kSvcSlots - 1u);
+        const uint32_t epoch = (uint32_t)q6 & 0xFFFFFFu;
+        /* ---- the item's slice: pinned host memory -> the request's device staging buffer, written through ---- */
+        {
+            const uint32_t end = (blk.srcLen + 15u) & ~15u;
+            for (uint32_t o = blk.parseFrom + tid * 16u; o < end; o += (uint32_t)kThreads * 16u) {
+                const u64 a = __hip_atomic_load((const u64 *)(hSrc + o), QZ_RLX_SYSTEM);
+                const u64 b = __hip_atomic_load((const u64 *)(hSrc + o + 8u), QZ_RLX_SYSTEM);
+                __hip_atomic_store((u64 *)(dSrc + o), a, QZ_RLX_AGENT);
+                __hip_atomic_store((u64 *)(dSrc + o + 8u), b, QZ_RLX_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every storing wave drains before the flag */
+            __syncthreads();
+            if (wave == 0u) {
+                if (lane == 0u) __hip_atomic_store(&sv->sliceFlag[slotIdx][k], epoch, QZ_RLX_AGENT);
+                /* the slices before this one: copied by the items before it (handed out earlier, waiting for nothing) */
+                uint32_t spins = 0u, ok = 1u;
+                for (;;) {
+                    const bool there = lane >= k || __hip_atomic_load(&sv->sliceFlag[slotIdx][lane], QZ_RLX_AGENT) == epoch;
+                    if (__all(there)) break;
+                    if (++spins > spinLimit) { ok = 0u; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* ONE acquire after the match; plain loads from here */
+                if (lane == 0u) ctl[17] = ok;
+            }
+            __syncthreads();
+        }
+        uint32_t count = QZSTD_HIP_NSEQ_ERROR;
+        if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, false, TURNS>(args, blk, dSrc, out, nullptr);
+        else if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->spinFails, 1u, QZ_RLX_AGENT);
+        /* ---- completion: every wave's result stores are performed, then the count — the host's flag — with a system-scope release ---- */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == (uint32_t)kMatchThreads) { /* lane 0 of the parse wave: it holds the count */
+            __hip_atomic_store(countWord, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            (void)__hip_atomic_fetch_add(&sv->done, 1u, QZ_RLX_AGENT);
+        }
+    }
+}
+
+/* one wave: host ring -> device queue, and the service's life cycle */
+__global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcDev *sv, uint32_t level, uint32_t idleUs, uint32_t drainUs)
+{
+    const uint32_t lane = threadIdx.x;
+    u64 head = __hip_atomic_load(&hs->consumed, QZ_RLX_SYSTEM); /* where the previous launch stopped */
+    uint32_t tail = 0u;                                          /* items queued in this launch */
+    u64 lastWork = __builtin_amdgcn_s_memrealtime();             /* 100 MHz */
+    u64 polls = 0, seen = 0;
+    for (;;) {
+        u64 g = 0;
+        if ((++polls & 255u) == 0u && lane < 6u) { /* diagnostics for qzstd_hip_service_info */
+            const u64 v = lane == 0u ? polls : lane == 1u ? seen : lane == 2u ? (u64)tail : lane == 3u ? (u64)__hip_atomic_load(&sv->started, QZ_RLX_AGENT)
+                        : lane == 4u ? (u64)__hip_atomic_load(&sv->taken, QZ_RLX_AGENT) : (u64)__hip_atomic_load(&sv->done, QZ_RLX_AGENT);
+            __hip_atomic_store(&hs->dbg[lane], v, QZ_RLX_SYSTEM);
+        }
+        if (lane < 8u) g = __hip_atomic_load(&hs->ring[head & (kSvcRing - 1u)][lane], QZ_RLX_SYSTEM);
+        else if (lane == 8u) g = (u64)__hip_atomic_load(&hs->quitReq, QZ_RLX_SYSTEM);
+        const bool mine = lane >= 8u || (g >> 56) == svc_tag(head, kSvcRing);
+        const bool quitReq = rdlane((uint32_t)g, 8u) != 0u;
+        if (__all(mine) && !quitReq) {
+            const u64 r0 = svc_payload(__shfl(g, 0)), r1 = svc_payload(__shfl(g, 1)), r2 = svc_payload(__shfl(g, 2)),
+                      r3 = svc_payload(__shfl(g, 3)), r4 = svc_payload(__shfl(g, 4)), r5 = svc_payload(__shfl(g, 5)),
+                      r6 = svc_payload(__shfl(g, 6));
+            const uint32_t srcLen = (uint32_t)r4 & 0x3FFFFu, itemBytes = (uint32_t)(r4 >> 18) & 0x3FFFFu;
+            const uint32_t nItems = (uint32_t)(r4 >> 36) & 63u, slotIdx = (uint32_t)(r4 >> 42) & (kSvcSlots - 1u);
+            const uint32_t cap = (uint32_t)r5 & 0xFFFFFFu, epoch = (uint32_t)r6 & 0xFFFFFFu, lv = (uint32_t)(r6 >> 24) & 0xFFu;
+            const bool sane = nItems >= 1u && nItems <= kSvcMaxItems && itemBytes != 0u && srcLen != 0u && srcLen <= QZSTD_HIP_BLOCK_MAX &&
+                              (u64)(nItems - 1u) * itemBytes < srcLen && lv == level;
+            if (!sane) { /* another level (the workers serve one), or nonsense: handed back, the caller takes the launch path */
+                if (lane < umin(nItems, kSvcMaxItems)) __hip_atomic_store((uint32_t *)r3 + lane, kSvcRejected, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                /* room in the queue: items still running keep nothing in it (a worker copies its entry first), so the bound is
+                 * generous — wait while more than a queue's worth is unfinished */
+                uint32_t spins = 0u;
+                while (tail + nItems - __hip_atomic_load(&sv->done, QZ_RLX_AGENT) > kSvcQueue && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(8);
+                if (lane < nItems) {
+                    const u64 t = (u64)tail + lane, tg = svc_tag(t, kSvcQueue) << 56;
+                    u64 *e = sv->items[t & (kSvcQueue - 1u)];
+                    const uint32_t from = lane * itemBytes;
+                    const uint32_t upTo = umin(srcLen, from + itemBytes);
+                    __hip_atomic_store(e + 0, tg | r0, QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 1, tg | r1, QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 2, tg | (r2 + (u64)lane * cap * 16ull), QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 3, tg | (r3 + 4ull * lane), QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 4, tg | upTo | ((u64)from << 18) | ((u64)lane << 36) | ((u64)slotIdx << 42), QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 5, tg | cap, QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 6, tg | epoch, QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 7, tg, QZ_RLX_AGENT);
+                }
+                tail += nItems;
+            }
+            head++;
+            seen++;
+            if (lane == 0u) __hip_atomic_store(&hs->consumed, head, QZ_RLX_SYSTEM);
+            lastWork = __builtin_amdgcn_s_memrealtime();
+            continue;
+        }
+        const u64 now = __builtin_amdgcn_s_memrealtime();
+        const bool drained = __hip_atomic_load(&sv->done, QZ_RLX_AGENT) == tail;
+        if (quitReq || (drained && now - lastWork > (u64)idleUs * 100ull)) {
+            if (!quitReq) {
+                /* idle: say so, then look at the ring once more — a request written after this look finds `state` 2 or 0 and
+                 * its writer launches the service again (PCIe: the read does not pass the write) */
+                if (lane == 0u) __hip_atomic_store(&hs->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                u64 g2 = 0;
+                if (lane < 8u) g2 = __hip_atomic_load(&hs->ring[head & (kSvcRing - 1u)][lane], QZ_RLX_SYSTEM);
+                if (__all(lane >= 8u || (g2 >> 56) == svc_tag(head, kSvcRing))) {
+                    if (lane == 0u) __hip_atomic_store(&hs->state, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    lastWork = now;
+                    continue;
+                }
+            }
+            /* leave: let the items in flight finish (bounded), tell the workers, report */
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(&sv->done, QZ_RLX_AGENT) != tail && __builtin_amdgcn_s_memrealtime() - t0 < (u64)drainUs * 100ull)
+                __builtin_amdgcn_s_sleep(16);
+            if (lane == 0u) {
+                __hip_atomic_store(&sv->quit, 1u, QZ_RLX_AGENT);
+                __hip_atomic_store(&hs->itemsDone, hs->itemsDone + __hip_atomic_load(&sv->done, QZ_RLX_AGENT), QZ_RLX_SYSTEM);
+                __hip_atomic_store(&hs->spinFails, hs->spinFails + __hip_atomic_load(&sv->spinFails, QZ_RLX_AGENT), QZ_RLX_SYSTEM);
+                __hip_atomic_store(&hs->state, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
 }
 
 /* Does the LDS hand the lanes of ONE ds_max_rtn instruction that hit the same address their values in lane order?  Every
@@ -1230,6 +1502,70 @@ int fail_msg(const char *what)
         hipError_t e_ = (call);                    \
         if (e_ != hipSuccess) return fail(what, e_); \
     } while (0)
+
+/* ---- the resident service: host-side state (the kernels: qzstd_service_worker / qzstd_service_dispatcher above) ---- */
+struct Service {
+    std::mutex mu; /* set-up, launches, stops */
+    SvcHost *hs = nullptr;
+    SvcDev *dv = nullptr;
+    hipStream_t sWork = nullptr, sDisp = nullptr;
+    hipEvent_t ev = nullptr;
+    int level = 0;   /* the level (profile) the resident workers serve */
+    int workers = 0;
+    int broken = 0;  /* a request timed out or a launch failed: the service is not used again */
+    std::atomic<unsigned long long> reserve{0}; /* request numbers handed to submitters */
+    unsigned long launches = 0, requests = 0, refused = 0;
+};
+Service g_svc[64];
+std::atomic<int> g_svcFreeze{0}; /* > 0: memory is being freed (hipFree / hipHostFree wait for every stream of the device) */
+
+struct SvcConfig { int enabled, workers, idleUs, spinLimit; };
+const SvcConfig &svc_config()
+{
+    static const SvcConfig c = [] {
+        SvcConfig k;
+        const char *e = getenv("QZSTD_HIP_SERVICE"), *w = getenv("QZSTD_HIP_SERVICE_WORKERS"), *i = getenv("QZSTD_HIP_SERVICE_IDLE_US");
+        k.enabled = e ? atoi(e) : 1;
+        k.workers = w ? atoi(w) : 0; /* 0 = one per CU */
+        k.idleUs = i ? atoi(i) : 20000;
+        if (k.idleUs < 100) k.idleUs = 100;
+        k.spinLimit = 1 << 20; /* polls of a slice flag before an item gives up (seconds) */
+        return k;
+    }();
+    return c;
+}
+
+/* asks the resident kernels of one device to leave and waits (bounded) until they have; 0 = stopped (or never running) */
+int svc_stop_locked(Service &s, unsigned waitMs)
+{
+    if (!s.hs) return 0;
+    if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) != 0u) {
+        __atomic_store_n(&s.hs->quitReq, 1u, __ATOMIC_RELEASE);
+        struct timespec t0, t;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        while (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) != 0u) {
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            if ((t.tv_sec - t0.tv_sec) * 1000ll + (t.tv_nsec - t0.tv_nsec) / 1000000ll > (long long)waitMs) { s.broken = 1; return 1; }
+            sched_yield();
+        }
+    }
+    return 0;
+}
+
+/* before memory is freed: hipFree / hipHostFree wait for every stream, which a resident kernel never lets finish */
+struct SvcFreeze {
+    SvcFreeze()
+    {
+        g_svcFreeze.fetch_add(1);
+        for (int d = 0; d < 64; d++) {
+            Service &s = g_svc[d];
+            if (!s.hs) continue;
+            std::lock_guard<std::mutex> g(s.mu);
+            (void)svc_stop_locked(s, 2000);
+        }
+    }
+    ~SvcFreeze() { g_svcFreeze.fetch_sub(1); }
+};
 
 } // namespace
 
@@ -1324,6 +1660,7 @@ void *qzstd_hip_malloc(int device, size_t bytes)
 void qzstd_hip_free(int device, void *dptr)
 {
     if (!dptr) return;
+    SvcFreeze frozen; /* hipFree waits for every stream of the device: the resident service has to leave first */
     if (phys(device) >= 0 && hipSetDevice(phys(device)) == hipSuccess) (void)hipFree(dptr);
 }
 
@@ -1344,9 +1681,19 @@ void *qzstd_hip_host_device_ptr(void *hptr)
     return d;
 }
 
+void *qzstd_hip_host_alloc_coherent(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { fail("hipHostMalloc(coherent)", e); return nullptr; }
+    return p;
+}
+
 void qzstd_hip_host_free(void *hptr)
 {
-    if (hptr) (void)hipHostFree(hptr);
+    if (!hptr) return;
+    SvcFreeze frozen; /* hipHostFree waits for the device's streams too */
+    (void)hipHostFree(hptr);
 }
 
 void *qzstd_hip_stream_create(int device)
@@ -1507,6 +1854,214 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (!kernel) return fail_msg("qzstd_hip_find_sequences: unsupported profile (no kernel variant)");
     QZ_CHECK(hipLaunchKernel(kernel, grid, wg, kargs, lds, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
+    return 0;
+}
+
+} /* extern "C" */
+
+/* ---------------------------------------------------------------- the resident service (host side) ---------- */
+namespace {
+
+const void *svc_worker_variant(const qzstd_hip_profile_t &p)
+{
+    if (p.chainDepth || p.longSize) return nullptr; /* levels 3-4 fill a CU's LDS, the chain levels need per-item scratch: launch path */
+    if (p.repWin) return p.subTileLog ? reinterpret_cast<const void *>(qzstd_service_worker<false, true, true>)
+                                      : reinterpret_cast<const void *>(qzstd_service_worker<false, true, false>);
+    return p.subTileLog ? reinterpret_cast<const void *>(qzstd_service_worker<false, false, true>)
+                        : reinterpret_cast<const void *>(qzstd_service_worker<false, false, false>);
+}
+
+int svc_launch_locked(int device, Service &s, int level)
+{
+    const SvcConfig &cfg = svc_config();
+    LaunchArgs a;
+    memset(&a, 0, sizeof(a));
+    if (qzstd_hip_profile_for_level(level, QZSTD_HIP_BLOCK_MAX, &a.prof)) return fail_msg("service: bad level");
+    const void *worker = svc_worker_variant(a.prof);
+    const size_t lds = qzstd_hip_lds_bytes(level, QZSTD_HIP_BLOCK_MAX);
+    if (!worker || lds == 0 || 2u * lds > 163840u) return fail_msg("service: level not served");
+    QZ_SET_DEVICE(device);
+    if (!s.hs) {
+        hipDeviceProp_t prop;
+        QZ_CHECK(hipGetDeviceProperties(&prop, phys(device)), "hipGetDeviceProperties");
+        s.workers = cfg.workers > 0 ? cfg.workers : prop.multiProcessorCount;
+        if (s.workers > 1024) s.workers = 1024;
+        void *h = nullptr, *d = nullptr;
+        QZ_CHECK(hipHostMalloc(&h, sizeof(SvcHost), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(service ring)");
+        memset(h, 0, sizeof(SvcHost));
+        if (hipMalloc(&d, sizeof(SvcDev)) != hipSuccess || hipStreamCreateWithFlags(&s.sWork, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&s.sDisp, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (d) (void)hipFree(d);
+            (void)hipHostFree(h);
+            s.broken = 1;
+            return fail_msg("service: set-up failed");
+        }
+        s.hs = static_cast<SvcHost *>(h);
+        s.dv = static_cast<SvcDev *>(d);
+    }
+    /* per-function attribute, once per variant and device would do; cheap enough to repeat on the (rare) launches */
+    QZ_CHECK(hipFuncSetAttribute(worker, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(service worker)");
+    /* the queue is cleared, and the previous service's kernels (which have said good-bye) are off their streams, before the new
+     * ones go out — by waiting here, not by an event between the streams: a cross-stream dependency that resolves against
+     * "the last command of the other stream" would tie the dispatcher to the workers, which never finish */
+    QZ_CHECK(hipStreamSynchronize(s.sDisp), "hipStreamSynchronize(service dispatcher stream)");
+    QZ_CHECK(hipMemsetAsync(s.dv, 0, sizeof(SvcDev), s.sWork), "hipMemsetAsync(service queue)");
+    QZ_CHECK(hipStreamSynchronize(s.sWork), "hipStreamSynchronize(service worker stream)");
+    __atomic_store_n(&s.hs->quitReq, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&s.hs->state, 1u, __ATOMIC_RELEASE);
+    s.level = level;
+    SvcHost *hsDev = nullptr;
+    QZ_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&hsDev), s.hs, 0), "hipHostGetDevicePointer");
+    uint32_t ctlOff = (uint32_t)(lds - 96u - kLdsBase), spin = (uint32_t)cfg.spinLimit;
+    void *wargs[4] = { &a, &s.dv, &ctlOff, &spin };
+    uint32_t lv = (uint32_t)level & 0xFFu, idle = (uint32_t)cfg.idleUs, drain = 1000000u;
+    if (level & QZSTD_HIP_LEVEL_REPCODES) lv |= 0x80u;
+    void *dargs[5] = { &hsDev, &s.dv, &lv, &idle, &drain };
+    /* the dispatcher first: workers without one would never be told to leave */
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(qzstd_service_dispatcher), dim3(1), dim3(64), dargs, 0, s.sDisp);
+    if (e != hipSuccess) {
+        __atomic_store_n(&s.hs->state, 0u, __ATOMIC_RELEASE);
+        s.broken = 1;
+        return fail("launch of the service dispatcher", e);
+    }
+    e = hipLaunchKernel(worker, dim3((unsigned)s.workers), dim3(kThreads), wargs, lds, s.sWork);
+    if (e != hipSuccess) {
+        __atomic_store_n(&s.hs->quitReq, 1u, __ATOMIC_RELEASE); /* the dispatcher leaves by itself and says so */
+        s.broken = 1;
+        return fail("launch of the service workers", e);
+    }
+    s.launches++;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r)
+{
+    const SvcConfig &cfg = svc_config();
+    if (!cfg.enabled || g_svcFreeze.load() > 0 || device < 0 || device >= 64 || phys(device) < 0 || !r) return 1;
+    Service &s = g_svc[device];
+    if (s.broken) return 1;
+    {
+        qzstd_hip_profile_t p;
+        if (qzstd_hip_profile_for_level(level, QZSTD_HIP_BLOCK_MAX, &p) || !svc_worker_variant(p) ||
+            2u * qzstd_hip_lds_bytes(level, QZSTD_HIP_BLOCK_MAX) > 163840u)
+            return 1;
+    }
+    if (r->nItems < 1u || r->nItems > kSvcMaxItems || r->slot >= kSvcSlots || r->srcLen == 0u || r->srcLen > QZSTD_HIP_BLOCK_MAX ||
+        r->itemBytes == 0u || (size_t)(r->nItems - 1u) * r->itemBytes >= r->srcLen || (r->itemBytes & 15u) || !r->hSrc || !r->dSrc ||
+        !r->hSeqs || !r->hCount || r->seqCapPerItem < 4u || r->seqCapPerItem > 0xFFFFFFu)
+        return fail_msg("qzstd_hip_service_submit: bad request");
+    /* the service of this device: running for this level, or stopped (then it is launched for it) */
+    if (!s.hs || __atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) == 0u) {
+        std::lock_guard<std::mutex> g(s.mu);
+        if (s.broken || g_svcFreeze.load() > 0) return 1;
+        if (!s.hs || __atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) == 0u) {
+            if (svc_launch_locked(device, s, level) != 0) return 1;
+        }
+    }
+    if (s.level != level) { s.refused++; return 1; } /* the resident workers serve another level: launch path */
+    void *dvSrc = nullptr, *dvSeqs = nullptr, *dvCount = nullptr;
+    if (hipHostGetDevicePointer(&dvSrc, const_cast<void *>(r->hSrc), 0) != hipSuccess || hipHostGetDevicePointer(&dvSeqs, r->hSeqs, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&dvCount, r->hCount, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_msg("qzstd_hip_service_submit: the buffers are not pinned host memory");
+    }
+    const unsigned long long n = s.reserve.fetch_add(1);
+    {   /* room in the ring: the request kSvcRing before this one has been taken */
+        struct timespec t0, t;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        unsigned spins = 0;
+        while (n - __atomic_load_n(&s.hs->consumed, __ATOMIC_ACQUIRE) >= kSvcRing) {
+            if ((++spins & 1023u) == 0u) {
+                clock_gettime(CLOCK_MONOTONIC, &t);
+                if (t.tv_sec - t0.tv_sec >= 2) { s.broken = 1; return fail_msg("qzstd_hip_service_submit: the request ring stays full"); }
+                sched_yield();
+            }
+        }
+    }
+    const u64 tg = ((n / kSvcRing) % 255ull + 1ull) << 56;
+    const u64 lv = (u64)((unsigned)level & 0xFFu) | ((level & QZSTD_HIP_LEVEL_REPCODES) ? 0x80ull : 0ull);
+    volatile u64 *e = s.hs->ring[n & (kSvcRing - 1u)];
+    e[0] = tg | (u64)(uintptr_t)dvSrc;
+    e[1] = tg | (u64)(uintptr_t)r->dSrc;
+    e[2] = tg | (u64)(uintptr_t)dvSeqs;
+    e[3] = tg | (u64)(uintptr_t)dvCount;
+    e[4] = tg | (u64)r->srcLen | ((u64)r->itemBytes << 18) | ((u64)r->nItems << 36) | ((u64)r->slot << 42);
+    e[5] = tg | (u64)r->seqCapPerItem;
+    e[6] = tg | (u64)(r->epoch & 0xFFFFFFu) | (lv << 24);
+    e[7] = tg;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    /* is anybody there to take it?  2 = the dispatcher is deciding whether to leave: wait for its verdict (microseconds) */
+    uint32_t st;
+    unsigned spins = 0;
+    while ((st = __atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE)) == 2u && ++spins < (1u << 26)) {}
+    if (st != 1u) {
+        std::lock_guard<std::mutex> g(s.mu);
+        if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) == 0u) {
+            /* a stopped service takes the ring up where it left it; while memory is being freed it stays down and the
+             * caller's wait runs into its time-out — rather than that, the launch waits for the free to finish */
+            unsigned w = 0;
+            while (g_svcFreeze.load() > 0 && ++w < 2000u) { const struct timespec nap = { 0, 1000000 }; nanosleep(&nap, nullptr); }
+            if (s.broken || svc_launch_locked(device, s, level) != 0) return -1;
+        }
+    }
+    __atomic_fetch_add(&s.requests, 1ul, __ATOMIC_RELAXED);
+    return 0;
+}
+
+int qzstd_hip_service_stop(int device)
+{
+    if (device < 0 || device >= 64) return -1;
+    Service &s = g_svc[device];
+    std::lock_guard<std::mutex> g(s.mu);
+    if (!s.hs) return 0;
+    const int r = svc_stop_locked(s, 2000);
+    if (r == 0 && phys(device) >= 0 && hipSetDevice(phys(device)) == hipSuccess) {
+        /* the kernels have said good-bye; their streams follow within microseconds */
+        (void)hipStreamSynchronize(s.sWork);
+        (void)hipStreamSynchronize(s.sDisp);
+    }
+    return r;
+}
+
+void qzstd_hip_service_mark_broken(int device)
+{
+    if (device < 0 || device >= 64) return;
+    Service &s = g_svc[device];
+    s.broken = 1;
+    if (s.hs) __atomic_store_n(&s.hs->quitReq, 1u, __ATOMIC_RELEASE);
+}
+
+int qzstd_hip_service_info(int device, unsigned long out[8])
+{
+    if (device < 0 || device >= 64 || !out) return -1;
+    Service &s = g_svc[device];
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    out[0] = s.launches;
+    out[1] = s.requests;
+    out[2] = s.refused;
+    out[3] = (unsigned long)s.broken;
+    if (s.hs) {
+        out[4] = (unsigned long)__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE);
+        out[5] = (unsigned long)s.hs->itemsDone;
+        out[6] = (unsigned long)s.hs->spinFails;
+        out[7] = (unsigned long)s.workers;
+    }
+    return 0;
+}
+
+int qzstd_hip_service_debug(int device, unsigned long out[8])
+{
+    if (device < 0 || device >= 64 || !out) return -1;
+    Service &s = g_svc[device];
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (!s.hs) return 0;
+    for (int k = 0; k < 6; k++) out[k] = (unsigned long)__atomic_load_n(&s.hs->dbg[k], __ATOMIC_RELAXED);
+    out[6] = (unsigned long)__atomic_load_n(&s.hs->consumed, __ATOMIC_RELAXED);
     return 0;
 }
 

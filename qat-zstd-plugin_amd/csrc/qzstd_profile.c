@@ -9,7 +9,7 @@
  * LDS budget per workgroup (gfx950: 160 KiB = 163840 B per CU, target: TWO workgroups per CU):
  *     48 KiB ring of recent block bytes (+128 B wrap mirror) + 4*tableSize + near table 4<<tileLog
  *     + 2 tiles of per-position parse words + per-window emission records + 64 B control
- *     = 81 664 B with 6400 table entries at tileLog 9.
+ *     (+ 96 B of item words for the resident service) = 81 776 B with 6400 table entries at tileLog 9.
  */
 #include "qzstd_hip.h"
 
@@ -17,6 +17,7 @@
 
 #define QZ_LDS_MAX 163840u
 #define QZ_LDS_CTRL (64u + 16u) /* control words + the 16 bytes below the kernel's first LDS address (kLdsBase) */
+#define QZ_LDS_SVC 96u          /* the resident service's item words, at the end of the allocation (csrc/qzstd_kernels.hip) */
 
 
 int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t *out)
@@ -55,9 +56,11 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
         /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
          * level 2, which buys its better ratio with them */
         out->subTileLog = (chains || level == 2) ? 6u : 0u;
-        /* no match crosses a 32 KiB boundary (and the repeat-aware parse forgets its offsets there), so that a lone block
-         * can be parsed as four segments in parallel with the same result (qzstd_hip_block_t.parseFrom) */
-        out->segLog = 15u;
+        /* no match crosses a 4 KiB boundary (and the repeat-aware parse forgets its offsets there), so that a lone block
+         * can be parsed as up to 32 work items in parallel with the same result (qzstd_hip_block_t.parseFrom: an item
+         * parses any run of whole segments).  Costs 0.10-0.15 % of compressed size and takes the GPU time
+         * of a lone 128 KiB level-1 block from 566 us (one item) over 164 us (four) to 46 us (32 items) */
+        out->segLog = 12u;
     }
     return 0;
 }
@@ -90,6 +93,6 @@ size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
            + 2u * ((4u << p.tileLog) + 32u) /* per-position parse words (+ override spill), 2 tiles in flight */
            + 2u * ((1u << p.tileLog) >> 6) * 32u /* per-window emission records, x2 */
            + (p.chainDepth ? (4u << p.tileLog) : 0u) /* chain levels: slot | tag of the tile's positions, for the insert wave */
-           + QZ_LDS_CTRL;
+           + QZ_LDS_CTRL + QZ_LDS_SVC;
     return need <= QZ_LDS_MAX ? need : 0;
 }

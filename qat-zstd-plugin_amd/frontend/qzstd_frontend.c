@@ -57,6 +57,10 @@ static void qfAnnounce(QZSTD_Front *f, QF_Worker *w, size_t seg)
     /* the block grid of the announcement: the chunk when a chunk is one block; 128 KiB blocks inside bigger frames */
     if (grid > 131072) grid = 131072;
     if ((grid & 15) || len > QF_HINT_MAX) return; /* not announceable: the callbacks take the per-block path */
+    /* every chunk is its own frame whose blocks start at the chunk's start: the announcement's grid (anchored at the
+     * segment's start) only names those blocks if the chunks are whole grid cells — otherwise every callback would miss
+     * and the GPU would match-find everything twice (round-2 ADVICE) */
+    if (f->p.chunkSize > grid && f->p.chunkSize % grid != 0) return;
     (void)QZSTD_hintSource(w->state, f->src + off, len, grid, f->p.level);
 }
 
@@ -198,6 +202,19 @@ void QZSTD_frontStats(QZSTD_Front *f, unsigned long stats[2])
         if (f->w[t].state) QZSTD_hintStats(f->w[t].state, s);
         stats[0] += s[0];
         stats[1] += s[1];
+    }
+}
+
+void QZSTD_frontFailStats(QZSTD_Front *f, unsigned long stats[8])
+{
+    int t, k;
+    if (!stats) return;
+    for (k = 0; k < 8; k++) stats[k] = 0;
+    if (!f || !f->p.useProducer) return;
+    for (t = 0; t < f->p.nThreads; t++) {
+        unsigned long s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (f->w[t].state) QZSTD_failStats(f->w[t].state, s);
+        for (k = 0; k < 8; k++) stats[k] += s[k];
     }
 }
 

@@ -60,6 +60,12 @@
 #define QZ_DEFAULT_TIMEOUT_MS 2000 /* reference: 2 s of polling, src/qatseqprod.c:1099-1104 */
 
 static int qzLogLevel = DEBUGLEVEL; /* 0 silent, 1 errors, 2 events, 3 every sequence */
+
+/* Why a callback returned ZSTD_SEQUENCE_PRODUCER_ERROR (counted per state, QZSTD_failStats; the reference counts only
+ * the device-down case: failOffloadCnt, src/qatseqprod.c:122,:1141).  The failing site names the cause in a thread-local;
+ * a batch's leader leaves it in the request for the member that waits. */
+enum { QZ_CAUSE_NONE = 0, QZ_CAUSE_GUARD, QZ_CAUSE_DEVICE_DOWN, QZ_CAUSE_TIMEOUT, QZ_CAUSE_CAPACITY, QZ_CAUSE_RUNTIME, QZ_CAUSE_N };
+static __thread int qzCause = QZ_CAUSE_NONE;
 #define QZ_LOG(l, ...)                                       \
     do {                                                     \
         if ((l) <= qzLogLevel) {                             \
@@ -88,7 +94,18 @@ typedef struct {
     /* launch scratch (hash chains of levels >= 5), grow-only: one block / an announced batch */
     void *dWork; size_t dWorkCap;
     void *dBatchWork; size_t dBatchWorkCap;
+    /* buffers of the resident service's requests (qzstd_hip_service_submit), created on first use: the staged block, its
+     * device twin, QZ_SVC_ITEMS_MAX result regions and count words — the words are what the caller polls */
+    unsigned char *vSrc;   /* pinned */
+    unsigned char *vdSrc;  /* device */
+    ZSTD_Sequence *vSeqs;  /* pinned, QZ_SVC_ITEMS_MAX x QZ_SVC_ITEM_CAP */
+    unsigned int *vCount;  /* pinned, QZ_SVC_ITEMS_MAX */
+    unsigned int vEpoch, vItems; /* the last request: its epoch, its item count */
+    int vStuck;            /* that request timed out: the slot serves no request before all its count words have arrived */
 } QZSTD_Slot_T;
+#define QZ_SVC_ITEMS_MAX QZSTD_HIP_SVC_MAX_ITEMS
+#define QZ_SVC_ITEM_CAP ((size_t)1371) /* ZSTD_sequenceBound(4096): the smallest item is one 4 KiB segment; 32 of them hold any block's worst case */
+#define QZ_NOT_SERVED ((size_t)-2)     /* qzServiceBlock: the resident service does not take this request, use the launch path */
 
 /*
  * Cross-thread request coalescing (one per GPU).  The producer API hands over ONE block per call and waits, and a
@@ -104,12 +121,15 @@ typedef struct {
 #define QZ_BATCH_MAX 128
 #define QZ_BATCHES 4
 #define QZ_BATCH_PITCH ((size_t)16384) /* sequences per block in the batch's result area; denser blocks are redone alone */
-#define QZ_SEGS_MAX 4 /* a block of a level whose profile has segLog is submitted as up to four segments (lone-request latency) */
+#define QZ_SEGS_MAX 4 /* a batched block goes to the GPU as up to four work items, each a run of whole segments (profile.segLog) */
+#define QZ_ITEM_BYTES ((size_t)32768) /* ... of this size; the service path (below) cuts finer */
+#define QZ_SPLIT_ITEMS_MAX 256 /* batches are only cut into segment items while the launch stays within one workgroup per CU */
 typedef struct {
     const void *src;
     size_t srcSize, cap, rc;
     int level;
     int nSeg, dense;                /* segments submitted; the batch's result area was too small: redo alone */
+    int cause;                      /* QZ_CAUSE_* when rc is the error code (set by the batch's leader) */
     unsigned int segCnt[QZ_SEGS_MAX]; /* sequences per segment, each including its delimiter */
 } QZSTD_Req_T;
 
@@ -154,10 +174,13 @@ typedef struct {
     int timeoutMs;           /* QZSTD_HIP_TIMEOUT_MS */
     int split;               /* QZSTD_HIP_SPLIT: announced buffers are split across this many GPUs (default: all) */
     int splitBlocks;         /* QZSTD_HIP_SPLIT_BLOCKS (default 1): per-block requests of segmentable levels go as segments */
+    int service;             /* QZSTD_HIP_SERVICE (default 1): per-block requests go to the resident service where it serves the level */
+    int svcItemBytes;        /* QZSTD_HIP_SERVICE_ITEM (default 4096): bytes per work item of a service request (whole segments) */
+    int svcSpinUs;           /* QZSTD_HIP_SERVICE_SPIN_US (default 400): busy polling of the count words before napping */
     pthread_mutex_t mutex;
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, PTHREAD_MUTEX_INITIALIZER };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, PTHREAD_MUTEX_INITIALIZER };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
  * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
@@ -190,7 +213,21 @@ typedef struct {
     qzstd_hip_block_t *hDesc; /* pinned */
     void *dvSeqs, *dvCount, *dvDesc; /* device-side addresses of the three: the kernels use them directly */
     size_t hSrcCap, hSeqsCap, hCountCap, hDescCap; /* bytes */
+    int nStuck, stuckSlot[QZ_HINT_PARTS]; /* slots whose wait timed out: a kernel may still read and write the buffers above */
 } QZSTD_Hint_T;
+
+/* Pinned buffers of an announcement that a timed-out kernel may still read (hSrc, hDesc) and write (hSeqs, hCount): the
+ * announcement gets fresh ones, these are parked here — never reused, scrubbed or freed — until the streams of the slots
+ * involved have drained (round-2 ADVICE: a late kernel must not write into the next announcement's results). */
+typedef struct QZSTD_Orphan_S {
+    struct QZSTD_Orphan_S *next;
+    void *buf[4];
+    size_t srcCap;
+    int nSlots, slot[QZ_HINT_PARTS];
+} QZSTD_Orphan_T;
+static QZSTD_Orphan_T *qzOrphans;
+static unsigned long qzOrphanCount; /* test hook / log: announcements whose buffers were parked */
+static pthread_mutex_t qzOrphanMu = PTHREAD_MUTEX_INITIALIZER;
 
 /* Per-CCtx state (opaque to the caller). */
 typedef struct {
@@ -206,7 +243,9 @@ typedef struct {
     size_t pipeChunk;
     uintptr_t mapLo, mapHi;                     /* the caller's mapping the last guess was confined to */
     unsigned long autoLaunched, autoServed;
-    unsigned long servedFromBatch, servedSync;
+    unsigned long servedFromBatch, servedSync, servedService;
+    unsigned long fail[QZ_CAUSE_N]; /* callbacks that returned the error code, by cause ([0] = all of them) */
+    unsigned long redoneAlone;      /* blocks too dense for a batch's result area, redone on a slot of their own (not errors) */
     unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs; /* event log only */
 } QZSTD_Session_T;
 
@@ -214,6 +253,8 @@ typedef struct {
 #define QZ_AUTO_DEPTH_MAX 32u
 #define QZ_HINT_STALE_MISSES 16u /* an announcement that was used and then missed this often is dropped */
 static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block);
+static void qzReapOrphans(int force);
+static size_t qzFailed(QZSTD_Session_T *s, int cause);
 static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t blockSize, int compressionLevel);
 static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need);
 
@@ -244,8 +285,8 @@ static unsigned long qzNowNs(void)
 static int qzWait(int dev, void *stream)
 {
     const int r = qzstd_hip_stream_wait(dev, stream, (unsigned)gProc.timeoutMs);
-    if (r == 1) QZ_LOG(1, "device %d: request timed out after %d ms\n", dev, gProc.timeoutMs);
-    if (r < 0) QZ_LOG(1, "device %d: %s\n", dev, qzstd_hip_last_error());
+    if (r == 1) { qzCause = QZ_CAUSE_TIMEOUT; QZ_LOG(1, "device %d: request timed out after %d ms\n", dev, gProc.timeoutMs); }
+    if (r < 0) { qzCause = QZ_CAUSE_RUNTIME; QZ_LOG(1, "device %d: %s\n", dev, qzstd_hip_last_error()); }
     return r;
 }
 
@@ -277,6 +318,11 @@ static void qzFreeSlot(QZSTD_Slot_T *s)
     qzstd_hip_free(s->device, s->dBatchSrc);
     qzstd_hip_free(s->device, s->dWork);
     qzstd_hip_free(s->device, s->dBatchWork);
+    if (s->vSrc) memset(s->vSrc, 0, QZSTD_HIP_BLOCK_MAX + 64); /* staged caller data: scrubbed before the pages go back */
+    qzstd_hip_host_free(s->vSrc);
+    qzstd_hip_host_free(s->vSeqs);
+    qzstd_hip_host_free(s->vCount);
+    qzstd_hip_free(s->device, s->vdSrc);
     if (s->stream) qzstd_hip_stream_destroy(s->device, s->stream);
     {
         const int dev = s->device;
@@ -431,8 +477,11 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         int sg;
         r->nSeg = 1;
         r->dense = 0;
-        if (gProc.splitBlocks && qzstd_hip_profile_for_level(r->level, r->srcSize, &pf) == 0 && pf.segLog) {
+        /* a full batch fills the GPU as it is: segment items then only repeat the insert work of the block before them
+         * (and, at the chain levels, multiply the scratch); they pay for batches that leave CUs idle */
+        if (gProc.splitBlocks && n * QZ_SEGS_MAX <= QZ_SPLIT_ITEMS_MAX && qzstd_hip_profile_for_level(r->level, r->srcSize, &pf) == 0 && pf.segLog) {
             seg = (size_t)1 << pf.segLog;
+            if (seg < QZ_ITEM_BYTES) seg = QZ_ITEM_BYTES; /* a multiple of the segment size: both are powers of two */
             if (r->srcSize > seg && (r->srcSize + seg - 1) / seg <= QZ_SEGS_MAX) r->nSeg = (int)((r->srcSize + seg - 1) / seg);
         }
         first[j] = k;
@@ -469,7 +518,11 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         }
         k1 = g1 < n ? first[g1] : k;
         work = qzstd_hip_workspace_bytes(level, (unsigned int)(k1 - k0), maxLen);
-        if (work > bt->dWorkCap && launches) failed = qzWait(dev, bt->stream) != 0; /* the scratch is about to be replaced */
+        if (work > bt->dWorkCap && launches) { /* the scratch is about to be replaced: what runs on it has to finish first */
+            const int w = qzWait(dev, bt->stream);
+            if (w == 1) bt->stuck = 1;
+            failed = w != 0;
+        }
         if (work && !failed) bt->dWork = qzGrowDev(dev, bt->dWork, &bt->dWorkCap, work);
         failed = failed || (work && !bt->dWork) ||
                  qzstd_hip_find_sequences(dev, bt->stream, level, bt->dSrc, (const qzstd_hip_block_t *)bt->dvDesc + k0,
@@ -478,10 +531,16 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         launches++;
         g0 = g1;
     }
-    if (!failed) {
+    /* whatever was queued — the copy, the launches of earlier level groups — has to be off the stream before the batch's
+     * buffers are handed back, also when a later step failed (round-2 ADVICE) */
+    if (!bt->stuck) {
         const int w = qzWait(dev, bt->stream);
         if (w == 1) bt->stuck = 1; /* the kernel may still write into this batch's buffers: quarantined */
-        failed = w != 0;
+        failed = failed || w != 0;
+    }
+    {
+        const int cause = bt->stuck ? QZ_CAUSE_TIMEOUT : QZ_CAUSE_RUNTIME;
+        for (j = 0; j < n; j++) bt->req[j].cause = cause;
     }
     for (j = 0; j < n; j++) {
         QZSTD_Req_T *r = &bt->req[order[j]];
@@ -496,6 +555,7 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         /* capacity rule, reference :1318-1322; a result area of the batch that was too small (not the caller's
          * capacity) means: redo this block alone */
         if (bad) r->dense = !failed && (r->nSeg > 1 || r->cap > QZ_BATCH_PITCH);
+        if (!failed) r->cause = QZ_CAUSE_CAPACITY;
         r->rc = (bad || total >= r->cap - 1) ? ZSTD_SEQUENCE_PRODUCER_ERROR : total;
     }
     if (failed) QZ_LOG(1, "device request failed: %s\n", qzstd_hip_last_error());
@@ -535,6 +595,7 @@ static size_t qzCoalescedBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSe
             if (bt) break;
             if (!usable) { /* every batch is stuck or cannot be set up: fail the block (libzstd's fallback takes over) */
                 pthread_mutex_unlock(&c->mu);
+                qzCause = QZ_CAUSE_RUNTIME;
                 return ZSTD_SEQUENCE_PRODUCER_ERROR;
             }
         }
@@ -571,6 +632,7 @@ static size_t qzCoalescedBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSe
     pthread_mutex_unlock(&c->mu);
 
     rc = bt->req[i].rc;
+    if (rc == ZSTD_SEQUENCE_PRODUCER_ERROR) qzCause = bt->req[i].cause;
     if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) {
         const QZSTD_Req_T *r = &bt->req[i];
         if (r->nSeg == 1) {
@@ -606,7 +668,10 @@ static size_t qzCoalescedBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSe
     pthread_mutex_unlock(&c->mu);
     /* a block with more sequences than the batch's result pitch holds (incompressible-looking data with many
      * short matches) is redone alone with the caller's full capacity */
-    if (dense) rc = qzSlotBlock(s, dev, outSeqs, outSeqsCapacity, src, srcSize, level);
+    if (dense) {
+        s->redoneAlone++;
+        rc = qzSlotBlock(s, dev, outSeqs, outSeqsCapacity, src, srcSize, level);
+    }
     return rc;
 }
 
@@ -669,6 +734,9 @@ int QZSTD_startQatDevice(void)
         gProc.levelFlags = (rep && atoi(rep) > 0) ? QZSTD_HIP_LEVEL_REPCODES : 0;
         gProc.timeoutMs = qzEnvInt("QZSTD_HIP_TIMEOUT_MS", QZ_DEFAULT_TIMEOUT_MS, 1, 600000);
         gProc.splitBlocks = qzEnvInt("QZSTD_HIP_SPLIT_BLOCKS", 1, 0, 1);
+        gProc.service = qzEnvInt("QZSTD_HIP_SERVICE", 1, 0, 1);
+        gProc.svcItemBytes = qzEnvInt("QZSTD_HIP_SERVICE_ITEM", 4096, 4096, (int)QZSTD_HIP_BLOCK_MAX) & ~4095;
+        gProc.svcSpinUs = qzEnvInt("QZSTD_HIP_SERVICE_SPIN_US", 400, 0, 1000000);
         {
             /* The transparent look-ahead READS memory behind the block a callback names, so it is strictly opt-in:
              * QZSTD_HIP_LOOKAHEAD = 0 / unset: off; 1: on; 2: on and always through a pipe.  It needs a fault-safe read:
@@ -700,8 +768,10 @@ void QZSTD_stopQatDevice(void)
 {
     int i;
     pthread_mutex_lock(&gProc.mutex);
+    for (i = 0; i < gProc.numDevices; i++) (void)qzstd_hip_service_stop(i); /* the resident kernels leave before anything is freed */
     if (gProc.slots) {
-        for (i = 0; i < gProc.numSlots; i++) qzFreeSlot(&gProc.slots[i]);
+        for (i = 0; i < gProc.numSlots; i++) qzFreeSlot(&gProc.slots[i]); /* waits (bounded) for each stream */
+        qzReapOrphans(1);
         free(gProc.slots);
     }
     if (gProc.coal) {
@@ -725,14 +795,62 @@ void *QZSTD_createSeqProdState(void)
     return s;
 }
 
+/* frees (force) or tries to free the parked buffers whose streams have drained; scrubs the staged caller data first */
+static void qzReapOrphans(int force)
+{
+    QZSTD_Orphan_T **pp;
+    pthread_mutex_lock(&qzOrphanMu);
+    for (pp = &qzOrphans; *pp; ) {
+        QZSTD_Orphan_T *o = *pp;
+        int k, busy = 0;
+        for (k = 0; k < o->nSlots && !force; k++) {
+            const int i = o->slot[k];
+            if (gProc.slots && i >= 0 && i < gProc.numSlots && gProc.slots[i].stream &&
+                qzstd_hip_stream_query(gProc.slots[i].device, gProc.slots[i].stream) != 0)
+                busy = 1;
+        }
+        if (busy) { pp = &o->next; continue; }
+        if (o->buf[0]) memset(o->buf[0], 0, o->srcCap);
+        for (k = 0; k < 4; k++) qzstd_hip_host_free(o->buf[k]);
+        *pp = o->next;
+        free(o);
+    }
+    pthread_mutex_unlock(&qzOrphanMu);
+}
+
+/* the announcement's buffers may still be in use by a kernel that timed out: park them, the announcement starts afresh */
+static void qzOrphanHint(QZSTD_Hint_T *h)
+{
+    QZSTD_Orphan_T *o = (QZSTD_Orphan_T *)calloc(1, sizeof(*o));
+    int k;
+    if (o) { /* (no memory for the list node: the buffers are leaked rather than freed under a running kernel) */
+        o->buf[0] = h->hSrc; o->buf[1] = h->hSeqs; o->buf[2] = h->hCount; o->buf[3] = h->hDesc;
+        o->srcCap = h->hSrcCap;
+        o->nSlots = h->nStuck;
+        for (k = 0; k < h->nStuck; k++) o->slot[k] = h->stuckSlot[k];
+        pthread_mutex_lock(&qzOrphanMu);
+        o->next = qzOrphans;
+        qzOrphans = o;
+        qzOrphanCount++;
+        pthread_mutex_unlock(&qzOrphanMu);
+    }
+    h->hSrc = NULL; h->hSeqs = NULL; h->hCount = NULL; h->hDesc = NULL;
+    h->dvSeqs = h->dvCount = h->dvDesc = NULL;
+    h->hSrcCap = h->hSeqsCap = h->hCountCap = h->hDescCap = 0;
+    h->nStuck = 0;
+    QZ_LOG(1, "an announcement's buffers are parked until a timed-out stream drains\n");
+}
+unsigned long qzstd_test_orphans(void) { return qzOrphanCount; } /* test hook (tests/test_host_mock.py) */
+
 /* wait for one part of an announcement and give its slot back; the part becomes ready (2) or failed (3) */
-static void qzPartFinish(QZSTD_Part_T *pt)
+static void qzPartFinish(QZSTD_Hint_T *h, QZSTD_Part_T *pt)
 {
     if (pt->st != 1) return;
     if (gProc.slots && pt->slot >= 0 && pt->slot < gProc.numSlots) {
         QZSTD_Slot_T *sl = &gProc.slots[pt->slot];
         const int w = qzWait(sl->device, sl->stream);
         if (w == 1) sl->stuck = 1; /* the slot is given back, but nobody uses it before its stream has drained */
+        if (w != 0 && h->nStuck < QZ_HINT_PARTS) h->stuckSlot[h->nStuck++] = pt->slot; /* ... and the kernel may still use h's buffers */
         qzReleaseSlot(pt->slot);
         pt->st = w == 0 ? 2 : 3;
         if (w != 0) QZ_LOG(1, "look-ahead batch failed: %s\n", qzstd_hip_last_error());
@@ -745,7 +863,8 @@ static void qzPartFinish(QZSTD_Part_T *pt)
 static void qzHintDrop(QZSTD_Hint_T *h)
 {
     int k;
-    for (k = 0; k < h->nParts; k++) qzPartFinish(&h->part[k]);
+    for (k = 0; k < h->nParts; k++) qzPartFinish(h, &h->part[k]);
+    if (h->nStuck) qzOrphanHint(h);
     h->nParts = 0;
     h->st = 0;
     h->touched = 0;
@@ -795,6 +914,16 @@ static int qzDeviceUsable(QZSTD_Session_T *s)
     return 0;
 }
 
+/* a callback is about to return the error code: count it by cause (QZSTD_failStats) */
+static size_t qzFailed(QZSTD_Session_T *s, int cause)
+{
+    if (s) {
+        s->fail[0]++;
+        s->fail[cause > 0 && cause < QZ_CAUSE_N ? cause : QZ_CAUSE_RUNTIME]++;
+    }
+    return ZSTD_SEQUENCE_PRODUCER_ERROR;
+}
+
 /* one block, synchronously, on a slot */
 static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
                          size_t srcSize, int level)
@@ -829,6 +958,7 @@ static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeq
     count = *sl->hCount;
     if (count == QZSTD_HIP_NSEQ_ERROR || count == 0 || count >= outSeqsCapacity - 1) {
         QZ_LOG(1, "sequence count %zu does not fit capacity %zu\n", count, outSeqsCapacity);
+        qzCause = QZ_CAUSE_CAPACITY;
         return ZSTD_SEQUENCE_PRODUCER_ERROR; /* reference :1318-1322 */
     }
     if (count > first) {
@@ -844,6 +974,152 @@ static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeq
 fail:
     QZ_LOG(1, "device request failed: %s\n", qzstd_hip_last_error());
     return ZSTD_SEQUENCE_PRODUCER_ERROR;
+}
+
+/* buffers of a slot's service requests, first use only; 0 on success (a failure frees what was created) */
+static int qzSetupSlotService(QZSTD_Slot_T *sl)
+{
+    if (sl->vSrc) return 0;
+    sl->vSrc = (unsigned char *)qzstd_hip_host_alloc_coherent(QZSTD_HIP_BLOCK_MAX + 64);
+    sl->vSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc_coherent(QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP * sizeof(ZSTD_Sequence));
+    sl->vCount = (unsigned int *)qzstd_hip_host_alloc_coherent(QZ_SVC_ITEMS_MAX * sizeof(unsigned int));
+    sl->vdSrc = (unsigned char *)qzstd_hip_malloc(sl->device, QZSTD_HIP_BLOCK_MAX + 64);
+    if (!sl->vSrc || !sl->vSeqs || !sl->vCount || !sl->vdSrc) {
+        QZ_LOG(1, "service buffers of a slot on device %d: %s\n", sl->device, qzstd_hip_last_error());
+        qzstd_hip_host_free(sl->vSrc); qzstd_hip_host_free(sl->vSeqs); qzstd_hip_host_free(sl->vCount);
+        qzstd_hip_free(sl->device, sl->vdSrc);
+        sl->vSrc = NULL; sl->vSeqs = NULL; sl->vCount = NULL; sl->vdSrc = NULL;
+        return -1;
+    }
+    memset(sl->vCount, 0xFF, QZ_SVC_ITEMS_MAX * sizeof(unsigned int)); /* "arrived": nothing is outstanding */
+    sl->vItems = 0;
+    return 0;
+}
+
+/*
+ * One block through the resident service (qzstd_hip_service_submit): no launch, no stream — the block is staged in the slot's
+ * pinned buffer, one 64-byte request goes into the service's ring, workgroups that are already resident parse the block as
+ * up to 32 work items (runs of whole segments) and write sequences and, last, the counts into this slot's pinned memory;
+ * the caller polls those count words and joins the items' lists (the same join as the batch path's segments).
+ * Reference shape: synchronous submit + poll of one request on one DC instance, src/qatseqprod.c:1243-1272.
+ * Returns the count, the error code, or QZ_NOT_SERVED (no slot free right now, the level is not served, the service is
+ * down or busy with another level): the caller then takes the launch path.
+ */
+static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
+                             size_t srcSize, int level)
+{
+    QZSTD_Slot_T *sl;
+    qzstd_hip_svc_req_t rq;
+    size_t itemBytes, nItems, k, out = 0, carry = 0, total = 1;
+    unsigned long t0, spinNs, limitNs;
+    int i, rc, rejected = 0, bad = 0;
+
+    if (!gProc.service || srcSize == 0) return QZ_NOT_SERVED;
+    itemBytes = (size_t)gProc.svcItemBytes;
+    while ((srcSize + itemBytes - 1) / itemBytes > QZ_SVC_ITEMS_MAX) itemBytes *= 2;
+    nItems = (srcSize + itemBytes - 1) / itemBytes;
+    i = qzTryGrabSlot(s->slotHint, dev);
+    if (i < 0) return QZ_NOT_SERVED;
+    sl = &gProc.slots[i];
+    if (sl->vStuck) { /* a request of this slot timed out: usable again once every count word of it has arrived */
+        for (k = 0; k < sl->vItems; k++)
+            if (__atomic_load_n(&sl->vCount[k], __ATOMIC_ACQUIRE) == 0u) { qzReleaseSlot(i); return QZ_NOT_SERVED; }
+        sl->vStuck = 0;
+    }
+    if (qzSetupSlotService(sl) != 0) { qzReleaseSlot(i); return QZ_NOT_SERVED; }
+
+    memcpy(sl->vSrc, src, srcSize); /* staging copy, reference :1223 */
+    memset(sl->vSrc + srcSize, 0, ((srcSize + 15) & ~(size_t)15) - srcSize);
+    for (k = 0; k < nItems; k++) sl->vCount[k] = 0u;
+    sl->vItems = (unsigned int)nItems;
+    sl->vEpoch = (sl->vEpoch + 1u) & 0xFFFFFFu;
+    if (sl->vEpoch == 0u) sl->vEpoch = 1u;
+    rq.hSrc = sl->vSrc; rq.dSrc = sl->vdSrc; rq.hSeqs = sl->vSeqs; rq.hCount = sl->vCount;
+    rq.srcLen = (uint32_t)srcSize; rq.itemBytes = (uint32_t)itemBytes; rq.nItems = (uint32_t)nItems;
+    rq.seqCapPerItem = (uint32_t)(QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP / nItems); /* the slot's whole result area, shared out */
+    rq.slot = (uint32_t)i; rq.epoch = sl->vEpoch;
+    rc = qzstd_hip_service_submit(sl->device, level, &rq);
+    if (rc != 0) {
+        memset(sl->vCount, 0xFF, nItems * sizeof(unsigned int)); /* nothing outstanding */
+        qzReleaseSlot(i);
+        if (rc > 0) return QZ_NOT_SERVED;
+        QZ_LOG(1, "service request not queued: %s\n", qzstd_hip_last_error());
+        return QZ_NOT_SERVED; /* the launch path may still work */
+    }
+    /* poll the count words, last item first (the one with the longest history in front of it): busy for svcSpinUs, then naps */
+    t0 = qzNowNs();
+    spinNs = (unsigned long)gProc.svcSpinUs * 1000ul;
+    limitNs = (unsigned long)gProc.timeoutMs * 1000000ul;
+    for (k = nItems; k-- > 0; ) {
+        unsigned polls = 0;
+        while (__atomic_load_n(&sl->vCount[k], __ATOMIC_ACQUIRE) == 0u) {
+            __builtin_ia32_pause();
+            if ((++polls & 63u) == 0u) {
+                const unsigned long dt = qzNowNs() - t0;
+                if (dt > limitNs) { bad = 1; break; }
+                if (dt > spinNs) { const struct timespec nap = { 0, dt < 20000000ul ? 5000 : 200000 }; nanosleep(&nap, NULL); }
+            }
+        }
+        if (bad) break;
+    }
+    if (bad) { /* reference: the 2 s poll limit, :1261-1285 */
+        {
+            unsigned long in[8] = { 0 }, dg[8] = { 0 };
+            (void)qzstd_hip_service_info(sl->device, in);
+            (void)qzstd_hip_service_debug(sl->device, dg);
+            QZ_LOG(1, "device %d: service request timed out after %d ms (service: %lu launch(es), %lu request(s), state %lu; dispatcher: %lu poll(s), "
+                      "%lu request(s) taken, %lu item(s) queued; workers: %lu started, %lu item(s) picked up, %lu finished, %lu gave up on a slice)\n",
+                   sl->device, gProc.timeoutMs, in[0], in[1], in[4], dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], in[6]);
+        }
+        sl->vStuck = 1;
+        qzstd_hip_service_mark_broken(sl->device);
+        qzReleaseSlot(i);
+        qzCause = QZ_CAUSE_TIMEOUT;
+        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+    }
+    for (k = 0; k < nItems && !bad; k++) {
+        const unsigned int cnt = sl->vCount[k];
+        if (cnt == QZSTD_HIP_NSEQ_REJECTED) rejected = 1;
+        else if (cnt == QZSTD_HIP_NSEQ_ERROR || cnt > rq.seqCapPerItem) bad = 1; /* an item's region was too small: capacity rule */
+        else total += cnt - 1u;
+    }
+    if (rejected) { qzReleaseSlot(i); return QZ_NOT_SERVED; }
+    if (bad || total >= outSeqsCapacity - 1) { /* reference :1318-1322 */
+        qzReleaseSlot(i);
+        qzCause = QZ_CAUSE_CAPACITY;
+        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+    }
+    /* join the items' lists: the trailing literals of one flow into the first sequence of the next */
+    for (k = 0; k < nItems; k++) {
+        const ZSTD_Sequence *q = sl->vSeqs + k * rq.seqCapPerItem;
+        const size_t count = sl->vCount[k];
+        if (count > 1) {
+            memcpy(outSeqs + out, q, (count - 1) * sizeof(ZSTD_Sequence));
+            outSeqs[out].litLength += (unsigned int)carry;
+            out += count - 1;
+            carry = 0;
+        }
+        carry += q[count - 1].litLength;
+    }
+    outSeqs[out].offset = 0;
+    outSeqs[out].litLength = (unsigned int)carry;
+    outSeqs[out].matchLength = 0;
+    outSeqs[out].rep = 0;
+    out++;
+    qzReleaseSlot(i);
+    {   /* what arrived has to add up to the block (a torn or stale result must never reach libzstd, which does not validate
+         * sequences by default): one pass of additions */
+        size_t sum = 0;
+        for (k = 0; k < out; k++) sum += (size_t)outSeqs[k].litLength + outSeqs[k].matchLength;
+        if (sum != srcSize) {
+            QZ_LOG(1, "service result does not add up: %zu of %zu bytes\n", sum, srcSize);
+            qzstd_hip_service_mark_broken(sl->device);
+            qzCause = QZ_CAUSE_RUNTIME;
+            return ZSTD_SEQUENCE_PRODUCER_ERROR;
+        }
+    }
+    s->servedService++;
+    return out;
 }
 
 /* one block on a slot of its own (QZSTD_HIP_COALESCE=0, and blocks too dense for a batch) */
@@ -883,14 +1159,15 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     /* guards, reference :1123-1137 */
     if (windowSize < (srcSize < 32 * 1024 ? srcSize : 32 * 1024) || dictSize > 0 || dict) {
         QZ_LOG(2, "window %zu too small for block %zu, or dictionary given (%zu)\n", windowSize, srcSize, dictSize);
-        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+        return qzFailed(s, QZ_CAUSE_GUARD);
     }
     if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) {
         QZ_LOG(1, "only levels 1-12 can be offloaded, got %d\n", compressionLevel);
-        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+        return qzFailed(s, QZ_CAUSE_GUARD);
     }
-    if (!s || !outSeqs || !src || srcSize > QZSTD_HIP_BLOCK_MAX || outSeqsCapacity < 3) return ZSTD_SEQUENCE_PRODUCER_ERROR;
-    if (!qzDeviceUsable(s)) return ZSTD_SEQUENCE_PRODUCER_ERROR;
+    if (!s || !outSeqs || !src || srcSize > QZSTD_HIP_BLOCK_MAX || outSeqsCapacity < 3) return qzFailed(s, QZ_CAUSE_GUARD);
+    if (!qzDeviceUsable(s)) return qzFailed(s, QZ_CAUSE_DEVICE_DOWN);
+    qzCause = QZ_CAUSE_RUNTIME; /* until a failing site below says otherwise */
 
     /* look-ahead batch hit?  (src, srcSize) must start on an announced (k < 2) or guessed (k >= 2) block grid and
      * cover one or more whole blocks of it: libzstd 1.5.7 cuts multi-block frames into blocks of 32..128 KiB at 32 KiB
@@ -948,7 +1225,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 if (pt->b1 <= b || pt->b0 >= e) continue;
                 if (pt->st == 1) {
                     const unsigned long w0 = qzNowNs();
-                    qzPartFinish(pt);
+                    qzPartFinish(h, pt);
                     s->hintWaitNs += qzNowNs() - w0;
                 }
                 if (pt->st != 2) ok = 0;
@@ -1035,7 +1312,10 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
         static volatile unsigned int nextDev = 0;
         if (s->slotHint < 0) s->slotHint = (int)(__sync_fetch_and_add(&nextDev, 1u) & 0x3FFFFFFFu);
     }
-    if (gProc.coalesce) {
+    rc = qzServiceBlock(s, s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize, compressionLevel | gProc.levelFlags);
+    if (rc != QZ_NOT_SERVED) {
+        QZ_LOG(2, "block %zu B level %d -> %zu sequences (service, device %d)\n", srcSize, compressionLevel, rc, s->slotHint % gProc.numDevices);
+    } else if (gProc.coalesce) {
         rc = qzCoalescedBlock(s, s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize,
                               compressionLevel | gProc.levelFlags);
         QZ_LOG(2, "block %zu B level %d -> %zu sequences (coalesced, device %d)\n", srcSize, compressionLevel, rc,
@@ -1044,6 +1324,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
         rc = qzSlotBlock(s, -1, outSeqs, outSeqsCapacity, src, srcSize, compressionLevel | gProc.levelFlags);
     }
     if (rc != ZSTD_SEQUENCE_PRODUCER_ERROR) s->servedSync++;
+    else (void)qzFailed(s, qzCause);
     return rc;
 }
 
@@ -1069,6 +1350,23 @@ static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need)
     p = qzstd_hip_malloc(dev, need);
     *cap = p ? need : 0;
     return p;
+}
+
+void QZSTD_failStats(void *sequenceProducerState, unsigned long stats[8])
+{
+    const QZSTD_Session_T *s = (const QZSTD_Session_T *)sequenceProducerState;
+    int k;
+    if (!stats) return;
+    for (k = 0; k < 8; k++) stats[k] = 0;
+    if (!s) return;
+    stats[0] = s->fail[0];
+    stats[1] = s->fail[QZ_CAUSE_GUARD];
+    stats[2] = s->fail[QZ_CAUSE_DEVICE_DOWN];
+    stats[3] = s->fail[QZ_CAUSE_TIMEOUT];
+    stats[4] = s->fail[QZ_CAUSE_CAPACITY];
+    stats[5] = s->fail[QZ_CAUSE_RUNTIME];
+    stats[6] = s->redoneAlone;
+    stats[7] = s->servedService;
 }
 
 void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4])
@@ -1175,7 +1473,7 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
             int k, j;
             for (k = 0; k < 4; k++)
                 for (j = 0; j < s->hint[k].nParts; j++)
-                    if (&s->hint[k] != h) qzPartFinish(&s->hint[k].part[j]);
+                    if (&s->hint[k] != h) qzPartFinish(&s->hint[k], &s->hint[k].part[j]);
             i = qzGrabSlot(s->slotHint, dev);
         }
         if (i < 0) return -1;
@@ -1226,6 +1524,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     int parts, k, firstDev;
 
     qzHintDrop(h); /* an old announcement that was never consumed */
+    if (qzOrphans) qzReapOrphans(0);
     nb = (srcSize + blockSize - 1) / blockSize;
     /* a fine grid means many blocks: the result area is sized by what a block of that size can produce at most */
     h->pitch = qzstd_hip_sequence_bound(blockSize) < QZ_HINT_PITCH ? qzstd_hip_sequence_bound(blockSize) : QZ_HINT_PITCH;

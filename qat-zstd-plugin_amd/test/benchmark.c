@@ -12,6 +12,9 @@
  * Written from scratch; one additive option:  -H<n>  announce each thread's buffer to the plugin
  * one segment ahead with QZSTD_hintSource(), so that the GPU match-finds segment k+1 in one batched
  * launch while this thread's libzstd entropy-codes segment k.
+ * -P1 puts a barrier between the loops and reports the wall-clock rate of every pass (median / min / max): what bench.py
+ * quotes.  After a GPU run the producer callbacks that returned the error code are printed by cause (QZSTD_failStats): with
+ * -F1 those blocks were compressed by libzstd's own match-finder.
  * -DQZ_SOFTWARE_ONLY builds the -m0 half alone, against any libzstd >= 1.4 (no producer API needed): the software
  * baseline timed with an optimised system libzstd next to the 1.5.x the plugin needs.
  */
@@ -35,6 +38,8 @@ static void swRegister(ZSTD_CCtx *zc, void *st, void *fn) { (void)zc; (void)st; 
 #define QZSTD_createSeqProdState swState
 #define QZSTD_freeSeqProdState swFree
 #define QZSTD_hintSource swHint
+static void swFail(void *s, unsigned long st[8]) { (void)s; for (int k = 0; k < 8; k++) st[k] = 0; }
+#define QZSTD_failStats swFail
 #define ZSTD_registerSequenceProducer(zc, st, fn) swRegister(zc, st, NULL)
 #endif
 
@@ -42,7 +47,7 @@ static void swRegister(ZSTD_CCtx *zc, void *st, void *fn) { (void)zc; (void)st; 
 #define NBUCKETS 200
 
 typedef struct {
-    unsigned threads, loops, level, mode, extRep, hint, split, fallback;
+    unsigned threads, loops, level, mode, extRep, hint, split, fallback, passes;
     size_t chunk;
     const unsigned char *src;
     size_t srcSize;
@@ -53,6 +58,7 @@ typedef struct {
     unsigned id;
     int pass;
     double compMBps, decompMBps, ratioPct;
+    unsigned long fail[8]; /* QZSTD_failStats of the thread's state */
 } Worker;
 
 /* latency histogram shared by all threads: bucket i upper bound = 1000 ns * 1.05^i */
@@ -60,7 +66,9 @@ static double gBound[NBUCKETS];
 static unsigned long gCount[NBUCKETS];
 static unsigned long gSamples, gSumNs, gMinNs = ~0ul, gMaxNs;
 static pthread_mutex_t gHistLock = PTHREAD_MUTEX_INITIALIZER;
-static pthread_barrier_t gStart, gMid;
+static pthread_barrier_t gStart, gMid, gPass;
+#define MAX_PASSES 4096
+static unsigned long gPassStartNs[MAX_PASSES], gPassEndNs[MAX_PASSES]; /* -P1: first thread in .. last thread out, per loop */
 
 static void histInit(void)
 {
@@ -135,6 +143,7 @@ static void usage(const char *exe)
             "  -L#   compression level [1-12] (default 1)\n"
             "  -m#   0 software zstd, 1 GPU sequence producer (default 1)\n"
             "  -F#   1 = ZSTD_c_enableSeqProducerFallback (producer errors fall back to libzstd's own match-finder)\n"
+            "  -P#   1 = barrier between the loops, wall-clock rate of every pass reported (median / min / max)\n"
             "  -H#   look-ahead with QZSTD_hintSource: 1 = 4 MiB segments, n>1 = n MiB segments (default 0 = off)\n", exe);
 }
 
@@ -192,6 +201,11 @@ static void *worker(void *arg)
     if (w->id == 0) gCompStartNs = nowNs(); /* wall clock of the compression phase: first barrier .. last thread done */
     for (unsigned l = 0; ok && l < o->loops; l++) {
         size_t off = 0, dpos = 0;
+        if (o->passes) { /* every pass starts together and is timed first thread in .. last thread out */
+            pthread_barrier_wait(&gPass);
+            if (w->id == 0 && l < MAX_PASSES) gPassStartNs[l] = nowNs();
+            pthread_barrier_wait(&gPass);
+        }
         if (useHint) { /* announce the first segment; later ones are announced one segment ahead */
             const unsigned long t0 = nowNs();
             QZSTD_hintSource(state, o->src, o->srcSize < segBytes ? o->srcSize : segBytes, grid, (int)o->level);
@@ -225,6 +239,11 @@ static void *worker(void *arg)
             off += n;
         }
         total = dpos;
+        if (o->passes && l < MAX_PASSES) {
+            const unsigned long tE = nowNs();
+            unsigned long prev = __atomic_load_n(&gPassEndNs[l], __ATOMIC_RELAXED);
+            while (tE > prev && !__atomic_compare_exchange_n(&gPassEndNs[l], &prev, tE, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
     }
     {
         const unsigned long tEnd = nowNs();
@@ -259,6 +278,8 @@ static void *worker(void *arg)
     w->compMBps = compNs ? (double)o->srcSize * o->loops / MB_BYTES / ((double)compNs / 1e9) : 0.0;
     w->decompMBps = decNs ? (double)o->srcSize * o->loops / MB_BYTES / ((double)decNs / 1e9) : 0.0;
     histAddBatch(local, nS, sumNs, mn, mx);
+    for (int k = 0; k < 8; k++) w->fail[k] = 0;
+    if (state) QZSTD_failStats(state, w->fail);
     ZSTD_freeCCtx(zc);
     ZSTD_freeDCtx(zd);
     QZSTD_freeSeqProdState(state);
@@ -268,7 +289,7 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-    Options o = { 1, 1, 1, 1, 0, 0, 0, 0, 32 * 1024, NULL, 0 };
+    Options o = { 1, 1, 1, 1, 0, 0, 0, 0, 0, 32 * 1024, NULL, 0 };
     const char *file = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -283,6 +304,7 @@ int main(int argc, char **argv)
         case 'H': o.hint = (unsigned)atoi(a + 2); break;
         case 'S': o.split = (unsigned)atoi(a + 2); break;
         case 'F': o.fallback = (unsigned)atoi(a + 2); break;
+        case 'P': o.passes = (unsigned)atoi(a + 2); break;
         default: usage(argv[0]); return a[1] == 'h' || a[1] == 'H' ? 0 : 1;
         }
     }
@@ -307,6 +329,7 @@ int main(int argc, char **argv)
     histInit();
     pthread_barrier_init(&gStart, NULL, o.threads);
     pthread_barrier_init(&gMid, NULL, o.threads);
+    pthread_barrier_init(&gPass, NULL, o.threads);
     pthread_t *th = (pthread_t *)calloc(o.threads, sizeof(pthread_t));
     Worker *ws = (Worker *)calloc(o.threads, sizeof(Worker));
     const unsigned long w0 = nowNs();
@@ -317,8 +340,10 @@ int main(int argc, char **argv)
     }
     int allPass = 1;
     double sumComp = 0, sumDec = 0;
+    unsigned long fail[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     for (unsigned t = 0; t < o.threads; t++) {
         pthread_join(th[t], NULL);
+        for (int k = 0; k < 8; k++) fail[k] += ws[t].fail[k];
         fprintf(stderr, "Thread %u: Compression: %zu -> %.0f (%.2f%%), %.1f MB/s, Decompression: %.1f MB/s, %s\n", t,
                 o.srcSize, ws[t].ratioPct * (double)o.srcSize / 100.0, ws[t].ratioPct, ws[t].compMBps, ws[t].decompMBps,
                 ws[t].pass ? "PASS" : "FAIL");
@@ -333,6 +358,22 @@ int main(int argc, char **argv)
                     "%.1f MB/s by the wall clock of the compression phase (%.3f s), decompression %.1f MB/s, wall %.3f s\n",
             o.mode ? "GPU sequence producer" : "software zstd", o.level, o.chunk, o.threads, sumComp,
             compWall > 0 ? (double)o.srcSize * o.loops * o.threads / MB_BYTES / compWall : 0.0, compWall, sumDec, wall);
+    if (o.passes && compWall > 0) { /* a failed thread leaves the barriers: only complete runs are reported per pass */
+        const unsigned np = o.loops < MAX_PASSES ? o.loops : MAX_PASSES;
+        double r[MAX_PASSES];
+        unsigned n = 0;
+        for (unsigned l = 0; l < np; l++)
+            if (gPassEndNs[l] > gPassStartNs[l])
+                r[n++] = (double)o.srcSize * o.threads / MB_BYTES / ((double)(gPassEndNs[l] - gPassStartNs[l]) / 1e9);
+        for (unsigned i = 1; i < n; i++) /* insertion sort */
+            for (unsigned j = i; j > 0 && r[j - 1] > r[j]; j--) { const double x = r[j]; r[j] = r[j - 1]; r[j - 1] = x; }
+        if (n) fprintf(stderr, "Passes: %u, wall clock per pass: median %.1f MB/s, min %.1f, max %.1f\n", n,
+                       n & 1 ? r[n / 2] : 0.5 * (r[n / 2 - 1] + r[n / 2]), r[0], r[n - 1]);
+    }
+    if (o.mode == 1)
+        fprintf(stderr, "Producer errors: %lu (guards %lu, device down %lu, time-outs %lu, capacity %lu, runtime %lu)%s; dense blocks redone alone: %lu\n",
+                fail[0], fail[1], fail[2], fail[3], fail[4], fail[5],
+                fail[0] ? (o.fallback ? " - those blocks were compressed by libzstd's own match-finder" : "") : "", fail[6]);
     if (gSamples)
         fprintf(stderr, "Latency (us): P25 %.1f  P50 %.1f  P75 %.1f  P99 %.1f  avg %.1f  min %.1f  max %.1f  (%lu calls)\n",
                 percentileNs(25) / 1e3, percentileNs(50) / 1e3, percentileNs(75) / 1e3, percentileNs(99) / 1e3,

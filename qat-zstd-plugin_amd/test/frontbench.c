@@ -70,7 +70,8 @@ int main(int argc, char **argv)
     if (!dst || !sizes || !back) { fprintf(stderr, "out of memory\n"); return 1; }
     memset(dst, 0, nChunks * stride); /* touch the pages before timing */
 
-    double best = 0, sum = 0;
+    double best = 0, sum = 0, rate[256];
+    unsigned nr = 0;
     int ok = 1;
     for (unsigned l = 0; l < loops + 1 && ok; l++) { /* the first pass warms buffers, streams and pinned memory */
         const double t0 = nowS();
@@ -80,6 +81,7 @@ int main(int argc, char **argv)
         if (l == 0) continue;
         sum += dt;
         if (best == 0 || dt < best) best = dt;
+        if (nr < 256 && dt > 0) rate[nr++] = (double)n / 1e6 / dt;
     }
     size_t csize = 0;
     ZSTD_DCtx *zd = ZSTD_createDCtx();
@@ -91,8 +93,11 @@ int main(int argc, char **argv)
     }
     if (ok && memcmp(back, src, n) != 0) ok = 0;
     ZSTD_freeDCtx(zd);
-    unsigned long st[2];
+    unsigned long st[2], fl[8];
     QZSTD_frontStats(f, st);
+    QZSTD_frontFailStats(f, fl);
+    for (unsigned i = 1; i < nr; i++) /* insertion sort: median / min / max of the passes */
+        for (unsigned j = i; j > 0 && rate[j - 1] > rate[j]; j--) { const double x = rate[j]; rate[j] = rate[j - 1]; rate[j - 1] = x; }
     QZSTD_freeFront(f);
     if (p.useProducer) QZSTD_stopQatDevice();
     printf("frontbench libzstd %s mode %d level %d chunk %zu threads %d segment %zu: %zu -> %zu bytes, wall-clock %.1f MB/s "
@@ -100,6 +105,9 @@ int main(int argc, char **argv)
            ZSTD_versionString(), p.useProducer, p.level, p.chunkSize, p.nThreads, p.segmentBytes, n, csize,
            sum > 0 ? (double)n * loops / 1e6 / sum : 0.0, loops, best > 0 ? (double)n / 1e6 / best : 0.0, st[0], st[1],
            ok ? "PASS" : "FAIL");
+    if (nr) printf("passes MB/s: median %.1f min %.1f max %.1f\n", nr & 1 ? rate[nr / 2] : 0.5 * (rate[nr / 2 - 1] + rate[nr / 2]), rate[0], rate[nr - 1]);
+    printf("producer errors: %lu (guards %lu, device down %lu, time-outs %lu, capacity %lu, runtime %lu) - blocks compressed by libzstd's "
+           "own match-finder instead; dense blocks redone alone: %lu\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], fl[6]);
     free(src); free(dst); free(sizes); free(back);
     return ok ? 0 : 1;
 }

@@ -198,7 +198,8 @@ int main(int argc, char **argv)
         jobs[t] = j;
         pthread_create(&th[t], NULL, worker, &jobs[t]);
     }
-    double best = 0, sum = 0;
+    double best = 0, sum = 0, rate[256];
+    unsigned nr = 0;
     for (unsigned l = 0; l < loops + 1; l++) { /* the first pass warms the contexts */
         pthread_barrier_wait(&bar);
         const double t0 = nowS();
@@ -207,7 +208,10 @@ int main(int argc, char **argv)
         if (l == 0) continue;
         sum += mbps;
         if (mbps > best) best = mbps;
+        if (nr < 256) rate[nr++] = mbps;
     }
+    for (unsigned i = 1; i < nr; i++) /* insertion sort: median / min / max of the passes */
+        for (unsigned j = i; j > 0 && rate[j - 1] > rate[j]; j--) { const double x = rate[j]; rate[j] = rate[j - 1]; rate[j - 1] = x; }
     int ok = 1;
     for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); if (jobs[t].failed) ok = 0; }
 
@@ -222,5 +226,6 @@ int main(int argc, char **argv)
     printf("replay: %d threads, level %d, chunk %zu, %zu bytes, %zu of %zu blocks recorded, csize %zu, "
            "%.1f MB/s wall (best pass %.1f), round trip %s\n",
            threads, level, chunk, n, recorded, tab.nRec, csize, sum / loops, best, ok ? "PASS" : "FAIL");
+    if (nr) printf("passes MB/s: median %.1f min %.1f max %.1f\n", nr & 1 ? rate[nr / 2] : 0.5 * (rate[nr / 2 - 1] + rate[nr / 2]), rate[0], rate[nr - 1]);
     return ok ? 0 : 1;
 }

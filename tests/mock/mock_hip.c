@@ -75,6 +75,54 @@ int qzstd_hip_memcpy2d_d2h(int device, void *s, void *dst, size_t dp, const void
     return 0;
 }
 
+/* ---- the resident service, mocked: a request is served synchronously by the oracle, item by item, counts written last.
+ * Test hooks: QZSTD_MOCK_SERVICE=0 -> "not served" (the callers take the launch path); a stall (qzstd_mock_stall_ms) ->
+ * the counts never arrive (the caller's poll times out); qzstd_mock_service_level(l) -> requests of other levels are
+ * handed back as rejected, as the dispatcher does when another level is resident. */
+static int gSvcRequests, gSvcBroken, gSvcStops, gSvcLevel;
+void qzstd_mock_service_level(int level) { gSvcLevel = level; }
+int qzstd_mock_service_requests(void) { return gSvcRequests; }
+void *qzstd_hip_host_alloc_coherent(size_t bytes) { return malloc(bytes ? bytes : 1); }
+int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r)
+{
+    const char *v = getenv("QZSTD_MOCK_SERVICE");
+    qzo_profile_t pf;
+    uint32_t k;
+    (void)device;
+    if ((v && atoi(v) == 0) || gSvcBroken) return 1;
+    if (qzo_profile_for_level(level, r->srcLen, &pf) || pf.chainDepth || pf.longSize) return 1; /* the levels the real one serves */
+    if (r->nItems < 1 || r->nItems > QZSTD_HIP_SVC_MAX_ITEMS || r->slot >= QZSTD_HIP_SVC_MAX_SLOTS || (r->itemBytes & ((1u << pf.segLog) - 1u)) ||
+        (size_t)(r->nItems - 1) * r->itemBytes >= r->srcLen) {
+        snprintf(gErr, sizeof gErr, "mock: bad service request");
+        return -1;
+    }
+    __sync_fetch_and_add(&gSvcRequests, 1);
+    if (nowNs() < gStallUntilNs) return 0; /* queued, never served */
+    for (k = 0; k < r->nItems; k++) {
+        const uint32_t from = k * r->itemBytes, upTo = from + r->itemBytes < r->srcLen ? from + r->itemBytes : r->srcLen;
+        size_t n;
+        if (gSvcLevel && gSvcLevel != level) { r->hCount[k] = QZSTD_HIP_NSEQ_REJECTED; continue; }
+        memcpy((uint8_t *)r->dSrc + from, (const uint8_t *)r->hSrc + from, upTo - from); /* the item's slice */
+        n = qzo_find_sequences_from(&pf, (const uint8_t *)r->dSrc, upTo, from, (qzo_seq_t *)r->hSeqs + (size_t)k * r->seqCapPerItem, r->seqCapPerItem);
+        __atomic_store_n(&r->hCount[k], n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n, __ATOMIC_RELEASE);
+    }
+    return 0;
+}
+int qzstd_hip_service_stop(int device) { (void)device; __sync_fetch_and_add(&gSvcStops, 1); return 0; }
+void qzstd_hip_service_mark_broken(int device) { (void)device; gSvcBroken = 1; }
+void qzstd_mock_service_repair(void) { gSvcBroken = 0; }
+int qzstd_hip_service_info(int device, unsigned long out[8])
+{
+    int k;
+    (void)device;
+    for (k = 0; k < 8; k++) out[k] = 0;
+    out[1] = (unsigned long)gSvcRequests;
+    out[3] = (unsigned long)gSvcBroken;
+    return 0;
+}
+
+int qzstd_hip_service_debug(int device, unsigned long out[8]) { int k; (void)device; for (k = 0; k < 8; k++) out[k] = 0; return 0; }
+
 int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_src, const qzstd_hip_block_t *d_blocks,
                              uint32_t nBlocks, uint32_t maxBlockLen, void *d_seqs, uint32_t *d_nseq, void *d_work,
                              size_t workBytes)

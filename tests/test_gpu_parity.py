@@ -114,7 +114,7 @@ def test_randomised_blocks(gpu_plugin, oracle, level, seed):
 @pytest.mark.parametrize("level", [1, 2, 3, 4, 6, 9, 12, 0x101, 0x105])
 def test_segment_work_items(gpu_plugin, oracle, level):
     """qzstd_hip_block_t.parseFrom (every level): a work item that holds a block up to a segment's end and parses the
-    segment only (what the per-block path submits, four items per 128 KiB block) — bit-exact against the oracle's
+    segment(s) only (what the per-block paths submit: up to 32 items per 128 KiB block) — bit-exact against the oracle's
     qzo_find_sequences_from, ragged sizes included; a parseFrom that is no segment boundary is refused"""
     items, froms = [], []
     for gen, size in (("text", 131072), ("system", 131072), ("weblog", 100001), ("binary", 70000), ("mix", 33000)):
@@ -133,6 +133,16 @@ def test_segment_work_items(gpu_plugin, oracle, level):
         for s0 in (32768, 98304):
             items.append(blk[:min(len(blk), s0 + 32768)])
             froms.append(s0)
+    # the service path's granularity: one item per 4 KiB segment (32 per 128 KiB block), and runs of three segments
+    fine = K.by_name("system", 131072, seed=37)
+    for step in (4096, 12288):
+        for s0 in range(0, len(fine), step):
+            items.append(fine[:min(len(fine), s0 + step)])
+            froms.append(s0)
+    ragged = K.by_name("weblog", 50001, seed=41)
+    for s0 in range(0, len(ragged), 4096):
+        items.append(ragged[:min(len(ragged), s0 + 4096)])
+        froms.append(s0)
     counts, seqs, stride = gpu_plugin.find_batch(items, level, parse_from=froms)
     for i, (blk, s0) in enumerate(zip(items, froms)):
         want_n, want = oracle.find(oracle.profile(level, len(blk)), blk, cap=stride, parse_from=s0)

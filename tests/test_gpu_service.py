@@ -1,0 +1,144 @@
+"""GPU: the resident service (qzstd_hip_service_submit — per-block requests without a launch, include/qzstd_hip.h) against
+the oracle, item by item and through the plugin's callback path; its life cycle (idle exit and relaunch, memory freed while
+it is resident, another level asking)."""
+import ctypes as C
+import os
+import threading
+import time
+
+import pytest
+
+import qz_bind as B
+import qz_corpus as K
+
+pytestmark = pytest.mark.gpu
+
+
+def check_request(oracle, lane, blk, level, item_bytes=4096):
+    r = lane.run(blk, level, item_bytes)
+    assert r is not None, "not served"
+    counts, seqs, cap, item = r
+    pf = oracle.profile(level, len(blk))
+    for k, got_n in enumerate(counts):
+        upto = min(len(blk), (k + 1) * item)
+        want_n, want = oracle.find(pf, blk[:upto], cap=cap, parse_from=k * item)
+        assert got_n == (want_n if want_n != B.SEQ_ERROR else B.NSEQ_ERROR), "item %d of %d: count %d, oracle %d" % (k, len(counts), got_n, want_n)
+        if want_n == B.SEQ_ERROR:
+            continue
+        for i in range(want_n):
+            g, w = seqs[k * cap + i], want[i]
+            assert (g.offset, g.litLength, g.matchLength) == (w.offset, w.litLength, w.matchLength), "item %d sequence %d" % (k, i)
+
+
+@pytest.mark.parametrize("level", [1, 2, 0x101, 0x102])
+def test_service_items_equal_the_oracle(gpu_plugin, oracle, level):
+    """every work item of a request — 4 KiB items, coarser items, ragged block sizes, degenerate content — bit-exact against
+    qzo_find_sequences_from; the count words are the only completion signal"""
+    lane = gpu_plugin.service_lane(slot=7)
+    try:
+        data = K.by_name("system", 4 * 131072, seed=3)
+        for o in range(0, len(data), 131072):
+            check_request(oracle, lane, data[o:o + 131072], level)
+        for gen, size in (("text", 100001), ("weblog", 32768), ("binary", 4097), ("mix", 4096), ("text", 1), ("text", 17), ("mix", 65537)):
+            check_request(oracle, lane, K.by_name(gen, size, seed=size), level)
+        for item in (8192, 16384, 65536):
+            check_request(oracle, lane, data[:131072], level, item)
+        for blk in (bytes(131072), b"ab" * 65536, ((b"abcdefgh" * 5 + b"X") * 3197)[:131072], K.incompressible(9, 131072)):
+            check_request(oracle, lane, blk, level)
+    finally:
+        lane.close()
+
+
+def test_service_levels_it_does_not_serve(gpu_plugin):
+    lane = gpu_plugin.service_lane(slot=8)
+    try:
+        blk = K.text(5, 65536)
+        for level in (3, 4, 5, 6, 9, 12):  # fill a CU's LDS / need per-item chain scratch: the launch path's
+            assert lane.run(blk, level) is None
+    finally:
+        lane.close()
+
+
+def test_service_concurrent_callers_idle_exit_and_frees(gpu_plugin, oracle):
+    """16 callers at once (one slot each); then the service idles out (QZSTD_HIP_SERVICE_IDLE_US, default 20 ms) and the next
+    request launches it again; memory freed while it is resident (hipFree waits for every stream: the service leaves first)"""
+    L = gpu_plugin.lib
+    info = (C.c_ulong * 8)()
+    data = K.by_name("system", 16 * 131072, seed=11)
+    lanes = [gpu_plugin.service_lane(slot=20 + t) for t in range(16)]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                blk = data[((t + rep) % 16) * 131072:((t + rep) % 16 + 1) * 131072]
+                check_request(oracle, lanes[t], blk if rep % 3 else blk[:100000 + t], 1)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:3]
+    L.qzstd_hip_service_info(0, C.byref(info))
+    launches = info[0]
+    time.sleep(0.2)  # > the idle time: the kernels have left
+    L.qzstd_hip_service_info(0, C.byref(info))
+    assert info[4] == 0, list(info)
+    assert lanes[0].run(data[:131072], 1) is not None
+    L.qzstd_hip_service_info(0, C.byref(info))  # (checking against the oracle takes longer than the idle time: look first)
+    assert info[0] == launches + 1 and info[4] == 1 and info[3] == 0, list(info)
+    check_request(oracle, lanes[0], data[:131072], 1)
+    # free memory while the service is resident: must not hang
+    p = L.qzstd_hip_malloc(0, 1 << 20)
+    t0 = time.time()
+    L.qzstd_hip_free(0, p)
+    assert time.time() - t0 < 1.0
+    check_request(oracle, lanes[1], data[131072:262144], 1)
+    # another level while level 1 is resident: refused (launch path), then served once the service has gone
+    r = lanes[2].run(data[:65536], 2)
+    assert r is None or r[0][0] not in (0, B.NSEQ_REJECTED)
+    assert L.qzstd_hip_service_stop(0) == 0
+    check_request(oracle, lanes[2], data[:65536], 2)
+    assert L.qzstd_hip_service_stop(0) == 0
+    for ln in lanes:
+        ln.close()
+
+
+@pytest.mark.parametrize("service", ["1", "0"])
+def test_unchanged_callers_through_the_plugin(gpu_plugin, zstd, oracle, service, tmp_path):
+    """the callback path in a child process (the switch is read at QZSTD_startQatDevice): frames of libzstd + plugin equal the
+    frames of libzstd + oracle with the service on and off, 8 threads; the service counter says who served"""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys, threading
+sys.path.insert(0, %r)
+import qz_bind as B, qz_corpus as K
+z, orc, plug = B.Zstd(), B.Oracle(), B.Plugin()
+assert plug.lib.QZSTD_startQatDevice() == 0
+data = K.by_name("system", 24 * 131072, seed=21)
+bad = []
+def run(t):
+    st = plug.lib.QZSTD_createSeqProdState()
+    zc = z.cctx(1, producer=plug.producer_addr, state=st, fallback=False, validate=True)
+    zo = z.cctx(1, producer=orc.producer_addr, state=None, fallback=False, validate=True)
+    for c in range(t, 24, 8):
+        blk = data[c * 131072:(c + 1) * 131072][:131072 - 1000 * (c %% 3)]
+        if z.compress2(zc, blk) != z.compress2(zo, blk): bad.append(c)
+    fs = (C.c_ulong * 8)(); plug.lib.QZSTD_failStats(st, C.byref(fs))
+    served.append((fs[7], fs[0]))
+    z.free(zc); z.free(zo); plug.lib.QZSTD_freeSeqProdState(st)
+served = []
+th = [threading.Thread(target=run, args=(t,)) for t in range(8)]
+[x.start() for x in th]; [x.join() for x in th]
+plug.lib.QZSTD_stopQatDevice()
+print("RESULT", len(bad), sum(a for a, _ in served), sum(b for _, b in served))
+''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, QZSTD_HIP_SERVICE=service))
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert int(res[1]) == 0 and int(res[3]) == 0, res
+    assert int(res[2]) == (24 if service == "1" else 0), res

@@ -42,7 +42,7 @@ def test_front_end_library_exports_what_its_header_declares(plugin):
     import ctypes
     declared = declared_functions("qzstd_frontend.h")
     assert declared == {"QZSTD_createFront", "QZSTD_frontFrameStride", "QZSTD_frontCompress", "QZSTD_frontCompact",
-                        "QZSTD_frontStats", "QZSTD_freeFront"}
+                        "QZSTD_frontStats", "QZSTD_frontFailStats", "QZSTD_freeFront"}
     B.Zstd()  # libzstd first (RTLD_GLOBAL): the front-end links against it
     lib = ctypes.CDLL(os.path.join(B.PKG_DIR, "lib", "libqzstdfront.so"))
     for name in sorted(declared):

@@ -473,3 +473,149 @@ def test_replay_ceiling_tool_over_the_mock(mock, zstd, tmp_path):
         out = subprocess.run([exe] + args + [str(f)], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "round trip PASS" in out.stdout, out.stdout + out.stderr
         assert "%d of %d blocks recorded" % (nrec, nrec) in out.stdout, out.stdout
+
+
+# ---------------------------------------------------------------- round 3: the resident service, fallback counters, parked buffers
+@pytest.fixture(autouse=True)
+def _service_in_service(mock):
+    """a test that lets a service request time out leaves the (mock) service marked broken: every test starts with it repaired"""
+    mock.lib.qzstd_mock_service_repair()
+    yield
+
+
+def fail_stats(plug, st):
+    s = (C.c_ulong * 8)()
+    plug.lib.QZSTD_failStats(st, C.byref(s))
+    return list(s)
+
+
+@pytest.mark.parametrize("level,chunk", [(1, 131072), (2, 65536), (1, 100001), (1, 4096), (2, 1000)])
+def test_service_path_serves_unchanged_callers(mock, zstd, oracle, level, chunk):
+    """per-block requests of the levels the resident service serves go through qzstd_hip_service_submit (mocked: the oracle
+    per work item, 4 KiB items, counts written last) and the joined lists give the oracle's frames; with QZSTD_HIP_SERVICE=0
+    the same callers take the launch path — same frames"""
+    data = K.by_name("mix", 9 * chunk + 321, seed=level + 40)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    want = oracle_frames(zstd, oracle, data, chunk, level)
+    before = L.qzstd_mock_service_requests()
+    st = L.QZSTD_createSeqProdState()
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, level)
+    fs, hs = fail_stats(mock, st), stats_of(mock, st)
+    L.QZSTD_freeSeqProdState(st)
+    assert got == want
+    assert L.qzstd_mock_service_requests() - before == 10 and fs[7] == 10 and hs[1] == 10 and fs[0] == 0, (fs, hs)
+    with restarted(mock, QZSTD_HIP_SERVICE="0"):
+        before = L.qzstd_mock_service_requests()
+        st = L.QZSTD_createSeqProdState()
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, level)
+        fs = fail_stats(mock, st)
+        L.QZSTD_freeSeqProdState(st)
+        assert got == want and L.qzstd_mock_service_requests() == before and fs[7] == 0
+
+
+def test_service_coarser_items_and_other_levels(mock, zstd, oracle):
+    """QZSTD_HIP_SERVICE_ITEM: items of several segments; levels the service does not serve (3: fills a CU's LDS, 6: chains)
+    and requests the dispatcher hands back (another level is resident) take the launch path"""
+    chunk = 131072
+    data = K.by_name("system", 3 * chunk, seed=3)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_service_level.argtypes = [C.c_int]
+    with restarted(mock, QZSTD_HIP_SERVICE_ITEM="16384"):
+        st = L.QZSTD_createSeqProdState()
+        assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1) == oracle_frames(zstd, oracle, data, chunk, 1)
+        assert fail_stats(mock, st)[7] == 3
+        L.QZSTD_freeSeqProdState(st)
+    for level in (3, 6):
+        st = L.QZSTD_createSeqProdState()
+        assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), chunk, chunk, level) == oracle_frames(zstd, oracle, data[:chunk], chunk, level)
+        assert fail_stats(mock, st)[7] == 0 and stats_of(mock, st)[1] == 1
+        L.QZSTD_freeSeqProdState(st)
+    L.qzstd_mock_service_level(2)  # "level 2 is resident": level-1 requests come back rejected
+    try:
+        st = L.QZSTD_createSeqProdState()
+        assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1) == oracle_frames(zstd, oracle, data, chunk, 1)
+        fs = fail_stats(mock, st)
+        assert fs[7] == 0 and fs[0] == 0 and stats_of(mock, st)[1] == 3, fs
+        L.QZSTD_freeSeqProdState(st)
+    finally:
+        L.qzstd_mock_service_level(0)
+
+
+def test_service_time_out_is_an_error_then_the_launch_path_takes_over(mock, zstd):
+    """a service request whose counts never arrive: the error code after QZSTD_HIP_TIMEOUT_MS (reference: 2 s of polling,
+    src/qatseqprod.c:1261-1285), counted as a time-out; the service is not used again, the slot not before its counts have
+    arrived; later blocks are served by the launch path"""
+    import time
+    chunk = 65536
+    data = K.by_name("text", 2 * chunk, seed=33)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_stall_ms.argtypes = [C.c_int]
+    with restarted(mock, QZSTD_HIP_TIMEOUT_MS="40", QZSTD_HIP_COALESCE="1"):
+        st = L.QZSTD_createSeqProdState()
+        seqs = (B.Sequence * B.sequence_bound(chunk))()
+        L.qzstd_mock_stall_ms(200)
+        t0 = time.time()
+        rc = L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 1, 1 << 17)
+        assert rc == B.SEQ_ERROR and 0.03 <= time.time() - t0 < 0.19
+        fs = fail_stats(mock, st)
+        assert fs[0] == 1 and fs[3] == 1, fs
+        L.qzstd_mock_stall_ms(0)
+        time.sleep(0.25)
+        rc = L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 1, 1 << 17)
+        assert rc != B.SEQ_ERROR and rc > 1
+        fs = fail_stats(mock, st)
+        assert fs[0] == 1 and fs[7] == 0 and stats_of(mock, st)[1] == 1, fs  # served, by the launch path
+        L.QZSTD_freeSeqProdState(st)
+    L.qzstd_mock_service_repair()
+
+
+def test_fail_stats_count_every_cause(mock, zstd):
+    """QZSTD_failStats: guards, capacity rule, time-outs — what libzstd's fallback would otherwise hide"""
+    chunk = 32768
+    data = K.by_name("text", chunk, seed=35)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    st = L.QZSTD_createSeqProdState()
+    seqs = (B.Sequence * B.sequence_bound(chunk))()
+    assert L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 13, 1 << 17) == B.SEQ_ERROR   # level
+    assert L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, buf, 8, 1, 1 << 17) == B.SEQ_ERROR     # dictionary
+    assert L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 1, 1024) == B.SEQ_ERROR       # window
+    assert L.qatSequenceProducer(st, seqs, 64, buf, chunk, None, 0, 1, 1 << 17) == B.SEQ_ERROR           # 64 entries cannot hold it
+    assert L.qatSequenceProducer(st, seqs, 64, buf, chunk, None, 0, 6, 1 << 17) == B.SEQ_ERROR           # ... on the launch path neither
+    assert L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 1, 1 << 17) > 1
+    fs = fail_stats(mock, st)
+    assert fs[0] == 5 and fs[1] == 3 and fs[4] == 2 and fs[2] == fs[3] == fs[5] == 0, fs
+    L.QZSTD_freeSeqProdState(st)
+
+
+def test_timed_out_announcement_parks_its_buffers(mock, zstd, oracle):
+    """round-2 ADVICE: a part of an announcement that timed out may still be read and written by its kernel — the announcement's
+    pinned buffers are parked (neither reused, scrubbed nor freed) until the stream has drained, the next announcement gets
+    fresh ones, and its frames are the oracle's"""
+    import time
+    chunk = 65536
+    data = K.by_name("system", 8 * chunk, seed=5)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_stall_ms.argtypes = [C.c_int]
+    L.qzstd_test_orphans.restype = C.c_ulong
+    with restarted(mock, QZSTD_HIP_TIMEOUT_MS="30"):
+        before = L.qzstd_test_orphans()
+        st = L.QZSTD_createSeqProdState()
+        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) == 0
+        L.qzstd_mock_stall_ms(300)
+        seqs = (B.Sequence * B.sequence_bound(chunk))()
+        assert L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 3, 1 << 17) == B.SEQ_ERROR  # the part times out, the launch path too
+        # a state holds two announcements: the second call from here reuses — drops — the one whose part timed out
+        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) in (0, -1)
+        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) in (0, -1)
+        assert L.qzstd_test_orphans() == before + 1  # its buffers are parked, not reused
+        L.qzstd_mock_stall_ms(0)
+        time.sleep(0.35)
+        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) == 0
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 3)
+        L.QZSTD_freeSeqProdState(st)
+        assert got == oracle_frames(zstd, oracle, data, chunk, 3)

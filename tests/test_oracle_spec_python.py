@@ -113,7 +113,11 @@ def parse_rep(pf, src, cand, nh):
     while cur < nh:
         if pf.segLog and (cur >> pf.segLog) != rep_seg:  # a new segment starts without repeat offsets
             rep, rep_seg = [0, 0], cur >> pf.segLog
-        lim = min(((cur >> pf.tileLog) + 1) << pf.tileLog, nh)
+        start_end = seg_end(pf, cur, n) - 4 + 1  # nothing starts in a segment's last positions that cannot be hashed (4-byte hash here)
+        if cur >= start_end:
+            cur = seg_end(pf, cur, n)
+            continue
+        lim = min(((cur >> pf.tileLog) + 1) << pf.tileLog, start_end)
         W = min(pf.repWin, lim - cur)
         V = min(W + 2, lim - cur)
         G, opt = [], []

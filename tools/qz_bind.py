@@ -240,16 +240,27 @@ class HipBlock(C.Structure):
 
 
 NSEQ_ERROR = 0xFFFFFFFF
+NSEQ_REJECTED = 0xFFFFFFFE
+
+
+class SvcReq(C.Structure):
+    """qzstd_hip_svc_req_t (include/qzstd_hip.h): one block for the resident service"""
+    _fields_ = [("hSrc", C.c_void_p), ("dSrc", C.c_void_p), ("hSeqs", C.c_void_p), ("hCount", C.c_void_p),
+                ("srcLen", C.c_uint32), ("itemBytes", C.c_uint32), ("nItems", C.c_uint32), ("seqCapPerItem", C.c_uint32),
+                ("slot", C.c_uint32), ("epoch", C.c_uint32)]
+
 
 # every symbol include/qatseqprod.h and include/qzstd_hip.h declare
 PLUGIN_SYMBOLS = [
     "QZSTD_version", "qatSequenceProducer", "QZSTD_startQatDevice", "QZSTD_stopQatDevice",
-    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource", "QZSTD_hintStats",
+    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource", "QZSTD_hintStats", "QZSTD_failStats",
     "qzstd_hip_last_error", "qzstd_hip_profile_for_level", "qzstd_hip_sequence_bound", "qzstd_hip_lds_bytes",
     "qzstd_hip_device_count", "qzstd_hip_device_name", "qzstd_hip_malloc", "qzstd_hip_free",
     "qzstd_hip_host_alloc", "qzstd_hip_host_free", "qzstd_hip_stream_create", "qzstd_hip_stream_destroy",
     "qzstd_hip_stream_sync", "qzstd_hip_stream_query", "qzstd_hip_stream_wait", "qzstd_hip_memcpy_h2d", "qzstd_hip_memcpy_d2h",
     "qzstd_hip_memset", "qzstd_hip_memcpy2d_d2h", "qzstd_hip_host_device_ptr", "qzstd_hip_workspace_bytes", "qzstd_hip_find_sequences",
+    "qzstd_hip_service_submit", "qzstd_hip_service_stop", "qzstd_hip_service_mark_broken", "qzstd_hip_service_info", "qzstd_hip_service_debug",
+    "qzstd_hip_host_alloc_coherent",
 ]
 
 
@@ -266,6 +277,8 @@ class Plugin:
         L.QZSTD_hintSource.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.QZSTD_hintStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong * 4)]
         L.QZSTD_hintStats.restype = None
+        L.QZSTD_failStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong * 8)]
+        L.QZSTD_failStats.restype = None
         L.qatSequenceProducer.restype = C.c_size_t
         L.qatSequenceProducer.argtypes = [C.c_void_p, C.POINTER(Sequence), C.c_size_t, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]
@@ -297,6 +310,11 @@ class Plugin:
                                                C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.qzstd_hip_workspace_bytes.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
         L.qzstd_hip_workspace_bytes.restype = C.c_size_t
+        L.qzstd_hip_host_alloc_coherent.restype = C.c_void_p
+        L.qzstd_hip_host_alloc_coherent.argtypes = [C.c_size_t]
+        L.qzstd_hip_service_submit.argtypes = [C.c_int, C.c_int, C.POINTER(SvcReq)]
+        L.qzstd_hip_service_info.argtypes = [C.c_int, C.POINTER(C.c_ulong * 8)]
+        L.qzstd_hip_service_debug.argtypes = [C.c_int, C.POINTER(C.c_ulong * 8)]
         self.producer_addr = C.cast(L.qatSequenceProducer, C.c_void_p)
 
     def err(self) -> str:
@@ -311,6 +329,11 @@ class Plugin:
     def check(self, rc: int, what: str):
         if rc != 0:
             raise RuntimeError("%s failed: %s" % (what, self.err()))
+
+    def service_lane(self, slot: int, device: int = 0):
+        """buffers of one caller of the resident service (what a slot of the plugin holds): returns an object with
+        .run(block, level, item_bytes, timeout_s) -> (counts, Sequence array, cap per item) or None when not served"""
+        return ServiceLane(self, slot, device)
 
     def find_batch(self, blocks: list[bytes], level: int = 1, device: int = 0, stride: int | None = None,
                    caps: list[int] | None = None, parse_from: list[int] | None = None):
@@ -360,3 +383,45 @@ class Plugin:
                 if p:
                     L.qzstd_hip_free(device, p)
         return list(cnt), seqs, stride
+
+
+class ServiceLane:
+    """One request at a time through qzstd_hip_service_submit, by hand (tests, tools)."""
+    MAX_ITEMS, ITEM_CAP, BLOCK_MAX = 32, 1371, 1 << 17
+
+    def __init__(self, plug: Plugin, slot: int, device: int = 0):
+        L = self.L = plug.lib
+        self.plug, self.slot, self.device, self.epoch = plug, slot, device, 0
+        self.hsrc = L.qzstd_hip_host_alloc_coherent(self.BLOCK_MAX + 64)
+        self.hseq = L.qzstd_hip_host_alloc_coherent(self.MAX_ITEMS * self.ITEM_CAP * 16)
+        self.hcnt = L.qzstd_hip_host_alloc_coherent(self.MAX_ITEMS * 4)
+        self.dsrc = L.qzstd_hip_malloc(device, self.BLOCK_MAX + 64)
+        assert self.hsrc and self.hseq and self.hcnt and self.dsrc, plug.err()
+        self.cnt = (C.c_uint32 * self.MAX_ITEMS).from_address(self.hcnt)
+        self.seqs = (Sequence * (self.MAX_ITEMS * self.ITEM_CAP)).from_address(self.hseq)
+
+    def run(self, block: bytes, level: int, item_bytes: int = 4096, timeout_s: float = 5.0):
+        import time
+        n = len(block)
+        while -(-n // item_bytes) > self.MAX_ITEMS:
+            item_bytes *= 2
+        nit = -(-n // item_bytes)
+        cap = self.MAX_ITEMS * self.ITEM_CAP // nit
+        C.memmove(self.hsrc, block + bytes(16), n + 16)
+        for k in range(nit):
+            self.cnt[k] = 0
+        self.epoch = self.epoch % 0xFFFFFF + 1
+        rq = SvcReq(self.hsrc, self.dsrc, self.hseq, self.hcnt, n, item_bytes, nit, cap, self.slot, self.epoch)
+        rc = self.L.qzstd_hip_service_submit(self.device, level, C.byref(rq))
+        if rc == 1:
+            return None
+        assert rc == 0, self.plug.err()
+        t0 = time.perf_counter()
+        while not all(self.cnt[k] for k in range(nit)):
+            assert time.perf_counter() - t0 < timeout_s, "service request timed out: counts %s" % [self.cnt[k] for k in range(nit)]
+        return [self.cnt[k] for k in range(nit)], self.seqs, cap, item_bytes
+
+    def close(self):
+        L = self.L
+        L.qzstd_hip_host_free(self.hsrc); L.qzstd_hip_host_free(self.hseq); L.qzstd_hip_host_free(self.hcnt)
+        L.qzstd_hip_free(self.device, self.dsrc)
