@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--corpus", default="system", help="system | text | mix | weblog | mixed_entropy | /path/to/file")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / end-to-end legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--e2e-seconds", type=float, default=5.5, help="continuous load per first-class end-to-end leg")
     return ap.parse_args()
 
 
@@ -134,11 +135,30 @@ def build_tools():
     return tdir
 
 
+def _errors_of(text: str):
+    """"Producer errors: N (guards a, device down b, time-outs c, capacity d, runtime e)" / "producer errors: ..." printed by the tools"""
+    import re
+    m = re.search(r"[Pp]roducer errors: (\d+) \(guards (\d+), device down (\d+), time-outs (\d+), capacity (\d+), runtime (\d+)\)", text)
+    if not m:
+        return None
+    v = [int(x) for x in m.groups()]
+    return {"total": v[0], "guards": v[1], "device_down": v[2], "time_outs": v[3], "capacity": v[4], "runtime": v[5]}
+
+
+def _passes_of(text: str):
+    import re
+    m = re.search(r"[Pp]asses(?: MB/s)?:? ?(\d+)?,? ?(?:wall clock per pass: )?median ([0-9.]+)(?: MB/s,)? min ([0-9.]+),? max ([0-9.]+)", text)
+    if not m:
+        return None
+    return {"median": float(m.group(2)), "min": float(m.group(3)), "max": float(m.group(4)), "passes": int(m.group(1)) if m.group(1) else None}
+
+
 def c_benchmark(sample_file: str, block: int, level: int, threads: int, mode: int, hint: int = 0, ext_rep: int = 0,
-                loops: int = 2, env: dict | None = None, tool: str = "benchmark", split: int = 0):
+                loops: int = 2, env: dict | None = None, tool: str = "benchmark", split: int = 0, passes: bool = False):
     """run qat-zstd-plugin_amd/test/benchmark (counterpart of the reference's test/benchmark.c: T threads,
     one CCtx each, one ZSTD_compress2 per chunk, each chunk its own frame) on a sample file.  tool="benchmark_sw" is the
-    same source built software-only against the system's libzstd 1.4.x."""
+    same source built software-only against the system's libzstd 1.4.x.  passes=True: -P1, a barrier between the loops and the
+    wall-clock rate of every pass (median / min / max)."""
     import re
     import subprocess
     tdir = os.path.join(B.PKG_DIR, "test")
@@ -147,25 +167,51 @@ def c_benchmark(sample_file: str, block: int, level: int, threads: int, mode: in
         if not os.path.isfile(exe):
             return {"error": "%s not built" % tool}
         cmd = [exe, "-m%d" % mode, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level,
-               "-E%d" % ext_rep] + (["-H%d" % hint] if hint else []) + (["-S%d" % split] if split else []) + [sample_file]
+               "-E%d" % ext_rep] + (["-H%d" % hint] if hint else []) + (["-S%d" % split] if split else []) + (["-P1"] if passes else []) + [sample_file]
         t0 = time.perf_counter()
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
         wall = time.perf_counter() - t0
-        agg = re.search(r"aggregate compression ([0-9.]+) MB/s \(sum of per-thread rates\), ([0-9.]+) MB/s by the wall clock", out.stderr)
+        agg = re.search(r"aggregate compression ([0-9.]+) MB/s \(sum of per-thread rates\), ([0-9.]+) MB/s by the wall clock of the compression phase \(([0-9.]+) s\)", out.stderr)
         ver = re.search(r"libzstd ([0-9.]+);", out.stderr)
         first = re.search(r"Compression: (\d+) -> (\d+) ", out.stderr)
         lat = re.search(r"P50 ([0-9.]+)\s+P75 [0-9.]+\s+P99 ([0-9.]+)", out.stderr)
         if out.returncode != 0 or not agg or not first:
             return {"error": (out.stderr or "benchmark failed")[-300:]}
-        return {"MBps_wall": float(agg.group(2)), "MBps_sum_of_thread_rates": float(agg.group(1)), "threads": threads,
-                "libzstd": ver.group(1) if ver else None,
-                "bytes_per_thread": int(first.group(1)), "loops": loops,
-                "csize": int(first.group(2)), "ratio": round(int(first.group(1)) / max(int(first.group(2)), 1), 4),
-                "latency_us_p50": float(lat.group(1)) if lat else None, "latency_us_p99": float(lat.group(2)) if lat else None,
-                "tool": "qat-zstd-plugin_amd/test/%s " % tool + " ".join(cmd[1:-1]) + (" env " + " ".join("%s=%s" % kv for kv in env.items()) if env else ""),
-                "wall_s": round(wall, 2)}
+        r = {"MBps_wall": float(agg.group(2)), "MBps_sum_of_thread_rates": float(agg.group(1)), "threads": threads,
+             "compression_phase_s": float(agg.group(3)), "libzstd": ver.group(1) if ver else None,
+             "bytes_per_thread": int(first.group(1)), "loops": loops,
+             "csize": int(first.group(2)), "ratio": round(int(first.group(1)) / max(int(first.group(2)), 1), 4),
+             "latency_us_p50": float(lat.group(1)) if lat else None, "latency_us_p99": float(lat.group(2)) if lat else None,
+             "tool": "qat-zstd-plugin_amd/test/%s " % tool + " ".join(cmd[1:-1]) + (" env " + " ".join("%s=%s" % kv for kv in env.items()) if env else ""),
+             "wall_s": round(wall, 2)}
+        ps = _passes_of(out.stderr)
+        if ps:
+            r["MBps_pass"] = ps
+        er = _errors_of(out.stderr)
+        if er is not None:
+            r["producer_errors"] = er
+        return r
     except Exception as e:  # noqa: BLE001 - the bench line must still be printed
         return {"error": repr(e)[:300]}
+
+
+def measured(run, target_s: float = 5.5, min_passes: int = 5, max_loops: int = 400):
+    """A MEASUREMENT, not a maximum (round-2 verdict): one short calibration run (2 loops), then ONE run of enough loops for
+    >= target_s of continuous load and >= min_passes passes, a barrier between the passes; the leg's value is the MEDIAN pass,
+    min / max next to it.  `run(loops)` returns a tool result with MBps_wall (and MBps_pass when loops were timed one by one)."""
+    cal = run(2)
+    if "MBps_wall" not in cal:
+        return cal
+    bytes_per_pass = cal.get("bytes_per_pass") or (cal.get("bytes_per_thread", 0) * cal.get("threads", 1)) or cal.get("bytes", 0)
+    per_pass_s = bytes_per_pass / 1e6 / max(cal["MBps_wall"], 1e-9)
+    loops = int(min(max_loops, max(min_passes, -(-target_s // max(per_pass_s, 1e-6)))))
+    r = run(loops)
+    if "MBps_wall" not in r:
+        return r
+    ps = r.get("MBps_pass") or {"median": r["MBps_wall"], "min": r["MBps_wall"], "max": r["MBps_wall"], "passes": None}
+    r.update({"value": ps["median"], "min": ps["min"], "max": ps["max"], "passes": ps["passes"] or loops,
+              "continuous_load_s": round(loops * bytes_per_pass / 1e6 / max(r["MBps_wall"], 1e-9), 2)})
+    return r
 
 
 def frontbench(sample_file: str, block: int, level: int, threads: int, mode: int, loops: int = 3, seg_mib: int = 4, ext_rep: int = 0,
@@ -182,9 +228,22 @@ def frontbench(sample_file: str, block: int, level: int, threads: int, mode: int
         m = re.search(r": (\d+) -> (\d+) bytes, wall-clock ([0-9.]+) MB/s \(mean of \d+ passes; best ([0-9.]+) MB/s\), (\d+) block\(s\) from announcements, (\d+) per block, (PASS|FAIL)", out.stdout)
         if out.returncode != 0 or not m:
             return {"error": (out.stdout + out.stderr)[-300:]}
-        return {"MBps_wall": float(m.group(3)), "MBps_wall_best_pass": float(m.group(4)), "threads": threads, "bytes": int(m.group(1)),
-                "csize": int(m.group(2)), "blocks_from_announcements": int(m.group(5)), "blocks_per_block_path": int(m.group(6)),
-                "roundtrip": m.group(7), "tool": "qat-zstd-plugin_amd/test/frontbench " + " ".join(cmd[1:-1])}
+        r = {"MBps_wall": float(m.group(3)), "MBps_wall_best_pass": float(m.group(4)), "threads": threads, "bytes": int(m.group(1)),
+             "bytes_per_pass": int(m.group(1)), "loops": loops,
+             "csize": int(m.group(2)), "blocks_from_announcements": int(m.group(5)), "blocks_per_block_path": int(m.group(6)),
+             "roundtrip": m.group(7), "tool": "qat-zstd-plugin_amd/test/frontbench " + " ".join(cmd[1:-1]) +
+             (" env " + " ".join("%s=%s" % kv for kv in env.items()) if env else "")}
+        ps = _passes_of(out.stdout)
+        if ps:
+            ps["passes"] = loops
+            r["MBps_pass"] = ps
+        er = _errors_of(out.stdout)
+        if er is not None:
+            r["producer_errors"] = er
+        g = re.search(r"blocks per GPU \(announced/batched/service\): (.*)", out.stdout)
+        if g:
+            r["blocks_per_gpu_announced_batched_service"] = g.group(1).strip()
+        return r
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
 
@@ -200,18 +259,23 @@ def replaybench(sample_file: str, block: int, level: int, threads: int, loops: i
             return {"error": "replaybench not built"}
         cmd = [exe, "-t%d" % threads, "-l%d" % loops, "-c%d" % block, "-L%d" % level, sample_file]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-        m = re.search(r"(\d+) of (\d+) blocks recorded, csize (\d+), ([0-9.]+) MB/s wall \(best pass ([0-9.]+)\), round trip (PASS|FAIL)", out.stdout)
+        m = re.search(r"(\d+) bytes, (\d+) of (\d+) blocks recorded, csize (\d+), ([0-9.]+) MB/s wall \(best pass ([0-9.]+)\), round trip (PASS|FAIL)", out.stdout)
         if out.returncode != 0 or not m:
             return {"error": (out.stdout + out.stderr)[-300:]}
-        return {"MBps_wall": float(m.group(4)), "MBps_wall_best_pass": float(m.group(5)), "threads": threads, "blocks_recorded": int(m.group(1)),
-                "blocks": int(m.group(2)), "csize": int(m.group(3)), "roundtrip": m.group(6),
-                "tool": "qat-zstd-plugin_amd/test/replaybench " + " ".join(cmd[1:-1])}
+        r = {"MBps_wall": float(m.group(5)), "MBps_wall_best_pass": float(m.group(6)), "threads": threads, "blocks_recorded": int(m.group(2)),
+             "blocks": int(m.group(3)), "csize": int(m.group(4)), "roundtrip": m.group(7), "bytes_per_pass": int(m.group(1)), "loops": loops,
+             "tool": "qat-zstd-plugin_amd/test/replaybench " + " ".join(cmd[1:-1])}
+        ps = _passes_of(out.stdout)
+        if ps:
+            ps["passes"] = loops
+            r["MBps_pass"] = ps
+        return r
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
 
 
 def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, chunk_blocks: int = 512, depth: int = 3,
-                      passes: int = 3):
+                      passes: int = 3, start_barrier=None):
     """Host-pinned -> host-pinned sequence production through the C ABI, nothing resident: the input sits in pinned host
     memory, every chunk of `chunk_blocks` blocks goes H2D on its own stream, is match-found there, and the kernel writes
     counts + sequences straight into pinned host result buffers (posted PCIe writes) — `depth` chunks in flight, so
@@ -274,6 +338,9 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
         run_pass()  # warm-up
         best, errs, seqs = None, 0, 0
         tot = 0.0
+        if start_barrier is not None:
+            start_barrier.wait()  # several GPUs at once: everybody warm, then go
+        t_begin = time.perf_counter()
         for _ in range(passes):
             dt, errs, seqs = run_pass()
             tot += dt
@@ -281,6 +348,7 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
         nbytes = nchunks * cbytes
         return {"GBps_input_per_gpu": round(nbytes * passes / tot / 1e9, 2), "GBps_best_pass": round(nbytes / best / 1e9, 2),
                 "bytes_per_pass": nbytes, "chunk_blocks": chunk_blocks, "chunks_in_flight": depth, "passes": passes,
+                "t_begin": t_begin, "t_end": time.perf_counter(), "device": device,
                 "result_bytes_per_pass": 16 * seqs, "dense_blocks_over_pitch": errs,
                 "what": "pinned host -> H2D -> kernel -> counts + sequences written by the kernel into pinned host memory; "
                         "%d chunks of %d blocks in flight on separate streams" % (depth, chunk_blocks)}
@@ -300,6 +368,66 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
             L.qzstd_hip_host_free(C.c_void_p(h_in))
 
 
+def product_multi_gpu_leg(plug, shard: bytes, block: int, level: int, want_gpus: int):
+    """The product's multi-GPU path in ONE process over the first `want_gpus` gfx950 devices (north star: "the batch shards across
+    the 8 GPUs of one node with per-GPU HIP streams and host-side gather (no RCCL)"; reference analogue: instances interleaved across
+    devices, src/qatseqprod.c:601-630):
+      pcie_pipeline   host-pinned -> host-pinned sequence production on EVERY GPU at the same time (one Python thread per GPU
+                      driving the C ABI), aggregate GB/s of input over the common wall clock;
+      frontend        the batch front-end (ZSTD_compress2, announcements) with QZSTD_HIP_SPLIT = 1 (an announcement stays on its
+                      state's GPU; states are spread round-robin) and = N (every announcement is cut into N block ranges, one per
+                      GPU), blocks per GPU from QZSTD_deviceStats."""
+    import tempfile
+    import threading
+    try:
+        n = min(int(want_gpus), int(plug.lib.qzstd_hip_device_count()))
+        if n < 1:
+            return {"error": "no device"}
+        res = [None] * n
+        bar = threading.Barrier(n)
+
+        def go(d):
+            try:
+                res[d] = pcie_pipeline_leg(plug, shard, block, level, d, passes=2, start_barrier=bar)
+            except Exception as e:  # noqa: BLE001
+                res[d] = {"error": repr(e)[:200]}
+                try:
+                    bar.abort()
+                except Exception:  # noqa: BLE001
+                    pass
+        th = [threading.Thread(target=go, args=(d,)) for d in range(n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        out = {"gpus": n}
+        ok = [r for r in res if r and "GBps_input_per_gpu" in r]
+        if len(ok) == n:
+            span = max(r["t_end"] for r in ok) - min(r["t_begin"] for r in ok)
+            out["pcie_pipeline"] = {"GBps_input_aggregate": round(sum(r["bytes_per_pass"] * r["passes"] for r in ok) / span / 1e9, 2),
+                                    "GBps_input_per_gpu": [r["GBps_input_per_gpu"] for r in ok], "common_wall_s": round(span, 3),
+                                    "what": "pinned host -> H2D -> kernel -> sequences written into pinned host memory, on %d GPU(s) at once" % n}
+        else:
+            out["pcie_pipeline"] = {"error": [r for r in res if not (r and "GBps_input_per_gpu" in r)][:1]}
+        ncpu, quota = host_cpu_budget()
+        base_t = max(1, min(int(quota), 128))
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            f.write(shard[:min(len(shard), 4096 * block)])
+            fbig = f.name
+        build_tools()
+        fe = {}
+        for split in sorted({1, n}):
+            r = frontbench(fbig, block, level, base_t, 1, loops=8, seg_mib=2, env={"QZSTD_HIP_SPLIT": str(split), "QZSTD_HIP_MAX_DEVICES": str(n)})
+            fe["split_%d" % split] = {k: r[k] for k in ("MBps_wall", "MBps_pass", "blocks_from_announcements", "blocks_per_block_path",
+                                                         "blocks_per_gpu_announced_batched_service", "producer_errors", "roundtrip", "error") if k in r}
+        os.unlink(fbig)
+        out["frontend"] = fe
+        out["frontend_threads"] = base_t
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     a = parse()
@@ -315,7 +443,8 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # control plane only (a barrier and a MAX of the elapsed time): gloo — the data path has no collective and no RCCL
+        dist.init_process_group("gloo")
 
     plug = B.Plugin()
     L = plug.lib
@@ -371,7 +500,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    wall = S.reduce_max_seconds(wall, dist if world > 1 else None, dev)
+    wall = S.reduce_max_seconds(wall, dist if world > 1 else None, None)  # gloo: a CPU tensor
     kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(a.steps)]
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
@@ -389,7 +518,8 @@ def main():
             "metric": "input MB/s via ZSTD_compress2 L1 128KiB blocks @1/2/4/8 GPU; ratio vs sw zstd",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(wall / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic batch assembled from real files of the ROCm image (system corpus, tools/qz_corpus.py), repeated to size" if a.corpus == "system" else "synthetic",
             "config": {"workload": "level-%d, %d KiB blocks, %d blocks (%.2f GiB) per GPU, sequence production "
                                    "(qzstd_hip_find_sequences = the kernel behind qatSequenceProducer), inputs resident in HBM"
                                    % (level, block >> 10, nb, size / 2 ** 30),
@@ -457,74 +587,110 @@ def main():
                 f.write(sample)
                 fname = f.name
             base_t = max(1, min(int(quota), 128))
-            # north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape, measured
-            # by the C tool in the same run on the host cores of this box — with the 1.5.x library the producer API needs
-            # and with the system's optimised 1.4.x (the 1.5.7 in this image is a slow build)
-            sw = c_benchmark(fname, block, level, base_t, mode=0, loops=6)
-            sw14 = c_benchmark(fname, block, level, base_t, mode=0, loops=8, tool="benchmark_sw")
+            tgt = a.e2e_seconds
+            # ---- north-star CPU baseline: libzstd's internal match-finder (plugin unregistered), benchmark.c shape, measured by the C
+            # tool in the same run on the host cores of this box — with the 1.5.x library the producer API needs and with the system's
+            # optimised 1.4.x (the 1.5.7 in this image is a slow build).  Every first-class leg below is ONE run of
+            # >= e2e_seconds of continuous load, the value = the median pass (>= 5 passes, barrier between them), min / max next to it.
+            sw = measured(lambda l: c_benchmark(fname, block, level, base_t, mode=0, loops=l, passes=True), tgt)
+            sw14 = measured(lambda l: c_benchmark(fname, block, level, base_t, mode=0, loops=l, tool="benchmark_sw", passes=True), tgt)
             out["cpu_libzstd_1_5"] = sw
             out["cpu_libzstd_1_4"] = sw14
-            best_sw = max([x for x in (sw, sw14) if "MBps_wall" in x], key=lambda x: x["MBps_wall"], default=None)
+            best_sw = max([x for x in (sw, sw14) if "value" in x], key=lambda x: x["value"], default=None)
             if best_sw:
-                out["cpu_baseline"] = {"value": best_sw["MBps_wall"], "unit": "MB/s", "cores": base_t, "kind": "reference",
+                other = sw if best_sw is sw14 else sw14
+                out["cpu_baseline"] = {"value": best_sw["value"], "min": best_sw["min"], "max": best_sw["max"], "unit": "MB/s", "cores": base_t, "kind": "reference",
                                        "sample": "libzstd %s own match-finder, plugin unregistered (the reference's software path, test/benchmark.c -m0 shape): "
-                                                 "%d threads x %d MiB x %d loops, one frame per %d KiB chunk, wall clock; the same with libzstd %s: %s MB/s"
-                                                 % (best_sw["libzstd"], base_t, len(sample) >> 20, best_sw["loops"], block >> 10,
-                                                    (sw if best_sw is sw14 else sw14).get("libzstd"), (sw if best_sw is sw14 else sw14).get("MBps_wall"))}
-            # end to end through ZSTD_compress2 with the plugin registered, thread sweep (wall clock AND sum of rates):
-            #   announced   QZSTD_hintSource 2 MiB ahead (-H2): the GPU match-finds segment k+1 while the thread entropy-codes k
-            #   plain       unchanged callers, library defaults: every block through the coalescer
-            #   lookahead   unchanged callers with the opt-in transparent look-ahead (QZSTD_HIP_LOOKAHEAD=1)
-            sweep = []
-            for t in sorted({base_t, max(base_t + 1, int(1.25 * base_t)), 2 * base_t, min(4 * base_t, 128)}):
-                row = {"threads": t}
-                for name, kw in (("announced", dict(hint=2)), ("plain", {}), ("lookahead", dict(env={"QZSTD_HIP_LOOKAHEAD": "1"}))):
-                    r = c_benchmark(fname, block, level, t, mode=1, loops=6 if t <= base_t else 3, **kw)
-                    row[name] = {k: r.get(k) for k in ("MBps_wall", "MBps_sum_of_thread_rates", "csize", "latency_us_p50", "error") if k in r}
-                    if "csize" in r and "csize" in sw:
-                        row[name]["csize_vs_sw"] = round(r["csize"] / sw["csize"], 4)
-                sweep.append(row)
-            out["e2e_sweep"] = sweep
-            # the batch front-end (include/qzstd_frontend.h): ONE big buffer (half of the batch, 2 MiB segments), a pool of CCtx threads fed
-            # from a shared segment counter, bytes / wall clock of the whole call
+                                                 "%d threads x %d MiB x %d passes (%.1f s of continuous load), one frame per %d KiB chunk, wall clock, median pass; "
+                                                 "the same with libzstd %s: %s MB/s"
+                                                 % (best_sw["libzstd"], base_t, len(sample) >> 20, best_sw["passes"], best_sw["continuous_load_s"], block >> 10,
+                                                    other.get("libzstd"), other.get("value"))}
+
+            def served(r):
+                """a leg only counts as the GPU's when no producer callback fell back to libzstd's own match-finder"""
+                return "value" in r and r.get("producer_errors", {}).get("total", 0) == 0
+
+            def slim(r):
+                keep = ("value", "min", "max", "passes", "continuous_load_s", "MBps_wall", "MBps_sum_of_thread_rates", "threads", "csize", "latency_us_p50",
+                        "latency_us_p99", "producer_errors", "blocks_from_announcements", "blocks_per_block_path", "blocks_per_gpu_announced_batched_service",
+                        "roundtrip", "tool", "error")
+                return {k: r[k] for k in keep if k in r}
+
+            # ---- the first-class end-to-end legs (input MB/s through ZSTD_compress2 with the plugin registered):
+            #   frontend            include/qzstd_frontend.h: one big buffer, a pool of CCtx threads announcing one segment ahead -> value_e2e
+            #   unchanged_callers   library defaults, nothing announced: every block through the resident service (levels 1-2) / the batches
+            #   announced           the benchmark tool with QZSTD_hintSource 2 MiB ahead (-H2)
+            #   e2e_ceiling_replay  the plugin's own sequences replayed by a memcpy-only producer: what ANY external producer can reach here
             with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
                 f.write(shard[:min(len(shard), 4096 * block)])
                 fbig = f.name
-            t_more = max(base_t + 1, int(1.25 * base_t))  # a few more workers than cores: a worker that waits for the GPU frees its core
-            out["frontend"] = {"gpu": frontbench(fbig, block, level, base_t, 1, seg_mib=2),
-                               "gpu_more_threads": frontbench(fbig, block, level, t_more, 1, seg_mib=2),
-                               "software_libzstd_1_5": frontbench(fbig, block, level, base_t, 0, loops=1, seg_mib=2)}
-            # the ceiling: the same caller shape with a producer that costs nothing (the plugin's own sequences, recorded, replayed by
-            # memcpy) — what the host's cores and this libzstd's entropy stage allow ANY external producer; a quarter of the buffer
             with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
                 f.write(shard[:min(len(shard), 2048 * block)])
                 fq = f.name
-            # 8 passes back to back (~0.5 s of continuous load): a run shorter than the cgroup's CPU period would be measured unthrottled
-            out["e2e_ceiling_replay"] = {"threads_%d" % base_t: replaybench(fq, block, level, base_t, loops=8),
-                                         "threads_%d" % t_more: replaybench(fq, block, level, t_more, loops=8),
-                                         "what": "ZSTD_compress2, recorded plugin sequences replayed by a memcpy-only producer: the Amdahl ceiling "
-                                                 "of any external sequence producer on these cores with this libzstd"}
+            front = measured(lambda l: frontbench(fbig, block, level, base_t, 1, loops=l, seg_mib=2), tgt)
+            plain = measured(lambda l: c_benchmark(fname, block, level, base_t, mode=1, loops=l, passes=True), tgt)
+            ann = measured(lambda l: c_benchmark(fname, block, level, base_t, mode=1, hint=2, loops=l, passes=True), tgt)
+            ceil = measured(lambda l: replaybench(fq, block, level, base_t, loops=l), tgt)
+            for r in (front, plain, ann):
+                if "csize" in r and "csize" in sw and r.get("bytes_per_thread", 0) == sw.get("bytes_per_thread", -1):
+                    r["csize_vs_sw"] = round(r["csize"] / sw["csize"], 4)
+            out["frontend"] = {"gpu": slim(front)}
+            out["announced"] = dict(slim(ann), csize_vs_sw=ann.get("csize_vs_sw"))
+            out["e2e_ceiling_replay"] = dict(slim(ceil), what="ZSTD_compress2, recorded plugin sequences replayed by a memcpy-only producer: the Amdahl "
+                                             "ceiling of any external sequence producer on these cores with this libzstd; %d threads, median pass" % base_t)
+            # one thread: what a lone unchanged caller gets (latency-bound: one block at a time)
+            one = {k: c_benchmark(fname, block, level, 1, mode=m, hint=h, loops=2) for k, m, h in (("software", 0, 0), ("plain", 1, 0), ("announced", 1, 2))}
+            uc = dict(slim(plain), csize_vs_sw=plain.get("csize_vs_sw"), served_by_gpu=served(plain),
+                      what="unchanged callers: ZSTD_compress2 per %d KiB chunk, plugin registered, NOTHING announced, library defaults, %d threads, median pass"
+                           % (block >> 10, base_t))
+            if "value" in plain and "value" in ann:
+                uc["vs_announced"] = round(plain["value"] / ann["value"], 3)
+            if "value" in plain and sw.get("value"):
+                uc["vs_cpu_libzstd_1_5"] = round(plain["value"] / sw["value"], 3)
+            if all("MBps_wall" in one[k] for k in one):
+                uc["one_thread"] = {"plain_MBps": one["plain"]["MBps_wall"], "plain_latency_us_p50": one["plain"]["latency_us_p50"],
+                                    "announced_MBps": one["announced"]["MBps_wall"], "software_1_5_MBps": one["software"]["MBps_wall"],
+                                    "plain_vs_software_1_5": round(one["plain"]["MBps_wall"] / max(one["software"]["MBps_wall"], 1e-9), 3),
+                                    "producer_errors": one["plain"].get("producer_errors")}
+            out["unchanged_callers"] = uc
+            if "value" in front:
+                v = front["value"]
+                out["value_e2e"] = {"value": v if served(front) else None, "min": front["min"], "max": front["max"], "passes": front["passes"],
+                                    "continuous_load_s": front["continuous_load_s"], "unit": "MB/s", "served_by_gpu": served(front),
+                                    "producer_errors": front.get("producer_errors"),
+                                    "what": "input MB/s through ZSTD_compress2, plugin registered: the batch front-end (include/qzstd_frontend.h), ONE %d MiB buffer, "
+                                            "%d worker threads (= usable cores), 2 MiB announcements, level %d, %d KiB chunks, libzstd %s; wall clock of "
+                                            "QZSTD_frontCompress, median pass" % (front["bytes"] >> 20, base_t, level, block >> 10, sw.get("libzstd")),
+                                    "how": "ONE named leg (not a maximum over legs): frontend.gpu",
+                                    "vs_cpu_libzstd_1_5": round(v / sw["value"], 3) if sw.get("value") else None,
+                                    "vs_cpu_libzstd_1_4": round(v / sw14["value"], 3) if sw14.get("value") else None,
+                                    "ratio_within_2pct": all(x.get("csize_vs_sw", 1.0) <= 1.02 for x in (plain, ann))}
+                if "value" in ceil:
+                    out["value_e2e"]["frac_of_replay_ceiling"] = round(v / ceil["value"], 3)
+                    if "value" in plain:
+                        out["unchanged_callers"]["frac_of_replay_ceiling"] = round(plain["value"] / ceil["value"], 3)
+            # ---- indicative only (short runs, one value each): more threads than cores, the opt-in look-ahead, software through the front-end
+            t_more = max(base_t + 1, int(1.25 * base_t))
+            sweep = []
+            for t in sorted({t_more, 2 * base_t, min(4 * base_t, 128)}):
+                row = {"threads": t}
+                for name, kw in (("announced", dict(hint=2)), ("plain", {})):
+                    r = c_benchmark(fname, block, level, t, mode=1, loops=4, **kw)
+                    row[name] = {k: r.get(k) for k in ("MBps_wall", "latency_us_p50", "producer_errors", "error") if k in r}
+                sweep.append(row)
+            out["e2e_sweep_indicative"] = {"rows": sweep, "note": "short single runs (about a second each), not medians: how the rates move past usable_cores threads",
+                                           "lookahead_optin_%d_threads" % base_t: slim(c_benchmark(fname, block, level, base_t, mode=1, loops=4, env={"QZSTD_HIP_LOOKAHEAD": "1"})),
+                                           "unchanged_callers_launch_path_%d_threads" % base_t:
+                                               slim(c_benchmark(fname, block, level, base_t, mode=1, loops=4, env={"QZSTD_HIP_SERVICE": "0"})),
+                                           "frontend_%d_threads" % t_more: slim(frontbench(fbig, block, level, t_more, 1, loops=3, seg_mib=2)),
+                                           "frontend_software_libzstd_1_5": slim(frontbench(fbig, block, level, base_t, 0, loops=1, seg_mib=2))}
             os.unlink(fq)
             os.unlink(fbig)
-            cands = [(row[n]["MBps_wall"], row["threads"], n) for row in sweep for n in ("announced", "plain", "lookahead") if row[n].get("MBps_wall")]
-            cands += [(r["MBps_wall"], r["threads"], "batch front-end") for r in out["frontend"].values()
-                      if r.get("MBps_wall") and r.get("blocks_from_announcements")]  # the software run of the front-end serves no block from the GPU
-            if cands:
-                v, t, n = max(cands)
-                out["value_e2e"] = {"value": v, "unit": "MB/s", "what": "input MB/s through ZSTD_compress2, plugin registered (%s callers), %d threads, "
-                                    "wall clock of the compression phase, level %d, %d KiB chunks, libzstd %s" % (n, t, level, block >> 10, sw.get("libzstd")),
-                                    "vs_cpu_libzstd_1_5": round(v / sw["MBps_wall"], 3) if sw.get("MBps_wall") else None,
-                                    "vs_cpu_libzstd_1_4": round(v / sw14["MBps_wall"], 3) if sw14.get("MBps_wall") else None,
-                                    "ratio_within_2pct": all(row[n2].get("csize_vs_sw", 1.0) <= 1.02 for row in sweep for n2 in ("announced", "plain")),
-                                    "how": "best of e2e_sweep (C benchmark tool, one buffer per thread) and frontend (one shared buffer, include/qzstd_frontend.h)"}
-                ceil = max([r.get("MBps_wall", 0.0) for r in out["e2e_ceiling_replay"].values() if isinstance(r, dict)] + [0.0])
-                if ceil:
-                    out["value_e2e"]["frac_of_replay_ceiling"] = round(v / ceil, 3)
             # ... the announced path with ZSTD_c_searchForExternalRepcodes on (-E1) and the repeat-offset aware parse
             rep = c_benchmark(fname, block, level, base_t, mode=1, hint=16, ext_rep=1, loops=4, env={"QZSTD_HIP_EXT_REPCODES": "1"})
-            if "csize" in rep and "csize" in sw:
+            if "csize" in rep and "csize" in sw and rep.get("bytes_per_thread") == sw.get("bytes_per_thread"):
                 rep["csize_vs_sw"] = round(rep["csize"] / sw["csize"], 4)
-            out["e2e_announced_repcodes"] = rep
+            out["e2e_announced_repcodes"] = slim(rep) | {"csize_vs_sw": rep.get("csize_vs_sw")}
             # BASELINE config 3's level on the same framing, libzstd defaults (no -E1): software level 6 vs the plugin
             # (exact hash chains), a quarter of the sample; and config 4's: level 12 on 32 KiB chunks
             if level == 1:
@@ -535,26 +701,35 @@ def main():
                     swl = c_benchmark(f6, blk, lv, base_t, mode=0, loops=1)
                     sw14l = c_benchmark(f6, blk, lv, base_t, mode=0, loops=2, tool="benchmark_sw")
                     pl = c_benchmark(f6, blk, lv, base_t, mode=1, hint=8, loops=2)
+                    pp = c_benchmark(f6, blk, lv, base_t, mode=1, loops=2)
                     if "csize" in pl and "csize" in swl:
                         pl["csize_vs_sw"] = round(pl["csize"] / swl["csize"], 4)
                         pl["ratio_within_2pct"] = pl["csize"] <= swl["csize"] * 1.02
                         pl["speedup_vs_libzstd_1_5"] = round(pl["MBps_wall"] / max(swl["MBps_wall"], 1e-9), 2)
                         if "MBps_wall" in sw14l:
                             pl["speedup_vs_libzstd_1_4"] = round(pl["MBps_wall"] / max(sw14l["MBps_wall"], 1e-9), 2)
-                    out[key] = {"cpu_libzstd_1_5": swl, "cpu_libzstd_1_4": sw14l, "e2e_announced": pl}
+                    out[key] = {"cpu_libzstd_1_5": slim(swl), "cpu_libzstd_1_4": slim(sw14l), "e2e_announced": slim(pl) | {k: pl.get(k) for k in ("csize_vs_sw", "ratio_within_2pct", "speedup_vs_libzstd_1_5", "speedup_vs_libzstd_1_4")},
+                                "unchanged_callers": slim(pp)}
                 # BASELINE config 5's shape: 4 MiB frames (32 producer calls per frame), level 3, ZSTD_c_blockSplitterLevel = 1 so that
                 # libzstd keeps the blocks of a frame at 128 KiB (its 1.5.7 pre-splitter otherwise cuts them at arbitrary offsets)
                 sw5 = c_benchmark(fname, 4 << 20, 3, base_t, mode=0, loops=2, split=1)
                 p5 = c_benchmark(fname, 4 << 20, 3, base_t, mode=1, hint=4, loops=3, split=1)
+                x5 = {}
                 if "csize" in p5 and "csize" in sw5:
-                    p5["csize_vs_sw"] = round(p5["csize"] / sw5["csize"], 4)
-                    p5["speedup_vs_libzstd_1_5"] = round(p5["MBps_wall"] / max(sw5["MBps_wall"], 1e-9), 2)
-                    p5["note"] = "software matches across the whole 4 MiB frame, the producer contract parses every 128 KiB block without history"
-                out["config5_shape_4MiB_frames_L3"] = {"cpu_libzstd_1_5": sw5, "e2e_announced": p5}
+                    x5 = {"csize_vs_sw": round(p5["csize"] / sw5["csize"], 4), "speedup_vs_libzstd_1_5": round(p5["MBps_wall"] / max(sw5["MBps_wall"], 1e-9), 2),
+                          "note": "the one BASELINE config where the north star's 2 % does not hold, by construction: software matches across the whole 4 MiB "
+                                  "frame, the producer contract parses every 128 KiB block without history (src/qatseqprod.h:103-105)"}
+                out["config5_shape_4MiB_frames_L3"] = {"cpu_libzstd_1_5": slim(sw5), "e2e_announced": slim(p5) | x5}
                 os.unlink(f6)
             os.unlink(fname)
+        if not a.no_cpu:
+            # ---- the product's multi-GPU path (rank 0, after the timed region; the other ranks wait at the barrier below): ONE process,
+            # every visible gfx950 device — the announcement split of QZSTD_hintSource (contiguous block ranges, one per GPU, per-GPU streams,
+            # results gathered in the announcement's pinned host buffers) and the PCIe-inclusive pipeline on every GPU at once
+            out["product_multi_gpu"] = product_multi_gpu_leg(plug, shard, block, level, max(world, 1))
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0's product leg uses every GPU: the others keep still until it is done
         dist.destroy_process_group()
 
 

@@ -141,6 +141,12 @@ void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4]);
  *   (served, not errors);  stats[7] = blocks served by the resident service (a subset of QZSTD_hintStats' [1]). */
 void QZSTD_failStats(void *sequenceProducerState, unsigned long stats[8]);
 
+/* Process-wide, per GPU (the blocks shard across the GPUs of a node with no exchange step; reference analogue: instances
+ * interleaved across devices, src/qatseqprod.c:601-630): stats[0] = blocks queued on that GPU from announcements (an
+ * announcement is cut into contiguous ranges, one per GPU), [1] = blocks that went through its batches, [2] = blocks served by
+ * its resident service, [3] = 0, since QZSTD_startQatDevice().  Returns the number of GPUs in use (stats may be NULL). */
+int QZSTD_deviceStats(int device, unsigned long stats[4]);
+
 #if defined(__cplusplus)
 }
 #endif

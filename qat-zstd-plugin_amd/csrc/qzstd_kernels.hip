@@ -1899,6 +1899,19 @@ int svc_launch_locked(int device, Service &s, int level)
         }
         s.hs = static_cast<SvcHost *>(h);
         s.dv = static_cast<SvcDev *>(d);
+        /* a process that ends without QZSTD_stopQatDevice() must not leave kernels polling memory that is about to go:
+         * registered after the HIP runtime's own handlers, so it runs before them */
+        static std::once_flag once;
+        std::call_once(once, [] {
+            atexit([] {
+                for (int dvc = 0; dvc < 64; dvc++) {
+                    Service &sv = g_svc[dvc];
+                    if (!sv.hs) continue;
+                    std::lock_guard<std::mutex> g(sv.mu);
+                    (void)svc_stop_locked(sv, 500);
+                }
+            });
+        });
     }
     /* per-function attribute, once per variant and device would do; cheap enough to repeat on the (rare) launches */
     QZ_CHECK(hipFuncSetAttribute(worker, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(service worker)");

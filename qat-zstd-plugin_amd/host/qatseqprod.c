@@ -177,10 +177,11 @@ typedef struct {
     int service;             /* QZSTD_HIP_SERVICE (default 1): per-block requests go to the resident service where it serves the level */
     int svcItemBytes;        /* QZSTD_HIP_SERVICE_ITEM (default 4096): bytes per work item of a service request (whole segments) */
     int svcSpinUs;           /* QZSTD_HIP_SERVICE_SPIN_US (default 400): busy polling of the count words before napping */
+    unsigned long devBlocks[QZ_MAX_DEVICES][3]; /* per GPU: blocks queued from announcements, blocks through batches, blocks through the service */
     pthread_mutex_t mutex;
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, PTHREAD_MUTEX_INITIALIZER };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
  * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
@@ -562,6 +563,7 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
     c->launches += (unsigned long)launches;
     c->batches++;
     c->blocks += (unsigned long)n;
+    __atomic_fetch_add(&gProc.devBlocks[dev][1], (unsigned long)n, __ATOMIC_RELAXED);
 }
 
 static size_t qzSlotBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
@@ -703,6 +705,7 @@ static int qzBuildSlots(void)
     if (!gProc.slots) return QZSTD_FAIL;
     gProc.numDevices = nDev;
     gProc.numSlots = nDev * perDev;
+    memset(gProc.devBlocks, 0, sizeof(gProc.devBlocks));
     for (i = 0; i < gProc.numSlots; i++) gProc.slots[i].device = i % nDev;
     gProc.coalesce = qzEnvInt("QZSTD_HIP_COALESCE", 1, 0, 1);
     gProc.split = qzEnvInt("QZSTD_HIP_SPLIT", nDev < QZ_HINT_PARTS ? nDev : QZ_HINT_PARTS, 1, nDev < QZ_HINT_PARTS ? nDev : QZ_HINT_PARTS);
@@ -1119,6 +1122,7 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
         }
     }
     s->servedService++;
+    __atomic_fetch_add(&gProc.devBlocks[sl->device][2], 1ul, __ATOMIC_RELAXED);
     return out;
 }
 
@@ -1352,6 +1356,15 @@ static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need)
     return p;
 }
 
+int QZSTD_deviceStats(int device, unsigned long stats[4])
+{
+    int k;
+    if (stats) for (k = 0; k < 4; k++) stats[k] = 0;
+    if (stats && device >= 0 && device < gProc.numDevices && device < QZ_MAX_DEVICES)
+        for (k = 0; k < 3; k++) stats[k] = __atomic_load_n(&gProc.devBlocks[device][k], __ATOMIC_RELAXED);
+    return gProc.numDevices;
+}
+
 void QZSTD_failStats(void *sequenceProducerState, unsigned long stats[8])
 {
     const QZSTD_Session_T *s = (const QZSTD_Session_T *)sequenceProducerState;
@@ -1500,6 +1513,7 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
         if (qzWait(sl->device, sl->stream) == 1) sl->stuck = 1;
         goto fail;
     }
+    __atomic_fetch_add(&gProc.devBlocks[sl->device][0], (unsigned long)(b1 - b0), __ATOMIC_RELAXED);
     pt->st = 1; /* in flight; the slot stays ours until qzPartFinish() */
     pt->slot = i;
     pt->b0 = b0;

@@ -99,6 +99,16 @@ int main(int argc, char **argv)
     for (unsigned i = 1; i < nr; i++) /* insertion sort: median / min / max of the passes */
         for (unsigned j = i; j > 0 && rate[j - 1] > rate[j]; j--) { const double x = rate[j]; rate[j] = rate[j - 1]; rate[j - 1] = x; }
     QZSTD_freeFront(f);
+    char perGpu[1024] = "";
+    if (p.useProducer) { /* who did the work: blocks per GPU (announcement ranges / batches / resident service) */
+        const int nd = QZSTD_deviceStats(0, NULL);
+        size_t o = 0;
+        for (int d = 0; d < nd && o + 64 < sizeof perGpu; d++) {
+            unsigned long ds[4];
+            (void)QZSTD_deviceStats(d, ds);
+            o += (size_t)snprintf(perGpu + o, sizeof perGpu - o, "%sgpu%d %lu/%lu/%lu", d ? ", " : "", d, ds[0], ds[1], ds[2]);
+        }
+    }
     if (p.useProducer) QZSTD_stopQatDevice();
     printf("frontbench libzstd %s mode %d level %d chunk %zu threads %d segment %zu: %zu -> %zu bytes, wall-clock %.1f MB/s "
            "(mean of %u passes; best %.1f MB/s), %lu block(s) from announcements, %lu per block, %s\n",
@@ -106,6 +116,7 @@ int main(int argc, char **argv)
            sum > 0 ? (double)n * loops / 1e6 / sum : 0.0, loops, best > 0 ? (double)n / 1e6 / best : 0.0, st[0], st[1],
            ok ? "PASS" : "FAIL");
     if (nr) printf("passes MB/s: median %.1f min %.1f max %.1f\n", nr & 1 ? rate[nr / 2] : 0.5 * (rate[nr / 2 - 1] + rate[nr / 2]), rate[0], rate[nr - 1]);
+    if (p.useProducer) printf("blocks per GPU (announced/batched/service): %s\n", perGpu);
     printf("producer errors: %lu (guards %lu, device down %lu, time-outs %lu, capacity %lu, runtime %lu) - blocks compressed by libzstd's "
            "own match-finder instead; dense blocks redone alone: %lu\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], fl[6]);
     free(src); free(dst); free(sizes); free(back);

@@ -619,3 +619,32 @@ def test_timed_out_announcement_parks_its_buffers(mock, zstd, oracle):
         got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 3)
         L.QZSTD_freeSeqProdState(st)
         assert got == oracle_frames(zstd, oracle, data, chunk, 3)
+
+
+def test_multi_gpu_product_leg_over_four_mock_devices(mock, zstd, tmp_path):
+    """bench.py's product_multi_gpu leg on CPU: test/frontbench.c over the mock with four "GPUs" — QZSTD_HIP_SPLIT=4 cuts every
+    announcement into four block ranges (every GPU gets a share), QZSTD_HIP_SPLIT=1 keeps an announcement on its state's GPU (the
+    states are spread round-robin); blocks per GPU from QZSTD_deviceStats, frames round-trip, no producer errors"""
+    import re
+    front_so = os.path.join(ROOT, "tests", "mock", "libqzstdfront_mock.so")
+    subprocess.check_call(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-shared", "-fPIC", "-pthread",
+                           "-I" + os.path.join(ROOT, "include"), "-o", front_so, os.path.join(B.PKG_DIR, "frontend", "qzstd_frontend.c"),
+                           MOCK_SO, zstd.path, "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)])
+    exe = str(tmp_path / "frontbench")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(B.PKG_DIR, "test", "frontbench.c"), front_so, MOCK_SO, zstd.path,
+                           "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path), "-lpthread"])
+    f = tmp_path / "in.bin"
+    f.write_bytes(K.by_name("system", 64 * 65536, seed=4))
+    for split in (4, 1):
+        out = subprocess.run([exe, "-t4", "-l1", "-c65536", "-L3", "-s1", "-m1", str(f)], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, QZSTD_MOCK_DEVICES="4", QZSTD_HIP_SPLIT=str(split)))
+        assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
+        assert "producer errors: 0 " in out.stdout, out.stdout
+        per = re.search(r"blocks per GPU \(announced/batched/service\): (.*)", out.stdout).group(1)
+        counts = [int(x.split()[1].split("/")[0]) for x in per.split(",")]
+        assert len(counts) == 4 and sum(counts) == 2 * 64, per  # two passes (one warms up) of 64 blocks, all announced
+        if split == 4:
+            assert all(c == 32 for c in counts), per  # every announcement of 16 blocks: four blocks per GPU
+        else:
+            assert all(c > 0 for c in counts), per    # whole announcements per GPU, four states round-robin
