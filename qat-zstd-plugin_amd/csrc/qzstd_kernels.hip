@@ -1450,35 +1450,52 @@ __global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcD
 }
 
 /* Does the LDS hand the lanes of ONE ds_max_rtn instruction that hit the same address their values in lane order?  Every
- * lane inserts an increasing value into the slot a pattern gives it and must get back the value of the nearest lower
- * lane with the same slot (0 if none); several patterns, among them "all lanes one slot" and runs. */
-__global__ void qzstd_probe_lds_order(uint32_t *bad)
+ * lane of wave 0 inserts an increasing value into the slot a pattern gives it and must get back the value of the nearest lower
+ * lane with the same slot (0 if none); several patterns, among them "all lanes one slot" and runs.  The probe runs under the
+ * contention the kernel has (round-2 verdict): a workgroup of nine waves, the other eight hammering the same LDS — returning
+ * and plain atomics, reads and writes on neighbouring words, bank conflicts included — while wave 0 is measured. */
+__global__ __launch_bounds__(kThreads) void qzstd_probe_lds_order(uint32_t *bad)
 {
     __shared__ uint32_t slots[64];
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint32_t noise[4096];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t wrong = 0;
+    for (uint32_t i = tid; i < 4096u; i += kThreads) noise[i] = 0u;
     for (uint32_t round = 0; round < 64u; round++) {
-        slots[lane] = 0u;
+        if (wave == 0u) slots[lane] = 0u;
         __syncthreads();
-        uint32_t slot;
-        switch (round & 7u) {
-        case 0: slot = 0u; break;
-        case 1: slot = lane & 1u; break;
-        case 2: slot = lane >> 3; break;
-        case 3: slot = lane % 7u; break;
-        case 4: slot = (lane * 2654435761u + round) >> 28; break;
-        case 5: slot = (lane * 0x85EBCA77u + round) >> 26; break;
-        case 6: slot = lane < 32u ? 5u : lane & 3u; break;
-        default: slot = (lane ^ (lane >> 2)) & 31u; break;
+        if (wave == 0u) {
+            uint32_t slot;
+            switch (round & 7u) {
+            case 0: slot = 0u; break;
+            case 1: slot = lane & 1u; break;
+            case 2: slot = lane >> 3; break;
+            case 3: slot = lane % 7u; break;
+            case 4: slot = (lane * 2654435761u + round) >> 28; break;
+            case 5: slot = (lane * 0x85EBCA77u + round) >> 26; break;
+            case 6: slot = lane < 32u ? 5u : lane & 3u; break;
+            default: slot = (lane ^ (lane >> 2)) & 31u; break;
+            }
+            const uint32_t mine = (round << 8) + lane + 1u;
+            const uint32_t got = atomicMax(&slots[slot], mine);
+            uint32_t want = 0u;
+            for (uint32_t l = 0; l < 64u; l++) {
+                const uint32_t sl = (uint32_t)__shfl((int)slot, (int)l);
+                if (l < lane && sl == slot) want = (round << 8) + l + 1u;
+            }
+            if (got != want) wrong++;
+        } else {
+            /* the other eight waves: what the matcher waves do to the LDS while the insert wave works */
+            uint32_t acc = 0u;
+            for (uint32_t k = 0; k < 24u; k++) {
+                const uint32_t a = (tid * 2654435761u + k * 40503u + round * 977u) >> 20; /* 0 .. 4095 */
+                acc += atomicMax(&noise[a], tid + k);
+                atomicMin(&noise[(a * 33u + 7u) & 4095u], acc);
+                acc ^= noise[(a + 64u * k) & 4095u];
+                noise[(a ^ 1u) & 4095u] = acc;
+            }
+            if (acc == 0xDEADBEEFu) wrong += 0u * acc; /* keep the traffic */
         }
-        const uint32_t mine = (round << 8) + lane + 1u;
-        const uint32_t got = atomicMax(&slots[slot], mine);
-        uint32_t want = 0u;
-        for (uint32_t l = 0; l < 64u; l++) {
-            const uint32_t sl = (uint32_t)__shfl((int)slot, (int)l);
-            if (l < lane && sl == slot) want = (round << 8) + l + 1u;
-        }
-        if (got != want) wrong++;
         __syncthreads();
     }
     if (wrong) atomicAdd(bad, wrong);
@@ -1592,7 +1609,7 @@ static int probe_lds_order(int device, int physDev)
     uint32_t *dBad = nullptr, hBad = 1u;
     if (!(force && atoi(force) == 0) && hipSetDevice(physDev) == hipSuccess && hipMalloc(&dBad, sizeof(uint32_t)) == hipSuccess) {
         if (hipMemset(dBad, 0, sizeof(uint32_t)) == hipSuccess) {
-            hipLaunchKernelGGL(qzstd_probe_lds_order, dim3(64), dim3(64), 0, 0, dBad);
+            hipLaunchKernelGGL(qzstd_probe_lds_order, dim3(512), dim3(kThreads), 0, 0, dBad); /* two workgroups per CU, nine waves each */
             if (hipGetLastError() == hipSuccess && hipMemcpy(&hBad, dBad, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess)
                 verdict = hBad == 0u;
         }

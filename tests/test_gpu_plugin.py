@@ -146,7 +146,8 @@ def test_one_shot_multiblock_frame(started, zstd):
 
 @pytest.mark.parametrize("level,chunk,corpus,size", [(1, 131072, "system", 64 * 131072), (3, 131072, "system", 64 * 131072),
                                                      (6, 131072, "system", 48 * 131072), (6, 131072, "text", 32 * 131072),
-                                                     (9, 131072, "system", 24 * 131072),
+                                                     (8, 131072, "system", 24 * 131072), (9, 131072, "system", 24 * 131072),
+                                                     (11, 131072, "system", 24 * 131072),
                                                      (12, 32768, "weblog", 96 * 32768), (12, 32768, "system", 96 * 32768)])
 def test_ratio_within_2pct_of_software(started, zstd, level, chunk, corpus, size):
     """north star: compressed size within 2 % of libzstd's own match-finder at the same level, same framing (one frame
