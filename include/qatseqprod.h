@@ -137,8 +137,8 @@ void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4]);
  * reference counts one cause only: failOffloadCnt, src/qatseqprod.c:122,:1141):
  *   stats[0] all of them = [1] argument guards (window, dictionary, level; reference :1123-1137) + [2] device not started
  *   + [3] time-outs (QZSTD_HIP_TIMEOUT_MS) + [4] capacity rule (count >= capacity - 1, reference :1318) + [5] runtime errors
- *   (allocation, launch, no free slot);  stats[6] = blocks too dense for a batch's result area that were redone alone
- *   (served, not errors);  stats[7] = blocks served by the resident service (a subset of QZSTD_hintStats' [1]). */
+ *   (allocation, launch, no free slot);  stats[6] = blocks served at the second attempt (too dense for a batch's result area and
+ *   redone alone, or redone through the batches after a request to the resident service timed out: served, not errors);  stats[7] = blocks served by the resident service (a subset of QZSTD_hintStats' [1]). */
 void QZSTD_failStats(void *sequenceProducerState, unsigned long stats[8]);
 
 /* Process-wide, per GPU (the blocks shard across the GPUs of a node with no exchange step; reference analogue: instances

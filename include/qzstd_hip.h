@@ -154,7 +154,8 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
  *
  * Resident kernels (one worker workgroup per CU + a one-wave dispatcher) are launched by the first request and leave
  * after QZSTD_HIP_SERVICE_IDLE_US (default 20000) without work, when memory is freed, or on qzstd_hip_service_stop().
- * Served: the levels whose workgroups leave half of a CU's LDS free (1, 2 and their | QZSTD_HIP_LEVEL_REPCODES forms).
+ * Served: every level; the workers serve ONE level (profile) at a time — a request of another level is handed back while they are
+ * resident — and leave when a launch needs the LDS they hold (levels 3-4 fill a CU).
  *
  *   qzstd_hip_service_submit   0 = queued;  1 = not served (level, QZSTD_HIP_SERVICE=0, another level is resident, the
  *                              service is down): the caller takes the launch path;  < 0 = error
@@ -170,7 +171,10 @@ typedef struct {
     uint32_t srcLen, itemBytes, nItems, seqCapPerItem;
     uint32_t slot;      /* < QZSTD_HIP_SVC_MAX_SLOTS: one request in flight per slot (its slices' flags) */
     uint32_t epoch;     /* 1 .. 0xFFFFFF, different from the slot's previous request */
+    void *dWork;        /* chain levels (>= 5): device scratch, nItems x QZSTD_HIP_SVC_WORK_BYTES (every item links the block before it
+                         * there); NULL at the other levels */
 } qzstd_hip_svc_req_t;
+#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 16u)
 int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *req);
 int qzstd_hip_service_stop(int device);          /* asks the resident kernels to leave and waits for them; 0 = stopped */
 void qzstd_hip_service_mark_broken(int device);  /* a request timed out: stop and do not use the service again */

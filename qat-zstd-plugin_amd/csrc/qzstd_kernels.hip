@@ -60,6 +60,11 @@ namespace {
 constexpr int kMatchWaves = 8;
 constexpr int kMatchThreads = kMatchWaves * 64; /* one position per matcher thread per tile */
 constexpr int kThreads = kMatchThreads + 64;     /* + 1 parse wave */
+#ifndef QZ_RING
+#define QZ_RING 32768u /* bytes of the LDS ring (csrc/qzstd_profile.c: QZ_RING_BYTES must agree).  32 KiB: two workgroups per CU at
+                        * levels 1-2 and 5-12.  Measured A/B (bit-exact either way): 16 KiB = three per CU buys nothing at level 1 (12.32 vs 11.96 ms per
+                        * GiB: the CU is VALU-bound, not latency-bound) and costs 13 % at the chain levels (more sources beyond the ring's reach) */
+#endif
 constexpr uint32_t kTileLog = 9;                 /* tile = 512 positions = kMatchThreads */
 constexpr uint32_t kTile = 1u << kTileLog;
 constexpr uint32_t kWin = kTile >> 6;            /* 64-position windows per tile (one per matcher wave) */
@@ -73,10 +78,12 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
  * so that a 36-byte read never has to wrap.  At iteration `it` the ring holds
  * [it*512 + 512 + kLook - kRing, it*512 + 512 + kLook); sources farther back than kNear bytes
  * ("far" candidates, a few %) are compared straight from HBM/L2 instead. */
-constexpr uint32_t kRing = 49152u;
+constexpr uint32_t kRing = QZ_RING;  /* a power of two: x mod kRing is one AND */
+constexpr uint32_t kRingMask = kRing - 1u;
 constexpr uint32_t kMirror = 128u;
 constexpr uint32_t kLook = 4608u;  /* bytes staged ahead of the current tile (covers the bounded extension) */
-constexpr uint32_t kNear = 40960u; /* kRing - kLook - 3 tiles of pipeline lag - slack */
+constexpr uint32_t kNear = kRing - kLook - 3u * kTile - 1024u; /* kRing - kLook - 3 tiles of pipeline lag - slack */
+static_assert((kRing & kRingMask) == 0u && kRing >= 16384u, "the ring is a power of two of at least 16 KiB");
 constexpr uint32_t kLdsBase = 16u; /* first LDS byte the kernel uses (csrc/qzstd_profile.c: QZ_LDS_CTRL covers it) */
 
 struct LaunchArgs {
@@ -125,13 +132,12 @@ struct Src {
 /* dword index inside the ring of byte position a (a < 3 * kRing) */
 __device__ __forceinline__ uint32_t ring_dw(uint32_t a)
 {
-    const uint32_t m = umin(a, a - kRing);
-    return umin(m, m - kRing) >> 2;
+    return (a & kRingMask) >> 2;
 }
 
 /* ring offsets kept incrementally (the matchers' hot path): x mod kRing moved by d < kRing, one add + one min */
-__device__ __forceinline__ uint32_t ring_fwd(uint32_t r, uint32_t d) { const uint32_t t = r + d; return umin(t, t - kRing); }
-__device__ __forceinline__ uint32_t ring_back(uint32_t r, uint32_t d) { const uint32_t t = r - d; return umin(t, t + kRing); }
+__device__ __forceinline__ uint32_t ring_fwd(uint32_t r, uint32_t d) { return (r + d) & kRingMask; }
+__device__ __forceinline__ uint32_t ring_back(uint32_t r, uint32_t d) { return (r - d) & kRingMask; }
 
 /* the same with the ring offset r of position a already known */
 template <int N>
@@ -447,8 +453,7 @@ constexpr uint32_t kChosenBit = 0x80000000u; /* marks a parse-word slot rewritte
 __device__ __forceinline__ uint32_t ring_byte(const Src &s, uint32_t x, bool far)
 {
     if (far) return reinterpret_cast<const __attribute__((address_space(1))) uint8_t *>(s.g)[x];
-    const uint32_t m = umin(x, x - kRing);
-    return reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(s.ring)[umin(m, m - kRing)];
+    return reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(s.ring)[x & kRingMask];
 }
 
 /* equality bitmap of the 64 bytes from `cur` against the bytes `rp` back (0 when rp == 0): bit b = byte cur+b matches.
@@ -465,8 +470,7 @@ __device__ __forceinline__ u64 rep_bitmap(const Src &src, uint32_t cur, uint32_t
 /* scalar x mod kRing for x < 3 * kRing (kept in SGPRs by the parse wave) */
 __device__ __forceinline__ uint32_t ring_off_s(uint32_t a)
 {
-    const uint32_t m = umin(a, a - kRing);
-    return umin(m, m - kRing);
+    return a & kRingMask;
 }
 
 /* parse from the cursor up to `limit` (a window boundary inside the tile that starts at `base`): one window
@@ -502,7 +506,7 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
         if (st.rep1 <= kNear && st.rep2 <= kNear) { /* the usual case: both sources inside the ring */
             /* 64 bytes from each of the three ring offsets: what runs over the ring's end is in the mirror (kMirror >= 64) */
             const uint32_t t1 = rc - st.rep1, t2 = rc - st.rep2; /* offsets never reach before the block */
-            const uint32_t r1 = umin(t1, t1 + kRing), r2 = umin(t2, t2 + kRing);
+            const uint32_t r1 = t1 & kRingMask, r2 = t2 & kRingMask;
             const uint32_t A = rb[rc + lane], B1 = rb[r1 + lane], B2 = rb[r2 + lane]; /* three byte loads, one wait */
             const u64 in = below(segEnd - st.cur); /* a repeat match never leaves its segment either */
             M1 = st.rep1 ? __ballot(A == B1) & in : 0ull;
@@ -641,6 +645,36 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
  * parse, CHAIN (levels >= 5) the walk along the main table's predecessor chain in device memory, TURNS (level 2 and
  * levels >= 5) the per-wave ordered table updates.
  */
+/* One window (64 positions, lane = position) of ORDERED inserts into the head table of the chain levels: returns every lane's
+ * predecessor entry in its slot — the nearest lower lane of the same slot in this window, else what the slot held before (0 =
+ * none).  `ordered`: this device's LDS serves same-address lanes of one returning ds_max in lane order (probed); otherwise the
+ * same-slot lanes are ordered with ballots.  st = slot | tag << 16, or kNone for a position that takes no part. */
+__device__ __forceinline__ uint32_t chain_insert_window(uint32_t *tbl, uint32_t st, uint32_t mine, uint32_t lane, bool ordered)
+{
+    const bool vk = st != kNone;
+    const uint32_t slotK = st & 0xFFFFu;
+    if (ordered) return vk ? atomicMax(&tbl[slotK], mine) : 0u;
+    uint32_t prd = 0u, fin = mine;
+    if (vk) {
+        uint32_t *e = &tbl[slotK];
+        prd = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        atomicMax(e, mine);
+        fin = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    u64 rem = __ballot(fin != mine); /* lanes that are not the newest of their slot in this window have a same-slot lane above them */
+    uint32_t predLane = lane;
+    while (rem) {
+        const uint32_t s0 = rdlane(slotK, (uint32_t)__builtin_ctzll(rem));
+        const bool in = vk && slotK == s0;
+        const u64 grp = __ballot(in);
+        const u64 lower = grp & below(lane);
+        if (in && lower) predLane = 63u - (uint32_t)__builtin_clzll(lower);
+        rem &= ~grp;
+    }
+    const uint32_t fromLane = (uint32_t)__shfl((int)mine, (int)predLane);
+    return vk ? (predLane != lane ? fromLane : prd) : 0u;
+}
+
 /* One work item (a block, or a run of whole segments of one): `blk` describes it, gsrc = the block's bytes in device memory,
  * out = the item's result region, chainB = its chain entries (CHAIN).  Returns, in the parse wave, the item's sequence
  * count including the delimiter or QZSTD_HIP_NSEQ_ERROR (every thread returns that for an item that is refused); the matcher
@@ -697,7 +731,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
      * and nothing else (levels 1-4: ds_max, no chains to link), the order of those inserts does not matter: all 576 threads
      * hash them straight from HBM, no ring, no barriers, and the tile loop starts at the segment's first tile — the state it
      * finds (tables, ring) is exactly what iterating over the history tiles would have left.  itBegin = that first tile. */
-    const uint32_t itBegin = CHAIN ? 0u : firstTile;
+    const uint32_t itBegin = firstTile;
     /* One pass over [0, hi) does both jobs, 16 bytes per thread and step, the loads running two steps ahead of their use (a
      * segment item spends most of its start-up here: 120 KiB of history in front of the last item of a block):
      *   - chunks below histEnd (= parseFrom: a segment boundary, so every position before it hashes bytes before it) are
@@ -712,26 +746,83 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     constexpr uint32_t kStep = (uint32_t)kThreads * 16u;
     uint32_t fo = (itBegin ? 0u : lo) + tid * 16u;
     uint4 fa0 = make_uint4(0u, 0u, 0u, 0u), fb0 = fa0, fa1 = fa0, fb1 = fa0;
-    if (fo < hi) { fa0 = g128[fo >> 4]; if (fo < histEnd) fb0 = g128[(fo >> 4) + 1u]; }
-    if (fo + kStep < hi) { fa1 = g128[(fo + kStep) >> 4]; if (fo + kStep < histEnd) fb1 = g128[((fo + kStep) >> 4) + 1u]; }
-    {
-        for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
+    const uint32_t hashEnd = CHAIN ? 0u : histEnd; /* the chain levels link their history in a pass of its own (below) */
+    if (fo < hi) { fa0 = g128[fo >> 4]; if (fo < hashEnd) fb0 = g128[(fo >> 4) + 1u]; }
+    if (fo + kStep < hi) { fa1 = g128[(fo + kStep) >> 4]; if (fo + kStep < hashEnd) fb1 = g128[((fo + kStep) >> 4) + 1u]; }
+    for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
+    if (!(CHAIN && itBegin != 0u)) { /* (the chain levels' history pass borrows these words first) */
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
         for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
     }
     if (itBegin != 0u) __syncthreads(); /* the cleared tables, before the first insert */
+    if (CHAIN && itBegin != 0u) {
+        /* Chain levels, segment item: the history [0, parseFrom) has to be INSERTED AND LINKED, exactly (every position's
+         * predecessor in its slot), but not walked.  Going through the tile loop for that costs one exposed HBM round trip per tile
+         * (the predecessor's entry): 5.5 us x 240 tiles in front of a block's last item.  Instead:
+         *   pass 1  groups of 2048 positions: 512 threads hash four positions each straight from device memory (slot | tag into
+         *           LDS words that are dead until the tile loop), then ONE wave inserts the group window by window, in position
+         *           order, and stores every position's predecessor (the first link of its chain entry);
+         *   pass 2  all threads complete the entries by chasing those first links three more steps (independent gathers, L2).
+         * The result in the head table and in the chain scratch is what the tile loop would have left; the loop starts at the
+         * item's first tile.  (Sibling items of the same block may share one scratch: they write identical values.) */
+        uint32_t *hist = nearTab; /* 2048 words: nearTab | srec | pv | control | slotTag */
+        constexpr uint32_t kGroup = 2048u;
+        for (uint32_t g0 = 0; g0 < histEnd; g0 += kGroup) {
+            if (tid < 512u) {
+                const uint32_t p0 = g0 + 4u * tid;
+                uint32_t w0 = 0u, w1 = 0u;
+                if (p0 < histEnd) { w0 = src.g[p0 >> 2]; w1 = src.g[(p0 >> 2) + 1u]; } /* parseFrom < n: the bytes behind exist */
+                const uint32_t segEc = seg_end(pf, p0, n); /* four positions from an aligned dword never straddle a boundary */
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t pj = p0 + j;
+                    const uint32_t v = j ? __builtin_amdgcn_alignbyte(w1, w0, j) : w0;
+                    const uint32_t mixH = v * kPrime1; /* the chain levels hash four bytes */
+                    const bool ok = pj < histEnd && pj + 4u <= segEc;
+                    hist[4u * tid + j] = ok ? (__umulhi(mixH, pf.tableSize) | (((mixH >> 3) & kTagMask) << 16)) : kNone;
+                }
+            }
+            __syncthreads();
+            if (wave == 2u) {
+                const uint32_t nW = umin(kGroup, histEnd - g0) >> 6; /* histEnd is a multiple of 4096 */
+                for (uint32_t w = 0; w < nW; w++) {
+                    const uint32_t st = hist[64u * w + lane];
+                    const uint32_t pos = g0 + 64u * w + lane;
+                    const uint32_t pred = chain_insert_window(tbl, st, ((pos + 1u) << kTagBits) | (st >> 16), lane, args.orderedLds != 0u);
+                    reinterpret_cast<uint32_t *>(chainB + pos)[0] = pred;
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t p0 = tid; p0 < histEnd; p0 += 4u * (uint32_t)kThreads) { /* four independent chases per thread in flight */
+            uint32_t e0[4], e1[4], e2[4], e3[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e0[i] = pp < histEnd ? reinterpret_cast<const uint32_t *>(chainB + pp)[0] : 0u; }
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) e1[i] = e0[i] ? reinterpret_cast<const uint32_t *>(chainB + ((e0[i] >> kTagBits) - 1u))[0] : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) e2[i] = e1[i] ? reinterpret_cast<const uint32_t *>(chainB + ((e1[i] >> kTagBits) - 1u))[0] : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) e3[i] = e2[i] ? reinterpret_cast<const uint32_t *>(chainB + ((e2[i] >> kTagBits) - 1u))[0] : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; if (pp < histEnd) chainB[pp] = make_uint4(e0[i], e1[i], e2[i], e3[i]); }
+        }
+        __syncthreads(); /* the scratch words of pass 1 are given back */
+        for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
+        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
+    }
     {
         const uint32_t hiMaskH = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
         for (; fo < hi; fo += kStep) {
             uint4 fa2 = make_uint4(0u, 0u, 0u, 0u), fb2 = fa2;
             const uint32_t o2 = fo + 2u * kStep;
-            if (o2 < hi) { fa2 = g128[o2 >> 4]; if (o2 < histEnd) fb2 = g128[(o2 >> 4) + 1u]; }
+            if (o2 < hi) { fa2 = g128[o2 >> 4]; if (o2 < hashEnd) fb2 = g128[(o2 >> 4) + 1u]; }
             if (fo >= lo) {
                 const uint32_t r = ring_dw(fo) << 2;
                 ring128[r >> 4] = fa0;
                 if (r < kMirror) ring128[(kRing + r) >> 4] = fa0;
             }
-            if (fo < histEnd) {
+            if (fo < hashEnd) {
                 /* segment mode below the chain levels: where the tables hold "the newest position of a slot" and nothing else
                  * (ds_max, no chains to link), the order of the inserts does not matter, so the history is inserted here — no
                  * ring, no barriers — and the tile loop starts at the segment's first tile: the state it finds (tables, ring)
@@ -755,7 +846,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             }
             fa0 = fa1; fb0 = fb1; fa1 = fa2; fb1 = fb2;
         }
-        if (itBegin != 0u && TURNS && tid == 0u) *turnCtr = itBegin * (uint32_t)kMatchWaves; /* the turn the first tile's wave 0 waits for */
+        if (itBegin != 0u && TURNS && !CHAIN && tid == 0u) *turnCtr = itBegin * (uint32_t)kMatchWaves; /* the turn the first tile's wave 0 waits for */
         if (itBegin == 0u) /* short blocks: zeros behind the end, as before */
             for (uint32_t o = hi + tid * 16u; o < kTile + kLook; o += kThreads * 16u) {
                 ring128[o >> 4] = make_uint4(0u, 0u, 0u, 0u);
@@ -864,7 +955,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         /* refill: the 512 bytes that enter the look-ahead window this iteration (HBM -> registers now,
          * registers -> ring after the barrier; the ring slots they replace left everyone's reach
          * three tiles ago) */
-        uint4 fresh = make_uint4(0u, 0u, 0u, 0u);
+        uint4 fresh; /* only the refilling lanes ever read it: declared "written" without an instruction (four v_mov per wave and tile otherwise) */
+        asm volatile("" : "=v"(fresh.x), "=v"(fresh.y), "=v"(fresh.z), "=v"(fresh.w));
         /* done by half of wave 1: waves 0 and 4 share their SIMD with the parse wave and carry no extra chores */
         const uint32_t fpos = t0 + kLook + (tid - 64u) * 16u; /* iteration it stages [t0 + kLook, t0 + kLook + kTile) */
         const bool refill = wave == 1u && it >= 1u && lane < kTile / 16u && fpos < nPad;
@@ -1168,8 +1260,12 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             const bool start = take && !defer1 && !defer2 && !defer3;
             const u64 startMask = __ballot(start);
             /* what the parse wave needs, one word per position (see parse_tile) */
-            const u64 here = startMask >> lane;
-            const uint32_t ns = here ? lane + (uint32_t)__builtin_ctzll(here) : 64u;
+            /* ns = the first start at/after this lane: the starts below the lane masked off word by word (a 64-bit shift by the
+             * lane is a quarter-rate instruction), v_ffbl's -1 for "none" drops out of the unsigned min */
+            const uint32_t smLo = (uint32_t)startMask, smHi = (uint32_t)(startMask >> 32);
+            const uint32_t keepLo = lane < 32u ? smLo & (0xFFFFFFFFu << (lane & 31u)) : 0u;
+            const uint32_t keepHi = lane < 32u ? smHi : smHi & (0xFFFFFFFFu << (lane & 31u));
+            const uint32_t ns = umin(umin(first_diff_bit(keepLo), first_diff_bit(keepHi) | 32u), 64u);
             const bool capped = cl == pf.capLen;
             const uint32_t endj = lane + cl;
             /* the next start at/after the match end is that position's `ns`: one ds_bpermute instead of a second 64-bit shift + count */
@@ -1231,6 +1327,7 @@ constexpr uint32_t kSvcQueue = 4096u;  /* entries of the device work queue */
 constexpr uint32_t kSvcRing = 256u;    /* entries of the host request ring */
 constexpr uint32_t kSvcMaxItems = 32u; /* work items per request */
 constexpr uint32_t kSvcSlots = 1024u;  /* request slots (one per caller in flight): slice flags */
+constexpr u64 kSvcChainBytes = (u64)QZSTD_HIP_BLOCK_MAX * 16ull; /* chain entries of one work item: four links per position of a 128 KiB block */
 constexpr uint32_t kSvcRejected = 0xFFFFFFFEu; /* count word: the service does not serve this request (other level): launch path */
 
 struct SvcDev { /* device memory, zeroed before every launch of the service */
@@ -1267,15 +1364,15 @@ __device__ __forceinline__ u64 svc_payload(u64 g) { return g & 0x00FFFFFFFFFFFFF
 /* request granules (host -> dispatcher):
  *   0 hSrc   1 dSrc   2 hSeqs   3 hCount   (pointers, 56 bits)
  *   4 srcLen (18) | itemBytes (18) << 18 | nItems (6) << 36 | slot (10) << 42
- *   5 seqCapPerItem (24)        6 epoch (24) | level (8) << 24        7 spare
+ *   5 seqCapPerItem (24)        6 epoch (24) | level (8) << 24        7 dWork: chain scratch, nItems regions of kSvcChainBytes (chain levels)
  *   (one field per word where a word is multiplied: hipcc 7.2 folded the mask of a packed seqCap away in the dispatcher's
  *   64-bit multiply and the items' result regions landed 256 MiB apart)
  * item granules (dispatcher -> worker):
  *   0 hSrc   1 dSrc   2 the item's result region   3 the item's count word
  *   4 srcLen (18: the block up to the item's end) | parseFrom (18) << 18 | item index (6) << 36 | slot (10) << 42
- *   5 seqCap (24)               6 epoch (24)                          7 spare */
+ *   5 seqCap (24)               6 epoch (24)                          7 the item's chain scratch (chain levels; else 0) */
 
-template <bool HAS_LONG, bool REP, bool TURNS>
+template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
 __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args, SvcDev *sv, uint32_t ctlOff, uint32_t spinLimit)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -1310,7 +1407,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
          * argument load — is for the compiler: the loops and branches of qz_item() stay scalar, its parse state in SGPRs */
         const u64 q0 = rdfirst(ctl[0]) | ((u64)rdfirst(ctl[1]) << 32), q1 = rdfirst(ctl[2]) | ((u64)rdfirst(ctl[3]) << 32),
                   q2 = rdfirst(ctl[4]) | ((u64)rdfirst(ctl[5]) << 32), q3 = rdfirst(ctl[6]) | ((u64)rdfirst(ctl[7]) << 32),
-                  q4 = rdfirst(ctl[8]) | ((u64)rdfirst(ctl[9]) << 32), q5 = rdfirst(ctl[10]), q6 = rdfirst(ctl[12]);
+                  q4 = rdfirst(ctl[8]) | ((u64)rdfirst(ctl[9]) << 32), q5 = rdfirst(ctl[10]), q6 = rdfirst(ctl[12]),
+                  q7 = rdfirst(ctl[14]) | ((u64)rdfirst(ctl[15]) << 32);
         const uint8_t *hSrc = (const uint8_t *)q0;
         uint8_t *dSrc = (uint8_t *)q1;
         uint4 *out = (uint4 *)q2;
@@ -1349,7 +1447,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
             __syncthreads();
         }
         uint32_t count = QZSTD_HIP_NSEQ_ERROR;
-        if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, false, TURNS>(args, blk, dSrc, out, nullptr);
+        if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, dSrc, out, CHAIN ? (uint4 *)q7 : nullptr);
         else if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->spinFails, 1u, QZ_RLX_AGENT);
         /* ---- completion: every wave's result stores are performed, then the count — the host's flag — with a system-scope release ---- */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1383,7 +1481,7 @@ __global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcD
         if (__all(mine) && !quitReq) {
             const u64 r0 = svc_payload(__shfl(g, 0)), r1 = svc_payload(__shfl(g, 1)), r2 = svc_payload(__shfl(g, 2)),
                       r3 = svc_payload(__shfl(g, 3)), r4 = svc_payload(__shfl(g, 4)), r5 = svc_payload(__shfl(g, 5)),
-                      r6 = svc_payload(__shfl(g, 6));
+                      r6 = svc_payload(__shfl(g, 6)), r7 = svc_payload(__shfl(g, 7));
             const uint32_t srcLen = (uint32_t)r4 & 0x3FFFFu, itemBytes = (uint32_t)(r4 >> 18) & 0x3FFFFu;
             const uint32_t nItems = (uint32_t)(r4 >> 36) & 63u, slotIdx = (uint32_t)(r4 >> 42) & (kSvcSlots - 1u);
             const uint32_t cap = (uint32_t)r5 & 0xFFFFFFu, epoch = (uint32_t)r6 & 0xFFFFFFu, lv = (uint32_t)(r6 >> 24) & 0xFFu;
@@ -1408,7 +1506,7 @@ __global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcD
                     __hip_atomic_store(e + 4, tg | upTo | ((u64)from << 18) | ((u64)lane << 36) | ((u64)slotIdx << 42), QZ_RLX_AGENT);
                     __hip_atomic_store(e + 5, tg | cap, QZ_RLX_AGENT);
                     __hip_atomic_store(e + 6, tg | epoch, QZ_RLX_AGENT);
-                    __hip_atomic_store(e + 7, tg, QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 7, tg | (r7 ? r7 + (u64)lane * kSvcChainBytes : 0ull), QZ_RLX_AGENT);
                 }
                 tail += nItems;
             }
@@ -1532,6 +1630,14 @@ struct Service {
     int broken = 0;  /* a request timed out or a launch failed: the service is not used again */
     std::atomic<unsigned long long> reserve{0}; /* request numbers handed to submitters */
     unsigned long launches = 0, requests = 0, refused = 0;
+    /* launches of the batch paths whose workgroups cannot share a CU with a worker (levels 3-4 fill a CU's LDS): while one of
+     * them is in flight the service stays down — resident workers would hold the LDS its remaining workgroups are waiting for,
+     * for as long as requests keep coming (found by the fuzz driver: an announced level-3 kernel, the service launched again
+     * behind it, its dispatcher queued behind that kernel in a shared hardware queue: nobody could move) */
+    static constexpr int kBig = 64;
+    hipEvent_t bigEv[kBig] = {};
+    bool bigUsed[kBig] = {};
+    int bigNext = 0;
 };
 Service g_svc[64];
 std::atomic<int> g_svcFreeze{0}; /* > 0: memory is being freed (hipFree / hipHostFree wait for every stream of the device) */
@@ -1817,6 +1923,17 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     const size_t lds = qzstd_hip_lds_bytes(level, maxBlockLen);
     if (lds == 0) return fail_msg("qzstd_hip_find_sequences: LDS budget exceeded");
     QZ_SET_DEVICE(device);
+    /* A resident service holds one worker's LDS (65 KB) on every CU.  A launch whose workgroups cannot share a CU with a worker
+     * (levels 3-4 fill a CU) would wait for as long as requests keep the service alive — and the service must not come back
+     * while such a launch is in flight: it is asked to leave first, and the launch is remembered by an event that the
+     * service's next launch checks.  One mutex per device covers "stop, launch, record". */
+    const bool big = lds + qzstd_hip_lds_bytes(1, QZSTD_HIP_BLOCK_MAX) > 163840u;
+    std::unique_lock<std::mutex> bigLock;
+    if (big && device >= 0 && device < 64) {
+        Service &sv = g_svc[device];
+        bigLock = std::unique_lock<std::mutex>(sv.mu);
+        if (sv.hs && __atomic_load_n(&sv.hs->state, __ATOMIC_ACQUIRE) != 0u) (void)svc_stop_locked(sv, 2000);
+    }
     /* [long][rep][chain/turns: 0 none, 1 turns, 2 chain + turns] */
     static const void *const variants[2][2][3] = {
         { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, false>),
@@ -1871,6 +1988,14 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (!kernel) return fail_msg("qzstd_hip_find_sequences: unsupported profile (no kernel variant)");
     QZ_CHECK(hipLaunchKernel(kernel, grid, wg, kargs, lds, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
+    if (big && bigLock.owns_lock()) {
+        Service &sv = g_svc[device];
+        const int k = sv.bigNext;
+        sv.bigNext = (k + 1) % Service::kBig;
+        if (!sv.bigEv[k] && hipEventCreateWithFlags(&sv.bigEv[k], hipEventDisableTiming) != hipSuccess) { sv.bigEv[k] = nullptr; (void)hipGetLastError(); }
+        if (sv.bigEv[k] && hipEventRecord(sv.bigEv[k], (hipStream_t)stream) == hipSuccess) sv.bigUsed[k] = true;
+        else (void)hipGetLastError();
+    }
     return 0;
 }
 
@@ -1881,11 +2006,12 @@ namespace {
 
 const void *svc_worker_variant(const qzstd_hip_profile_t &p)
 {
-    if (p.chainDepth || p.longSize) return nullptr; /* levels 3-4 fill a CU's LDS, the chain levels need per-item scratch: launch path */
-    if (p.repWin) return p.subTileLog ? reinterpret_cast<const void *>(qzstd_service_worker<false, true, true>)
-                                      : reinterpret_cast<const void *>(qzstd_service_worker<false, true, false>);
-    return p.subTileLog ? reinterpret_cast<const void *>(qzstd_service_worker<false, false, true>)
-                        : reinterpret_cast<const void *>(qzstd_service_worker<false, false, false>);
+#define QZ_W(L, R, C, T) reinterpret_cast<const void *>(qzstd_service_worker<L, R, C, T>)
+    if (p.chainDepth) return p.repWin ? QZ_W(false, true, true, true) : QZ_W(false, false, true, true);
+    if (p.longSize) return nullptr; /* levels 3-4: a worker would fill its CU's LDS and starve every other launch: batches */
+    if (p.repWin) return p.subTileLog ? QZ_W(false, true, false, true) : QZ_W(false, true, false, false);
+    return p.subTileLog ? QZ_W(false, false, false, true) : QZ_W(false, false, false, false);
+#undef QZ_W
 }
 
 int svc_launch_locked(int device, Service &s, int level)
@@ -1896,8 +2022,16 @@ int svc_launch_locked(int device, Service &s, int level)
     if (qzstd_hip_profile_for_level(level, QZSTD_HIP_BLOCK_MAX, &a.prof)) return fail_msg("service: bad level");
     const void *worker = svc_worker_variant(a.prof);
     const size_t lds = qzstd_hip_lds_bytes(level, QZSTD_HIP_BLOCK_MAX);
-    if (!worker || lds == 0 || 2u * lds > 163840u) return fail_msg("service: level not served");
+    if (!worker || lds == 0) return fail_msg("service: level not served");
+    if (a.prof.chainDepth) a.orderedLds = (uint32_t)probe_lds_order(device, phys(device));
     QZ_SET_DEVICE(device);
+    for (int k = 0; k < Service::kBig; k++) {
+        if (!s.bigUsed[k]) continue;
+        const hipError_t q = hipEventQuery(s.bigEv[k]);
+        if (q == hipErrorNotReady) return fail_msg("service: a launch that fills the CUs' LDS is in flight");
+        (void)hipGetLastError();
+        s.bigUsed[k] = false;
+    }
     if (!s.hs) {
         hipDeviceProp_t prop;
         QZ_CHECK(hipGetDeviceProperties(&prop, phys(device)), "hipGetDeviceProperties");
@@ -1906,8 +2040,12 @@ int svc_launch_locked(int device, Service &s, int level)
         void *h = nullptr, *d = nullptr;
         QZ_CHECK(hipHostMalloc(&h, sizeof(SvcHost), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(service ring)");
         memset(h, 0, sizeof(SvcHost));
-        if (hipMalloc(&d, sizeof(SvcDev)) != hipSuccess || hipStreamCreateWithFlags(&s.sWork, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&s.sDisp, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) {
+        /* streams of the highest priority: hardware queues of their own, so that neither kernel is serialised behind a batch
+         * kernel that happens to share a queue with it */
+        int prLeast = 0, prGreatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
+        if (hipMalloc(&d, sizeof(SvcDev)) != hipSuccess || hipStreamCreateWithPriority(&s.sWork, hipStreamNonBlocking, prGreatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&s.sDisp, hipStreamNonBlocking, prGreatest) != hipSuccess || hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (d) (void)hipFree(d);
             (void)hipHostFree(h);
@@ -1977,9 +2115,8 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
     if (s.broken) return 1;
     {
         qzstd_hip_profile_t p;
-        if (qzstd_hip_profile_for_level(level, QZSTD_HIP_BLOCK_MAX, &p) || !svc_worker_variant(p) ||
-            2u * qzstd_hip_lds_bytes(level, QZSTD_HIP_BLOCK_MAX) > 163840u)
-            return 1;
+        if (qzstd_hip_profile_for_level(level, QZSTD_HIP_BLOCK_MAX, &p) || !svc_worker_variant(p)) return 1;
+        if (p.chainDepth && !r->dWork) return fail_msg("qzstd_hip_service_submit: the chain levels need dWork");
     }
     if (r->nItems < 1u || r->nItems > kSvcMaxItems || r->slot >= kSvcSlots || r->srcLen == 0u || r->srcLen > QZSTD_HIP_BLOCK_MAX ||
         r->itemBytes == 0u || (size_t)(r->nItems - 1u) * r->itemBytes >= r->srcLen || (r->itemBytes & 15u) || !r->hSrc || !r->dSrc ||
@@ -2023,7 +2160,7 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
     e[4] = tg | (u64)r->srcLen | ((u64)r->itemBytes << 18) | ((u64)r->nItems << 36) | ((u64)r->slot << 42);
     e[5] = tg | (u64)r->seqCapPerItem;
     e[6] = tg | (u64)(r->epoch & 0xFFFFFFu) | (lv << 24);
-    e[7] = tg;
+    e[7] = tg | (u64)(uintptr_t)r->dWork;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     /* is anybody there to take it?  2 = the dispatcher is deciding whether to leave: wait for its verdict (microseconds) */
     uint32_t st;
@@ -2092,6 +2229,8 @@ int qzstd_hip_service_debug(int device, unsigned long out[8])
     if (!s.hs) return 0;
     for (int k = 0; k < 6; k++) out[k] = (unsigned long)__atomic_load_n(&s.hs->dbg[k], __ATOMIC_RELAXED);
     out[6] = (unsigned long)__atomic_load_n(&s.hs->consumed, __ATOMIC_RELAXED);
+    out[7] = (unsigned long)s.reserve.load() | ((unsigned long)__atomic_load_n(&s.hs->quitReq, __ATOMIC_RELAXED) << 62) |
+             ((unsigned long)(g_svcFreeze.load() > 0) << 61);
     return 0;
 }
 

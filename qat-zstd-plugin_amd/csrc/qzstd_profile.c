@@ -78,7 +78,10 @@ size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockL
     return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * 16u; /* four links per position */
 }
 
-#define QZ_RING_BYTES (49152u + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip) */
+#ifndef QZ_RING
+#define QZ_RING 32768u
+#endif
+#define QZ_RING_BYTES (QZ_RING + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip: kRing) */
 
 /* LDS per workgroup: independent of the block size — 81 664 B at levels 1-2 (two workgroups per CU) */
 size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)

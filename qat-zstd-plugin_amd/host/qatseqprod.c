@@ -100,6 +100,7 @@ typedef struct {
     unsigned char *vdSrc;  /* device */
     ZSTD_Sequence *vSeqs;  /* pinned, QZ_SVC_ITEMS_MAX x QZ_SVC_ITEM_CAP */
     unsigned int *vCount;  /* pinned, QZ_SVC_ITEMS_MAX */
+    void *vdWork;          /* device: chain scratch of the items (levels >= 5), QZ_SVC_ITEMS_MAX x QZSTD_HIP_SVC_WORK_BYTES, on first use */
     unsigned int vEpoch, vItems; /* the last request: its epoch, its item count */
     int vStuck;            /* that request timed out: the slot serves no request before all its count words have arrived */
 } QZSTD_Slot_T;
@@ -121,8 +122,8 @@ typedef struct {
 #define QZ_BATCH_MAX 128
 #define QZ_BATCHES 4
 #define QZ_BATCH_PITCH ((size_t)16384) /* sequences per block in the batch's result area; denser blocks are redone alone */
-#define QZ_SEGS_MAX 4 /* a batched block goes to the GPU as up to four work items, each a run of whole segments (profile.segLog) */
-#define QZ_ITEM_BYTES ((size_t)32768) /* ... of this size; the service path (below) cuts finer */
+#define QZ_SEGS_MAX 8 /* a batched block goes to the GPU as up to eight work items, each a run of whole segments (profile.segLog):
+                       * 16 KiB items for a 128 KiB block, 4 KiB items for a 32 KiB one; the service path (below) cuts finer */
 #define QZ_SPLIT_ITEMS_MAX 256 /* batches are only cut into segment items while the launch stays within one workgroup per CU */
 typedef struct {
     const void *src;
@@ -324,6 +325,7 @@ static void qzFreeSlot(QZSTD_Slot_T *s)
     qzstd_hip_host_free(s->vSeqs);
     qzstd_hip_host_free(s->vCount);
     qzstd_hip_free(s->device, s->vdSrc);
+    qzstd_hip_free(s->device, s->vdWork);
     if (s->stream) qzstd_hip_stream_destroy(s->device, s->stream);
     {
         const int dev = s->device;
@@ -482,8 +484,8 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
          * (and, at the chain levels, multiply the scratch); they pay for batches that leave CUs idle */
         if (gProc.splitBlocks && n * QZ_SEGS_MAX <= QZ_SPLIT_ITEMS_MAX && qzstd_hip_profile_for_level(r->level, r->srcSize, &pf) == 0 && pf.segLog) {
             seg = (size_t)1 << pf.segLog;
-            if (seg < QZ_ITEM_BYTES) seg = QZ_ITEM_BYTES; /* a multiple of the segment size: both are powers of two */
-            if (r->srcSize > seg && (r->srcSize + seg - 1) / seg <= QZ_SEGS_MAX) r->nSeg = (int)((r->srcSize + seg - 1) / seg);
+            while ((r->srcSize + seg - 1) / seg > QZ_SEGS_MAX) seg *= 2; /* whole segments per item */
+            if (r->srcSize > seg) r->nSeg = (int)((r->srcSize + seg - 1) / seg);
         }
         first[j] = k;
         for (sg = 0; sg < r->nSeg; sg++, k++) {
@@ -1041,6 +1043,16 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
     rq.srcLen = (uint32_t)srcSize; rq.itemBytes = (uint32_t)itemBytes; rq.nItems = (uint32_t)nItems;
     rq.seqCapPerItem = (uint32_t)(QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP / nItems); /* the slot's whole result area, shared out */
     rq.slot = (uint32_t)i; rq.epoch = sl->vEpoch;
+    rq.dWork = NULL;
+    if (qzstd_hip_workspace_bytes(level, 1, QZSTD_HIP_BLOCK_MAX) != 0) { /* a chain level: every item links the block before it in its own scratch */
+        if (!sl->vdWork) sl->vdWork = qzstd_hip_malloc(sl->device, (size_t)QZ_SVC_ITEMS_MAX * QZSTD_HIP_SVC_WORK_BYTES);
+        if (!sl->vdWork) {
+            memset(sl->vCount, 0xFF, nItems * sizeof(unsigned int));
+            qzReleaseSlot(i);
+            return QZ_NOT_SERVED;
+        }
+        rq.dWork = sl->vdWork;
+    }
     rc = qzstd_hip_service_submit(sl->device, level, &rq);
     if (rc != 0) {
         memset(sl->vCount, 0xFF, nItems * sizeof(unsigned int)); /* nothing outstanding */
@@ -1071,14 +1083,18 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
             (void)qzstd_hip_service_info(sl->device, in);
             (void)qzstd_hip_service_debug(sl->device, dg);
             QZ_LOG(1, "device %d: service request timed out after %d ms (service: %lu launch(es), %lu request(s), state %lu; dispatcher: %lu poll(s), "
-                      "%lu request(s) taken, %lu item(s) queued; workers: %lu started, %lu item(s) picked up, %lu finished, %lu gave up on a slice)\n",
-                   sl->device, gProc.timeoutMs, in[0], in[1], in[4], dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], in[6]);
+                      "%lu request(s) taken, %lu item(s) queued; workers: %lu started, %lu item(s) picked up, %lu finished, %lu gave up on a slice; ring: %lu "
+                      "consumed, %lu reserved, quit %lu, frozen %lu; this request: %zu item(s), level %#x)\n",
+                   sl->device, gProc.timeoutMs, in[0], in[1], in[4], dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], in[6], dg[6],
+                   dg[7] & 0x1FFFFFFFFFFFFFFFul, dg[7] >> 62, (dg[7] >> 61) & 1ul, nItems, (unsigned)level);
         }
         sl->vStuck = 1;
         qzstd_hip_service_mark_broken(sl->device);
         qzReleaseSlot(i);
-        qzCause = QZ_CAUSE_TIMEOUT;
-        return ZSTD_SEQUENCE_PRODUCER_ERROR;
+        /* the resident kernels are asked to leave and are not used again; THIS block is not lost: it goes through the batches
+         * (whose own wait has the same limit: a device that is really wedged then returns the error, reference :1261-1285) */
+        s->redoneAlone++;
+        return QZ_NOT_SERVED;
     }
     for (k = 0; k < nItems && !bad; k++) {
         const unsigned int cnt = sl->vCount[k];

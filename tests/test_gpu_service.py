@@ -49,12 +49,20 @@ def test_service_items_equal_the_oracle(gpu_plugin, oracle, level):
         lane.close()
 
 
-def test_service_levels_it_does_not_serve(gpu_plugin):
-    lane = gpu_plugin.service_lane(slot=8)
+@pytest.mark.parametrize("level", [5, 6, 9, 12, 0x106])
+def test_service_chain_levels(gpu_plugin, oracle, level):
+    """the chain levels through the service (every item links the block before it in its own scratch: the history pass of
+    qz_item), item by item against the oracle; levels 3-4 are not served (a worker would fill its CU's LDS and starve every
+    other launch)"""
+    lane = gpu_plugin.service_lane(slot=9)
     try:
-        blk = K.text(5, 65536)
-        for level in (3, 4, 5, 6, 9, 12):  # fill a CU's LDS / need per-item chain scratch: the launch path's
-            assert lane.run(blk, level) is None
+        assert lane.run(K.text(5, 65536), 3) is None and lane.run(K.text(5, 65536), 4) is None
+        data = K.by_name("system", 2 * 131072, seed=5)
+        check_request(oracle, lane, data[:131072], level)
+        check_request(oracle, lane, data[131072:][:100001], level)
+        check_request(oracle, lane, K.by_name("weblog", 32768, seed=4), level)
+        check_request(oracle, lane, data[:131072], level, 16384)
+        assert gpu_plugin.lib.qzstd_hip_service_stop(0) == 0
     finally:
         lane.close()
 

@@ -247,7 +247,7 @@ class SvcReq(C.Structure):
     """qzstd_hip_svc_req_t (include/qzstd_hip.h): one block for the resident service"""
     _fields_ = [("hSrc", C.c_void_p), ("dSrc", C.c_void_p), ("hSeqs", C.c_void_p), ("hCount", C.c_void_p),
                 ("srcLen", C.c_uint32), ("itemBytes", C.c_uint32), ("nItems", C.c_uint32), ("seqCapPerItem", C.c_uint32),
-                ("slot", C.c_uint32), ("epoch", C.c_uint32)]
+                ("slot", C.c_uint32), ("epoch", C.c_uint32), ("dWork", C.c_void_p)]
 
 
 # every symbol include/qatseqprod.h and include/qzstd_hip.h declare
@@ -396,6 +396,7 @@ class ServiceLane:
         self.hseq = L.qzstd_hip_host_alloc_coherent(self.MAX_ITEMS * self.ITEM_CAP * 16)
         self.hcnt = L.qzstd_hip_host_alloc_coherent(self.MAX_ITEMS * 4)
         self.dsrc = L.qzstd_hip_malloc(device, self.BLOCK_MAX + 64)
+        self.dwork = None
         assert self.hsrc and self.hseq and self.hcnt and self.dsrc, plug.err()
         self.cnt = (C.c_uint32 * self.MAX_ITEMS).from_address(self.hcnt)
         self.seqs = (Sequence * (self.MAX_ITEMS * self.ITEM_CAP)).from_address(self.hseq)
@@ -411,7 +412,13 @@ class ServiceLane:
         for k in range(nit):
             self.cnt[k] = 0
         self.epoch = self.epoch % 0xFFFFFF + 1
-        rq = SvcReq(self.hsrc, self.dsrc, self.hseq, self.hcnt, n, item_bytes, nit, cap, self.slot, self.epoch)
+        work = None
+        if self.L.qzstd_hip_workspace_bytes(level, 1, self.BLOCK_MAX):
+            if not self.dwork:
+                self.dwork = self.L.qzstd_hip_malloc(self.device, self.MAX_ITEMS * self.BLOCK_MAX * 16)
+                assert self.dwork, self.plug.err()
+            work = self.dwork
+        rq = SvcReq(self.hsrc, self.dsrc, self.hseq, self.hcnt, n, item_bytes, nit, cap, self.slot, self.epoch, work)
         rc = self.L.qzstd_hip_service_submit(self.device, level, C.byref(rq))
         if rc == 1:
             return None
@@ -425,3 +432,5 @@ class ServiceLane:
         L = self.L
         L.qzstd_hip_host_free(self.hsrc); L.qzstd_hip_host_free(self.hseq); L.qzstd_hip_host_free(self.hcnt)
         L.qzstd_hip_free(self.device, self.dsrc)
+        if self.dwork:
+            L.qzstd_hip_free(self.device, self.dwork)
