@@ -174,7 +174,7 @@ typedef struct {
     void *dWork;        /* chain levels (>= 5): device scratch, nItems x QZSTD_HIP_SVC_WORK_BYTES (every item links the block before it
                          * there); NULL at the other levels */
 } qzstd_hip_svc_req_t;
-#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 16u)
+#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 20u)
 int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *req);
 int qzstd_hip_service_stop(int device);          /* asks the resident kernels to leave and waits for them; 0 = stopped */
 void qzstd_hip_service_mark_broken(int device);  /* a request timed out: stop and do not use the service again */

@@ -93,7 +93,8 @@ struct LaunchArgs {
     uint32_t *nseq;
     qzstd_hip_profile_t prof; /* the level's search profile (block-size independent) */
     uint4 *chain;             /* levels >= 5: per-block chain entries (four links each), chainStride entries per block */
-    uint32_t chainStride;
+    uint32_t chainStride;     /* uint4 units between the scratch regions of consecutive work items */
+    uint32_t chainEntries;    /* entries per region; the region's dense array of first links (4 B per position) follows them */
     uint32_t orderedLds;      /* this device's LDS returns from ds_max_rtn, to lanes of one instruction that hit the same address, the
                                * values in lane order (probed once per device, probe_lds_order) */
 #ifdef QZ_DEBUG_DUMP
@@ -111,6 +112,13 @@ typedef unsigned long long u64;
 #define QZ_ABLATED(bit) false
 #define QZ_DBG 0u
 #endif
+
+/* A workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global loads and stores
+ * (s_waitcnt vmcnt(0)): every barrier of the tile loop then waits for the round trips of the ring refill's load and of the result
+ * stores — to PINNED HOST memory in the product paths — although no wave reads what another wave wrote to global memory (below the
+ * chain levels; there the barrier at the end of a tile stays a full one: chain entries).  Loads the compiler issued are still
+ * waited for where their registers are used. */
+#define QZ_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 /* v_readlane_b32 with an unsigned result (the builtin returns int: a set bit 31 would sign-extend) */
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -676,13 +684,13 @@ __device__ __forceinline__ uint32_t chain_insert_window(uint32_t *tbl, uint32_t 
 }
 
 /* One work item (a block, or a run of whole segments of one): `blk` describes it, gsrc = the block's bytes in device memory,
- * out = the item's result region, chainB = its chain entries (CHAIN).  Returns, in the parse wave, the item's sequence
+ * out = the item's result region, chainB = its chain entries (CHAIN), p1B = its array of first links (CHAIN, segment items).  Returns, in the parse wave, the item's sequence
  * count including the delimiter or QZSTD_HIP_NSEQ_ERROR (every thread returns that for an item that is refused); the matcher
  * waves return 0.  Both kernels below are thin shells around it: one launch = one item per workgroup
  * (qzstd_find_sequences_kernel), or a resident worker that takes items from a queue (qzstd_service_worker). */
 template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
 __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_hip_block_t &blk, const uint8_t *gsrc, uint4 *out,
-                                            uint4 *chainB)
+                                            uint4 *chainB, uint32_t *p1B)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -760,54 +768,104 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
          * predecessor in its slot), but not walked.  Going through the tile loop for that costs one exposed HBM round trip per tile
          * (the predecessor's entry): 5.5 us x 240 tiles in front of a block's last item.  Instead:
          *   pass 1  groups of 2048 positions: 512 threads hash four positions each straight from device memory (slot | tag into
-         *           LDS words that are dead until the tile loop), then ONE wave inserts the group window by window, in position
-         *           order, and stores every position's predecessor (the first link of its chain entry);
+         *           LDS), ONE wave inserts the group window by window, in position order, and stores every position's
+         *           predecessor (the first link of its chain entry);
          *   pass 2  all threads complete the entries by chasing those first links three more steps (independent gathers, L2).
          * The result in the head table and in the chain scratch is what the tile loop would have left; the loop starts at the
          * item's first tile.  (Sibling items of the same block may share one scratch: they write identical values.) */
-        uint32_t *hist = nearTab; /* 2048 words: nearTab | srec | pv | control | slotTag */
-        constexpr uint32_t kGroup = 2048u;
-        for (uint32_t g0 = 0; g0 < histEnd; g0 += kGroup) {
-            if (tid < 512u) {
-                const uint32_t p0 = g0 + 4u * tid;
-                uint32_t w0 = 0u, w1 = 0u;
-                if (p0 < histEnd) { w0 = src.g[p0 >> 2]; w1 = src.g[(p0 >> 2) + 1u]; } /* parseFrom < n: the bytes behind exist */
-                const uint32_t segEc = seg_end(pf, p0, n); /* four positions from an aligned dword never straddle a boundary */
+        /* pass 1, groups of 4096 positions (the ring's 32 KiB of LDS, unused until the prefill below, hold two words per position:
+         * slot | tag in, first link out):
+         *   hash     256 threads, 16 positions each from two coalesced 16-byte loads (the next group's are already in flight);
+         *   insert   TWO waves at once, one for the even slots, one for the odd ones: the order only matters among the positions
+         *            of one slot, so each walks all 64 windows in position order and inserts its own lanes (returning ds_max,
+         *            SIXTEEN windows in flight: one wave with eight in flight is bound by the atomics' latency, 130 us per
+         *            120 KiB measured; eight waves each owning an eighth of the slots are bound by the LDS's instruction rate,
+         *            230 us: every wave reads every window);
+         *   copy     the 4096 first links go out to the dense array p1B, 16 bytes per thread and store. */
+        constexpr uint32_t kGroup = 4096u;
+        static_assert(kGroup * 8u <= kRing, "two words per position of a group in the ring's LDS");
+        uint32_t *hist = ring32;          /* [kGroup] slot | tag */
+        uint32_t *link = ring32 + kGroup; /* [kGroup] first links */
+        const uint32_t nGroups = (histEnd + kGroup - 1u) / kGroup;
+        uint4 ha = make_uint4(0u, 0u, 0u, 0u), hb = ha;
+        if (tid < 256u && tid * 16u < histEnd) { ha = g128[tid]; hb = g128[tid + 1u]; }
+        for (uint32_t g = 0; g < nGroups && !QZ_ABLATED(2048u); g++) {
+            const uint32_t g0 = g * kGroup;
+            if (tid < 256u) { /* hash */
+                const uint32_t c = g0 + tid * 16u;
+                const uint32_t W[5] = { ha.x, ha.y, ha.z, ha.w, hb.x };
+                const uint32_t segEc = seg_end(pf, c, n); /* a 16-byte chunk never straddles a segment boundary */
+                uint32_t st16[16];
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    const uint32_t pj = p0 + j;
-                    const uint32_t v = j ? __builtin_amdgcn_alignbyte(w1, w0, j) : w0;
+                for (uint32_t k = 0; k < 16u; k++) {
+                    const uint32_t v = (k & 3u) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 1u], W[k >> 2], k & 3u) : W[k >> 2];
                     const uint32_t mixH = v * kPrime1; /* the chain levels hash four bytes */
-                    const bool ok = pj < histEnd && pj + 4u <= segEc;
-                    hist[4u * tid + j] = ok ? (__umulhi(mixH, pf.tableSize) | (((mixH >> 3) & kTagMask) << 16)) : kNone;
+                    const bool ok = c + k < histEnd && c + k + 4u <= segEc;
+                    st16[k] = ok ? (__umulhi(mixH, pf.tableSize) | (((mixH >> 3) & kTagMask) << 16)) : kNone;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++)
+                    reinterpret_cast<uint4 *>(hist)[tid * 4u + k] = make_uint4(st16[4u * k], st16[4u * k + 1u], st16[4u * k + 2u], st16[4u * k + 3u]);
+                const uint32_t cn = c + kGroup; /* the next group's bytes: in flight during the inserts */
+                ha = hb = make_uint4(0u, 0u, 0u, 0u);
+                if (cn < histEnd) { ha = g128[cn >> 4]; hb = g128[(cn >> 4) + 1u]; } /* parseFrom < n: the bytes behind exist */
+            }
+            QZ_BARRIER_LDS();
+            if (wave == 2u || wave == 3u) { /* insert: this wave's slots (neither wave shares its SIMD with the parse wave) */
+                const uint32_t nW = umin(kGroup, histEnd - g0) >> 6; /* histEnd is a multiple of 4096: nW of 64 */
+                const uint32_t par = wave & 1u;
+                if (args.orderedLds != 0u) {
+                    /* the returning ds_max of sixteen windows issued back to back (LDS operations of one wave execute in order) */
+                    for (uint32_t w0 = 0; w0 < nW; w0 += 16u) {
+                        uint32_t st[16], pred[16];
+#pragma unroll
+                        for (uint32_t k = 0; k < 16u; k++) st[k] = hist[64u * (w0 + k) + lane];
+#pragma unroll
+                        for (uint32_t k = 0; k < 16u; k++) {
+                            const uint32_t pos = g0 + 64u * (w0 + k) + lane;
+                            pred[k] = 0u;
+                            if (st[k] != kNone && (st[k] & 1u) == par) pred[k] = atomicMax(&tbl[st[k] & 0xFFFFu], ((pos + 1u) << kTagBits) | (st[k] >> 16));
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 16u; k++)
+                            if (st[k] == kNone || (st[k] & 1u) == par) link[64u * (w0 + k) + lane] = pred[k]; /* (no part: 0, from both waves) */
+                    }
+                } else {
+                    for (uint32_t w = 0; w < nW; w++) { /* the portable path: same-slot lanes ordered with ballots, window by window */
+                        const uint32_t st = hist[64u * w + lane];
+                        const uint32_t pos = g0 + 64u * w + lane;
+                        const bool mine = st != kNone && (st & 1u) == par;
+                        const uint32_t pred = chain_insert_window(tbl, mine ? st : kNone, ((pos + 1u) << kTagBits) | (st >> 16), lane, false);
+                        if (mine || st == kNone) link[64u * w + lane] = pred;
+                    }
                 }
             }
-            __syncthreads();
-            if (wave == 2u) {
-                const uint32_t nW = umin(kGroup, histEnd - g0) >> 6; /* histEnd is a multiple of 4096 */
-                for (uint32_t w = 0; w < nW; w++) {
-                    const uint32_t st = hist[64u * w + lane];
-                    const uint32_t pos = g0 + 64u * w + lane;
-                    const uint32_t pred = chain_insert_window(tbl, st, ((pos + 1u) << kTagBits) | (st >> 16), lane, args.orderedLds != 0u);
-                    reinterpret_cast<uint32_t *>(chainB + pos)[0] = pred;
-                }
+            QZ_BARRIER_LDS();
+            if (tid < 512u && !QZ_ABLATED(1024u)) { /* copy out: coalesced 16-byte stores */
+#pragma unroll
+                for (uint32_t k = 0; k < 2u; k++)
+                    if (g0 + (k * 512u + tid) * 4u < histEnd) reinterpret_cast<uint4 *>(p1B + g0)[k * 512u + tid] = reinterpret_cast<const uint4 *>(link)[k * 512u + tid];
             }
-            __syncthreads();
+            QZ_BARRIER_LDS(); /* the words are rewritten by the next group's hashes */
         }
-        for (uint32_t p0 = tid; p0 < histEnd; p0 += 4u * (uint32_t)kThreads) { /* four independent chases per thread in flight */
-            uint32_t e0[4], e1[4], e2[4], e3[4];
+        /* pass 2: every history position's entry = its first link and the three behind it, chased through the dense array (L2:
+         * about 1.8 us per dependent gather under load); eight independent chases per thread in flight (sixteen push the kernel past
+         * 104 VGPRs: one workgroup per CU, level 6 26 -> 37 ms per 256 MiB) */
+        constexpr uint32_t kChase = 8u;
+        for (uint32_t p0 = tid; p0 < histEnd && !QZ_ABLATED(512u); p0 += kChase * (uint32_t)kThreads) {
+            uint32_t e0[kChase], e1[kChase], e2[kChase], e3[kChase];
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e0[i] = pp < histEnd ? reinterpret_cast<const uint32_t *>(chainB + pp)[0] : 0u; }
+            for (uint32_t i = 0; i < kChase; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e0[i] = pp < histEnd ? p1B[pp] : 0u; }
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) e1[i] = e0[i] ? reinterpret_cast<const uint32_t *>(chainB + ((e0[i] >> kTagBits) - 1u))[0] : 0u;
+            for (uint32_t i = 0; i < kChase; i++) e1[i] = e0[i] ? p1B[(e0[i] >> kTagBits) - 1u] : 0u;
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) e2[i] = e1[i] ? reinterpret_cast<const uint32_t *>(chainB + ((e1[i] >> kTagBits) - 1u))[0] : 0u;
+            for (uint32_t i = 0; i < kChase; i++) e2[i] = e1[i] ? p1B[(e1[i] >> kTagBits) - 1u] : 0u;
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) e3[i] = e2[i] ? reinterpret_cast<const uint32_t *>(chainB + ((e2[i] >> kTagBits) - 1u))[0] : 0u;
+            for (uint32_t i = 0; i < kChase; i++) e3[i] = e2[i] ? p1B[(e2[i] >> kTagBits) - 1u] : 0u;
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; if (pp < histEnd) chainB[pp] = make_uint4(e0[i], e1[i], e2[i], e3[i]); }
+            for (uint32_t i = 0; i < kChase; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; if (pp < histEnd) chainB[pp] = make_uint4(e0[i], e1[i], e2[i], e3[i]); }
         }
-        __syncthreads(); /* the scratch words of pass 1 are given back */
+        __syncthreads();
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
         for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
     }
@@ -1296,7 +1354,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
 {
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
-                                                                CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr);
+                                                                CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr,
+                                                                CHAIN ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr);
     if (threadIdx.x == (uint32_t)kMatchThreads) args.nseq[blockIdx.x] = count; /* lane 0 of the parse wave */
 }
 
@@ -1327,7 +1386,7 @@ constexpr uint32_t kSvcQueue = 4096u;  /* entries of the device work queue */
 constexpr uint32_t kSvcRing = 256u;    /* entries of the host request ring */
 constexpr uint32_t kSvcMaxItems = 32u; /* work items per request */
 constexpr uint32_t kSvcSlots = 1024u;  /* request slots (one per caller in flight): slice flags */
-constexpr u64 kSvcChainBytes = (u64)QZSTD_HIP_BLOCK_MAX * 16ull; /* chain entries of one work item: four links per position of a 128 KiB block */
+constexpr u64 kSvcChainBytes = (u64)QZSTD_HIP_BLOCK_MAX * 20ull; /* scratch of one work item: 16 B of chain entry + 4 B of first link per position of a 128 KiB block */
 constexpr uint32_t kSvcRejected = 0xFFFFFFFEu; /* count word: the service does not serve this request (other level): launch path */
 
 struct SvcDev { /* device memory, zeroed before every launch of the service */
@@ -1447,7 +1506,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
             __syncthreads();
         }
         uint32_t count = QZSTD_HIP_NSEQ_ERROR;
-        if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, dSrc, out, CHAIN ? (uint4 *)q7 : nullptr);
+        if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, dSrc, out, CHAIN ? (uint4 *)q7 : nullptr,
+                                                                               CHAIN ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 16ull) : nullptr);
         else if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->spinFails, 1u, QZ_RLX_AGENT);
         /* ---- completion: every wave's result stores are performed, then the count — the host's flag — with a system-scope release ---- */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1967,6 +2027,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     }
     a.chain = nullptr;
     a.chainStride = 0;
+    a.chainEntries = 0;
     a.orderedLds = 0;
     if (a.prof.chainDepth) {
         a.orderedLds = (uint32_t)probe_lds_order(device, phys(device));
@@ -1974,6 +2035,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         if (!d_work || workBytes < need) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
         a.chain = static_cast<uint4 *>(d_work);
         a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
+        a.chainEntries = (uint32_t)(need / nBlocks / 20u);
     }
     a.src = static_cast<const uint8_t *>(d_src);
     a.blocks = d_blocks;

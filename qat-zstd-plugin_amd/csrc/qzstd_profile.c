@@ -70,12 +70,13 @@ size_t qzstd_hip_sequence_bound(size_t srcSize)
     return srcSize / 3 + 1 + srcSize / 1024 + 1;
 }
 
-/* device scratch of one launch: the chain entries of levels >= 5, 16 B (four links) per position of every block */
+/* device scratch of one launch: per position of every work item the chain entry of levels >= 5 (16 B, four links) and — for the
+ * history pass of segment items — its first link once more in a dense array (4 B) */
 size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockLen)
 {
     qzstd_hip_profile_t p;
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX || qzstd_hip_profile_for_level(level, maxBlockLen, &p) || !p.chainDepth) return 0;
-    return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * 16u; /* four links per position */
+    return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * 20u; /* a chain entry of four links + the first link again, dense */
 }
 
 #ifndef QZ_RING

@@ -122,8 +122,10 @@ typedef struct {
 #define QZ_BATCH_MAX 128
 #define QZ_BATCHES 4
 #define QZ_BATCH_PITCH ((size_t)16384) /* sequences per block in the batch's result area; denser blocks are redone alone */
-#define QZ_SEGS_MAX 8 /* a batched block goes to the GPU as up to eight work items, each a run of whole segments (profile.segLog):
-                       * 16 KiB items for a 128 KiB block, 4 KiB items for a 32 KiB one; the service path (below) cuts finer */
+#define QZ_SEGS_MAX 32 /* a batched block goes to the GPU as up to 32 work items, each a run of whole segments (profile.segLog): as many
+                        * as keep the launch within one workgroup per CU — 32 per block while at most 8 callers share a batch, 8 up to 32
+                        * callers, whole blocks beyond */
+#define QZ_DESC_MAX (QZ_BATCH_MAX + QZ_SPLIT_ITEMS_MAX) /* descriptors of a batch: unsplit, or split within QZ_SPLIT_ITEMS_MAX */
 #define QZ_SPLIT_ITEMS_MAX 256 /* batches are only cut into segment items while the launch stays within one workgroup per CU */
 typedef struct {
     const void *src;
@@ -131,6 +133,7 @@ typedef struct {
     int level;
     int nSeg, dense;                /* segments submitted; the batch's result area was too small: redo alone */
     int cause;                      /* QZ_CAUSE_* when rc is the error code (set by the batch's leader) */
+    unsigned int segPitch;          /* result entries per segment: QZ_BATCH_PITCH / nSeg */
     unsigned int segCnt[QZ_SEGS_MAX]; /* sequences per segment, each including its delimiter */
 } QZSTD_Req_T;
 
@@ -444,8 +447,8 @@ static int qzSetupBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
     bt->dSrc = (unsigned char *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * QZ_SRC_STRIDE);
     bt->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SRC_STRIDE);
     bt->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_BATCH_PITCH * sizeof(ZSTD_Sequence));
-    bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SEGS_MAX * sizeof(qzstd_hip_block_t));
-    bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SEGS_MAX * sizeof(unsigned int));
+    bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_DESC_MAX * sizeof(qzstd_hip_block_t));
+    bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_DESC_MAX * sizeof(unsigned int));
     bt->dvSeqs = qzstd_hip_host_device_ptr(bt->hSeqs);
     bt->dvDesc = qzstd_hip_host_device_ptr(bt->hDesc);
     bt->dvCount = qzstd_hip_host_device_ptr(bt->hCount);
@@ -482,11 +485,13 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         r->dense = 0;
         /* a full batch fills the GPU as it is: segment items then only repeat the insert work of the block before them
          * (and, at the chain levels, multiply the scratch); they pay for batches that leave CUs idle */
-        if (gProc.splitBlocks && n * QZ_SEGS_MAX <= QZ_SPLIT_ITEMS_MAX && qzstd_hip_profile_for_level(r->level, r->srcSize, &pf) == 0 && pf.segLog) {
+        const size_t segsMax = !gProc.splitBlocks ? 1 : (n * 32 <= QZ_SPLIT_ITEMS_MAX ? 32 : (n * 8 <= QZ_SPLIT_ITEMS_MAX ? 8 : 1));
+        if (segsMax > 1 && qzstd_hip_profile_for_level(r->level, r->srcSize, &pf) == 0 && pf.segLog) {
             seg = (size_t)1 << pf.segLog;
-            while ((r->srcSize + seg - 1) / seg > QZ_SEGS_MAX) seg *= 2; /* whole segments per item */
+            while ((r->srcSize + seg - 1) / seg > segsMax) seg *= 2; /* whole segments per item */
             if (r->srcSize > seg) r->nSeg = (int)((r->srcSize + seg - 1) / seg);
         }
+        r->segPitch = (unsigned int)(QZ_BATCH_PITCH / (size_t)r->nSeg);
         first[j] = k;
         for (sg = 0; sg < r->nSeg; sg++, k++) {
             qzstd_hip_block_t *d = &bt->hDesc[k];
@@ -499,9 +504,9 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
                 d->parseFrom = 0;
             } else { /* segment sg: the block up to the segment's end, parsed from the segment's start */
                 const size_t end = (size_t)(sg + 1) * seg;
-                d->seqOff = (size_t)order[j] * QZ_BATCH_PITCH + (size_t)sg * (QZ_BATCH_PITCH / QZ_SEGS_MAX);
+                d->seqOff = (size_t)order[j] * QZ_BATCH_PITCH + (size_t)sg * r->segPitch;
                 d->srcLen = (unsigned int)(end < r->srcSize ? end : r->srcSize);
-                d->seqCap = (unsigned int)(QZ_BATCH_PITCH / QZ_SEGS_MAX);
+                d->seqCap = r->segPitch;
                 d->parseFrom = (unsigned int)((size_t)sg * seg);
             }
         }
@@ -645,7 +650,7 @@ static size_t qzCoalescedBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSe
             size_t out = 0, carry = 0;
             int sg;
             for (sg = 0; sg < r->nSeg; sg++) {
-                const ZSTD_Sequence *q = bt->hSeqs + (size_t)i * QZ_BATCH_PITCH + (size_t)sg * (QZ_BATCH_PITCH / QZ_SEGS_MAX);
+                const ZSTD_Sequence *q = bt->hSeqs + (size_t)i * QZ_BATCH_PITCH + (size_t)sg * r->segPitch;
                 const size_t count = r->segCnt[sg];
                 if (count > 1) {
                     memcpy(outSeqs + out, q, (count - 1) * sizeof(ZSTD_Sequence));

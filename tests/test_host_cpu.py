@@ -90,15 +90,16 @@ def test_profile_tables_agree(plugin, oracle, level, block):
 
 
 def test_workspace_only_for_chain_levels(plugin):
-    """levels >= 5 keep their hash chains in device memory: 4 B per position of every block"""
+    """levels >= 5 keep their hash chains in device memory: per position of every work item a chain entry of four links (16 B)
+    and, for the history pass of segment items, its first link once more in a dense array (4 B)"""
     W = plugin.lib.qzstd_hip_workspace_bytes
     for level in range(1, 5):
         assert W(level, 100, 131072) == 0 and plugin.profile(level, 131072).chainDepth == 0
         assert plugin.profile(level, 131072).subTileLog == (6 if level == 2 else 0)
     for level in range(5, 13):
         assert plugin.profile(level, 131072).chainDepth in (8, 16, 32, 64) and plugin.profile(level, 131072).subTileLog == 6
-        assert W(level, 100, 131072) == 100 * 131072 * 16  # four links (16 B) per position
-        assert W(level, 3, 1000) == 3 * 1024 * 16
+        assert W(level, 100, 131072) == 100 * 131072 * 20
+        assert W(level, 3, 1000) == 3 * 1024 * 20
     assert W(6, 1, 131073) == 0 and W(0, 1, 1000) == 0
 
 

@@ -9,7 +9,7 @@ BM=qat-zstd-plugin_amd/test/benchmark
 make -s -C qat-zstd-plugin_amd/test benchmark >/dev/null 2>&1
 for L in ${LEVELS:-1}; do
 for T in ${THREADS:-1 16}; do
-  echo -n "L$L T=$T software : "; $BM -m0 -t$T -l${LOOPS:-4} -c131072 -L$L /tmp/e2e.bin 2>&1 | grep -o "[0-9.]* MB/s by the wall\|P50 [0-9.]*" | tr '\n' ' '; echo
-  echo -n "L$L T=$T announced: "; env $EXTRA $BM -m1 -H2 -t$T -l${LOOPS:-4} -c131072 -L$L /tmp/e2e.bin 2>&1 | grep -o "[0-9.]* MB/s by the wall\|P50 [0-9.]*" | tr '\n' ' '; echo
-  echo -n "L$L T=$T plain    : "; env $EXTRA $BM -m1 -t$T -l${LOOPS:-4} -c131072 -L$L /tmp/e2e.bin 2>&1 | grep -o "[0-9.]* MB/s by the wall\|P50 [0-9.]*" | tr '\n' ' '; echo
+  echo -n "L$L T=$T software : "; $BM -m0 -t$T -l${LOOPS:-4} -c${CHUNK:-131072} -L$L /tmp/e2e.bin 2>&1 | grep -o "[0-9.]* MB/s by the wall\|P50 [0-9.]*" | tr '\n' ' '; echo
+  echo -n "L$L T=$T announced: "; env $EXTRA $BM -m1 -H2 -t$T -l${LOOPS:-4} -c${CHUNK:-131072} -L$L /tmp/e2e.bin 2>&1 | grep -o "[0-9.]* MB/s by the wall\|P50 [0-9.]*" | tr '\n' ' '; echo
+  echo -n "L$L T=$T plain    : "; env $EXTRA $BM -m1 -t$T -l${LOOPS:-4} -c${CHUNK:-131072} -L$L /tmp/e2e.bin 2>&1 | grep -o "[0-9.]* MB/s by the wall\|P50 [0-9.]*" | tr '\n' ' '; echo
 done; done

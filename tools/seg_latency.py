@@ -9,6 +9,7 @@ import qz_bind as B, qz_corpus as K
 import torch
 
 def main():
+    only = os.environ.get("QZ_ONLY_LAST")
     levels = [int(a, 0) for a in sys.argv[1:]] or [1]
     plug = B.Plugin(); L = plug.lib
     data = K.system_corpus(64 * 131072)[0]
