@@ -204,7 +204,7 @@ def measured(run, target_s: float = 5.5, min_passes: int = 5, max_loops: int = 4
         return cal
     bytes_per_pass = cal.get("bytes_per_pass") or (cal.get("bytes_per_thread", 0) * cal.get("threads", 1)) or cal.get("bytes", 0)
     per_pass_s = bytes_per_pass / 1e6 / max(cal["MBps_wall"], 1e-9)
-    loops = int(min(max_loops, max(min_passes, -(-target_s // max(per_pass_s, 1e-6)))))
+    loops = int(min(max_loops, max(min_passes, -(-1.35 * target_s // max(per_pass_s, 1e-6)))))  # (the calibration run is the slower one: warm-up)
     r = run(loops)
     if "MBps_wall" not in r:
         return r
