@@ -177,6 +177,10 @@ typedef struct {
 #define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 20u)
 int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *req);
 int qzstd_hip_service_stop(int device);          /* asks the resident kernels to leave and waits for them; 0 = stopped */
+/* called by a caller that waits for its request: if the service has left meanwhile (idle exit, a free, a launch that needed the LDS)
+ * and requests wait in the ring, it is launched again (0); 1 = not now (memory is being freed, a launch that fills the LDS is in
+ * flight, the service is out of use): keep waiting, poke again */
+int qzstd_hip_service_poke(int device, int level);
 void qzstd_hip_service_mark_broken(int device);  /* a request timed out: stop and do not use the service again */
 /* out[0] launches of the service, [1] requests queued, [2] requests refused (another level resident), [3] broken,
  * [4] state (0 stopped, 1 running), [5] items finished, [6] items that gave up waiting for a slice, [7] workers */

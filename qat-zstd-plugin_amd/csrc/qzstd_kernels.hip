@@ -2229,17 +2229,27 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
     unsigned spins = 0;
     while ((st = __atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE)) == 2u && ++spins < (1u << 26)) {}
     if (st != 1u) {
+        /* the service left between the first look and the write (idle exit, a free, a launch that needs the LDS): it takes the
+         * ring up where it left it as soon as it is launched again — now if possible, else by the waiting caller's pokes
+         * (qzstd_hip_service_poke): a request that is in the ring is never abandoned */
         std::lock_guard<std::mutex> g(s.mu);
-        if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) == 0u) {
-            /* a stopped service takes the ring up where it left it; while memory is being freed it stays down and the
-             * caller's wait runs into its time-out — rather than that, the launch waits for the free to finish */
-            unsigned w = 0;
-            while (g_svcFreeze.load() > 0 && ++w < 2000u) { const struct timespec nap = { 0, 1000000 }; nanosleep(&nap, nullptr); }
-            if (s.broken || svc_launch_locked(device, s, level) != 0) return -1;
-        }
+        if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) == 0u && !s.broken && g_svcFreeze.load() == 0) (void)svc_launch_locked(device, s, level);
     }
     __atomic_fetch_add(&s.requests, 1ul, __ATOMIC_RELAXED);
     return 0;
+}
+
+int qzstd_hip_service_poke(int device, int level)
+{
+    if (device < 0 || device >= 64) return -1;
+    Service &s = g_svc[device];
+    if (!s.hs || s.broken) return 1;
+    if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) != 0u) return 0;
+    if (g_svcFreeze.load() > 0) return 1;
+    std::lock_guard<std::mutex> g(s.mu);
+    if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) != 0u) return 0;
+    if (__atomic_load_n(&s.hs->consumed, __ATOMIC_ACQUIRE) >= s.reserve.load()) return 0; /* nothing waits in the ring */
+    return svc_launch_locked(device, s, level) == 0 ? 0 : 1;
 }
 
 int qzstd_hip_service_stop(int device)
@@ -2254,6 +2264,8 @@ int qzstd_hip_service_stop(int device)
         (void)hipStreamSynchronize(s.sWork);
         (void)hipStreamSynchronize(s.sDisp);
     }
+    /* the device layer is being shut down: whoever wrote a request that was never taken has given up on it */
+    __atomic_store_n(&s.hs->consumed, (u64)s.reserve.load(), __ATOMIC_RELEASE);
     return r;
 }
 

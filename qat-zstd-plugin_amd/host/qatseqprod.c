@@ -1077,6 +1077,7 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
             if ((++polls & 63u) == 0u) {
                 const unsigned long dt = qzNowNs() - t0;
                 if (dt > limitNs) { bad = 1; break; }
+                if ((polls & 1023u) == 0u) (void)qzstd_hip_service_poke(sl->device, level); /* the service may have left with this request in its ring */
                 if (dt > spinNs) { const struct timespec nap = { 0, dt < 20000000ul ? 5000 : 200000 }; nanosleep(&nap, NULL); }
             }
         }

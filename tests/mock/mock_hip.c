@@ -109,6 +109,7 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
     }
     return 0;
 }
+int qzstd_hip_service_poke(int device, int level) { (void)device; (void)level; return 0; }
 int qzstd_hip_service_stop(int device) { (void)device; __sync_fetch_and_add(&gSvcStops, 1); return 0; }
 void qzstd_hip_service_mark_broken(int device) { (void)device; gSvcBroken = 1; }
 void qzstd_mock_service_repair(void) { gSvcBroken = 0; }

@@ -150,3 +150,51 @@ print("RESULT", len(bad), sum(a for a, _ in served), sum(b for _, b in served))
     res = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert int(res[1]) == 0 and int(res[3]) == 0, res
     assert int(res[2]) == (24 if service == "1" else 0), res
+
+
+def test_level3_announcements_beside_level1_callers(gpu_plugin):
+    """regression for a stall the fuzz driver found: a level-3 kernel of an announcement (its workgroups fill a CU's LDS) in flight
+    while per-block level-1 requests launch the resident service again — the workers took every CU, the kernel's remaining
+    workgroups waited for LDS and the dispatcher sat behind it in a shared hardware queue.  Two threads, two seconds: one announces
+    and compresses at level 3, one compresses unannounced at level 1; nothing may time out, fall back or be redone"""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys, threading, time
+sys.path.insert(0, %r)
+import qz_bind as B, qz_corpus as K
+z, plug = B.Zstd(), B.Plugin()
+assert plug.lib.QZSTD_startQatDevice() == 0
+data = K.by_name("system", 32 * 131072, seed=23)
+buf = (C.c_char * len(data)).from_buffer_copy(data)
+stop = time.time() + 2.0
+out = {}
+def run(level, announce):
+    st = plug.lib.QZSTD_createSeqProdState()
+    zc = z.cctx(level, producer=plug.producer_addr, state=st, fallback=False, validate=True)
+    n = 0
+    while time.time() < stop:
+        if announce: plug.lib.QZSTD_hintSource(st, buf, len(data), 131072, level)
+        for c in range(32):
+            blk = data[c * 131072:(c + 1) * 131072]
+            if announce:
+                cap = z.lib.ZSTD_compressBound(131072); dst = C.create_string_buffer(cap)
+                r = z.lib.ZSTD_compress2(zc, dst, cap, C.c_void_p(C.addressof(buf) + c * 131072), 131072)
+                assert not z.is_error(r), z.err(r)
+            else:
+                z.compress2(zc, blk)
+            n += 1
+    fs = (C.c_ulong * 8)(); plug.lib.QZSTD_failStats(st, C.byref(fs))
+    out[level] = (n, list(fs))
+    z.free(zc); plug.lib.QZSTD_freeSeqProdState(st)
+th = [threading.Thread(target=run, args=(3, True)), threading.Thread(target=run, args=(1, False))]
+[x.start() for x in th]; [x.join() for x in th]
+plug.lib.QZSTD_stopQatDevice()
+print("RESULT", out[3][0], out[1][0], out[3][1][0], out[1][1][0], out[3][1][6], out[1][1][6])
+''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert o.returncode == 0, o.stderr[-2000:]
+    res = [int(x) for x in [l for l in o.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:]]
+    assert res[0] > 100 and res[1] > 100, res          # both made progress (a stall would leave a handful of blocks)
+    assert res[2] == 0 and res[3] == 0, res            # no producer errors
+    assert res[4] == 0 and res[5] == 0, res            # nothing timed out in the service and was redone
