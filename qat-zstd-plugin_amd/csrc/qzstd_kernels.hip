@@ -236,6 +236,18 @@ __device__ __forceinline__ uint32_t head_len(const Src &s, const uint32_t (&oa)[
     return B >> 3;
 }
 
+/* the same, with the candidate's five dwords already requested (two candidates' loads in flight together) */
+__device__ __forceinline__ uint32_t head_cmp(const uint32_t (&oa)[4], const uint32_t (&Q)[5], uint32_t qs)
+{
+    uint32_t B = 128u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t x = oa[i] ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
+        B = umin(B, first_diff_bit(x) | (32u * (uint32_t)i));
+    }
+    return B >> 3;
+}
+
 /* first mismatching byte (0..32) of 32 bytes already byte-aligned in `pa` and the 32 bytes at q */
 __device__ __forceinline__ uint32_t tail_len(const Src &s, const uint32_t (&pa)[8], uint32_t q, uint32_t rq, bool far)
 {
@@ -1175,36 +1187,63 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                             }
                         }
                     }
+                    /* The four links of an entry, TWO AT A TIME: a wave's time is the chain of its LDS (and, for far candidates,
+                     * device-memory) round trips, one after the other — test, first 16 bytes, the next 32 ... — and the SIMDs are
+                     * half idle while 4.5 waves each wait for theirs.  The second link of a pair is tested against the best
+                     * BEFORE the first (a weaker test, still a necessary condition: it survives a little more often), both
+                     * tests are one round trip, both heads another; the updates follow in link order, so the result is
+                     * the sequential one. */
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t linkE = E[k];
-                        if (linkE != 0u && walked + (uint32_t)k < pf.chainDepth) {
-                            const uint32_t q = (linkE >> kTagBits) - 1u;
-                            const bool hit = (linkE & kTagMask) == tag && (pf.window == 0u || p - q <= pf.window);
-                            const bool far = p - q > kNear;
-                            bool maybe = hit && !QZ_ABLATED(2u) && !(QZ_ABLATED(64u) && far); /* profiling: 64 = what the HBM-side candidates cost */
-                            if (maybe && cl != 0u) {
-                                /* links come nearest first, so a later one can only win with MORE matching bytes than the best so
-                                 * far (its offset costs at least as much): it has to match at byte cl, in particular.  Four bytes
-                                 * ending there are compared before anything else (what zstd's chain search does too); a best
-                                 * that already fills the cap cannot be beaten at all.  Skips most of the full compares. */
-                                maybe = cl < cap &&
-                                        rd32_r(src, p + cl - 3u, ring_fwd(rp, cl - 3u), false) ==
-                                            rd32_r(src, q + cl - 3u, ring_fwd(ring_back(rp, p - q), cl - 3u), far);
-                            }
-                            if (maybe) {
-                                uint32_t l = head_len(src, oa, q, ring_back(rp, p - q), far);
-                                if (l == 16u && cap > 16u) {
-                                    for (;;) {
-                                        const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q, far);
-                                        l += c;
-                                        if (c < 32u || l >= cap) break;
-                                    }
+                    for (int kk = 0; kk < 4; kk += 2) {
+                        const uint32_t lA = E[kk], lB = E[kk + 1];
+                        const uint32_t qA = (lA >> kTagBits) - 1u, qB = (lB >> kTagBits) - 1u;
+                        const bool farA = p - qA > kNear, farB = p - qB > kNear;
+                        bool mA = lA != 0u && walked + (uint32_t)kk < pf.chainDepth && (lA & kTagMask) == tag && (pf.window == 0u || p - qA <= pf.window) &&
+                                  !QZ_ABLATED(2u) && !(QZ_ABLATED(64u) && farA); /* profiling: 64 = what the HBM-side candidates cost */
+                        bool mB = lB != 0u && walked + (uint32_t)kk + 1u < pf.chainDepth && (lB & kTagMask) == tag && (pf.window == 0u || p - qB <= pf.window) &&
+                                  !QZ_ABLATED(2u) && !(QZ_ABLATED(64u) && farB);
+                        const uint32_t rqA = ring_back(rp, p - qA), rqB = ring_back(rp, p - qB);
+                        if ((mA || mB) && cl != 0u) {
+                            /* links come nearest first, so a later one can only win with MORE matching bytes than the best so
+                             * far (its offset costs at least as much): it has to match at byte cl, in particular.  Four bytes
+                             * ending there are compared before anything else (what zstd's chain search does too); a best
+                             * that already fills the cap cannot be beaten at all.  Skips most of the full compares. */
+                            uint32_t vA = 0, vB = 0;
+                            const bool tA = mA && cl < cap, tB = mB && cl < cap;
+                            if (tA) vA = rd32_r(src, qA + cl - 3u, ring_fwd(rqA, cl - 3u), farA);
+                            if (tB) vB = rd32_r(src, qB + cl - 3u, ring_fwd(rqB, cl - 3u), farB);
+                            const uint32_t pw = rd32_r(src, p + cl - 3u, ring_fwd(rp, cl - 3u), false);
+                            mA = tA && vA == pw;
+                            mB = tB && vB == pw;
+                        }
+                        uint32_t QA[5] = { 0u, 0u, 0u, 0u, 0u }, QB[5] = { 0u, 0u, 0u, 0u, 0u };
+                        if (mA) load_dw_r<5>(src, qA, rqA, farA, QA);
+                        if (mB) load_dw_r<5>(src, qB, rqB, farB, QB);
+                        if (mA) {
+                            uint32_t l = head_cmp(oa, QA, qA & 3u);
+                            if (l == 16u && cap > 16u) {
+                                for (;;) {
+                                    const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - qA, farA);
+                                    l += c;
+                                    if (c < 32u || l >= cap) break;
                                 }
-                                l = umin(l, cap);
-                                const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q + 1u));
-                                if (l >= 4u && (cl == 0u || g > bg)) { cl = l; off = p - q; bg = g; }
                             }
+                            l = umin(l, cap);
+                            const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - qA + 1u));
+                            if (l >= 4u && (cl == 0u || g > bg)) { cl = l; off = p - qA; bg = g; }
+                        }
+                        if (mB && cl < cap) { /* (a best that fills the cap cannot be beaten: the sequential walk would not have looked) */
+                            uint32_t l = head_cmp(oa, QB, qB & 3u);
+                            if (l == 16u && cap > 16u) {
+                                for (;;) {
+                                    const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - qB, farB);
+                                    l += c;
+                                    if (c < 32u || l >= cap) break;
+                                }
+                            }
+                            l = umin(l, cap);
+                            const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - qB + 1u));
+                            if (l >= 4u && (cl == 0u || g > bg)) { cl = l; off = p - qB; bg = g; }
                         }
                     }
                     walked += cnt;
