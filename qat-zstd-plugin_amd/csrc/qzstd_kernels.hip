@@ -84,6 +84,7 @@ constexpr uint32_t kMirror = 128u;
 constexpr uint32_t kLook = 4608u;  /* bytes staged ahead of the current tile (covers the bounded extension) */
 constexpr uint32_t kNear = kRing - kLook - 3u * kTile - 1024u; /* kRing - kLook - 3 tiles of pipeline lag - slack */
 static_assert((kRing & kRingMask) == 0u && kRing >= 16384u, "the ring is a power of two of at least 16 KiB");
+constexpr size_t kLdsPerCu = 163840u; /* 160 KB */
 constexpr uint32_t kLdsBase = 16u; /* first LDS byte the kernel uses (csrc/qzstd_profile.c: QZ_LDS_CTRL covers it) */
 
 struct LaunchArgs {
@@ -1736,7 +1737,11 @@ struct Service {
     static constexpr int kBig = 64;
     hipEvent_t bigEv[kBig] = {};
     bool bigUsed[kBig] = {};
+    size_t bigLds[kBig] = {};   /* LDS per workgroup of the launch the event stands for */
     int bigNext = 0;
+    size_t lds = 0;             /* LDS of one worker of the service that runs (or ran last) */
+    bool wide = false;          /* a service whose workers leave no room for ANY batch workgroup on their CU (levels 3-4) has run on this
+                                 * device: from then on every launch is remembered by an event */
 };
 Service g_svc[64];
 std::atomic<int> g_svcFreeze{0}; /* > 0: memory is being freed (hipFree / hipHostFree wait for every stream of the device) */
@@ -2026,12 +2031,16 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
      * (levels 3-4 fill a CU) would wait for as long as requests keep the service alive — and the service must not come back
      * while such a launch is in flight: it is asked to leave first, and the launch is remembered by an event that the
      * service's next launch checks.  One mutex per device covers "stop, launch, record". */
-    const bool big = lds + qzstd_hip_lds_bytes(1, QZSTD_HIP_BLOCK_MAX) > 163840u;
+    /* Generally: a launch and a running service clash when one workgroup of each do not fit a CU's LDS together.  Levels 3-4
+     * clash with every service; a service of levels 3-4 clashes with every launch.  "Look at the service, stop it if it
+     * clashes, launch, remember" is one critical section per device. */
+    bool big = lds + qzstd_hip_lds_bytes(1, QZSTD_HIP_BLOCK_MAX) > kLdsPerCu;
     std::unique_lock<std::mutex> bigLock;
-    if (big && device >= 0 && device < 64) {
+    if (device >= 0 && device < 64) {
         Service &sv = g_svc[device];
         bigLock = std::unique_lock<std::mutex>(sv.mu);
-        if (sv.hs && __atomic_load_n(&sv.hs->state, __ATOMIC_ACQUIRE) != 0u) (void)svc_stop_locked(sv, 2000);
+        big = big || sv.wide;
+        if (sv.hs && __atomic_load_n(&sv.hs->state, __ATOMIC_ACQUIRE) != 0u && lds + sv.lds > kLdsPerCu) (void)svc_stop_locked(sv, 2000);
     }
     /* [long][rep][chain/turns: 0 none, 1 turns, 2 chain + turns] */
     static const void *const variants[2][2][3] = {
@@ -2091,10 +2100,15 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     if (big && bigLock.owns_lock()) {
         Service &sv = g_svc[device];
-        const int k = sv.bigNext;
+        int k = sv.bigNext;
+        for (int tries = 0; tries < Service::kBig && sv.bigUsed[k]; tries++) { /* an event whose launch has finished can be used again */
+            if (hipEventQuery(sv.bigEv[k]) != hipErrorNotReady) { (void)hipGetLastError(); sv.bigUsed[k] = false; break; }
+            k = (k + 1) % Service::kBig;
+        }
+        if (sv.bigUsed[k]) { (void)hipEventSynchronize(sv.bigEv[k]); (void)hipGetLastError(); } /* 64 launches in flight: wait for one */
         sv.bigNext = (k + 1) % Service::kBig;
         if (!sv.bigEv[k] && hipEventCreateWithFlags(&sv.bigEv[k], hipEventDisableTiming) != hipSuccess) { sv.bigEv[k] = nullptr; (void)hipGetLastError(); }
-        if (sv.bigEv[k] && hipEventRecord(sv.bigEv[k], (hipStream_t)stream) == hipSuccess) sv.bigUsed[k] = true;
+        if (sv.bigEv[k] && hipEventRecord(sv.bigEv[k], (hipStream_t)stream) == hipSuccess) { sv.bigUsed[k] = true; sv.bigLds[k] = lds; }
         else (void)hipGetLastError();
     }
     return 0;
@@ -2109,7 +2123,8 @@ const void *svc_worker_variant(const qzstd_hip_profile_t &p)
 {
 #define QZ_W(L, R, C, T) reinterpret_cast<const void *>(qzstd_service_worker<L, R, C, T>)
     if (p.chainDepth) return p.repWin ? QZ_W(false, true, true, true) : QZ_W(false, false, true, true);
-    if (p.longSize) return nullptr; /* levels 3-4: a worker would fill its CU's LDS and starve every other launch: batches */
+    if (p.longSize) return p.repWin ? QZ_W(true, true, false, false) : QZ_W(true, false, false, false); /* levels 3-4: a worker fills its CU's LDS
+                                                                                                         * (see Service::wide) */
     if (p.repWin) return p.subTileLog ? QZ_W(false, true, false, true) : QZ_W(false, true, false, false);
     return p.subTileLog ? QZ_W(false, false, false, true) : QZ_W(false, false, false, false);
 #undef QZ_W
@@ -2129,9 +2144,18 @@ int svc_launch_locked(int device, Service &s, int level)
     for (int k = 0; k < Service::kBig; k++) {
         if (!s.bigUsed[k]) continue;
         const hipError_t q = hipEventQuery(s.bigEv[k]);
-        if (q == hipErrorNotReady) return fail_msg("service: a launch that fills the CUs' LDS is in flight");
+        if (q == hipErrorNotReady) {
+            if (s.bigLds[k] + lds > kLdsPerCu) return fail_msg("service: a launch that cannot share a CU with its workers is in flight");
+            continue;
+        }
         (void)hipGetLastError();
         s.bigUsed[k] = false;
+    }
+    if (lds + qzstd_hip_lds_bytes(1, QZSTD_HIP_BLOCK_MAX) > kLdsPerCu && !s.wide) {
+        /* the first service of levels 3-4 on this device: launches up to now were not remembered (all of them go out under this
+         * mutex, so none can slip in): wait for them once */
+        s.wide = true;
+        QZ_CHECK(hipDeviceSynchronize(), "hipDeviceSynchronize(before the first service of levels 3-4)");
     }
     if (!s.hs) {
         hipDeviceProp_t prop;
@@ -2180,6 +2204,7 @@ int svc_launch_locked(int device, Service &s, int level)
     __atomic_store_n(&s.hs->quitReq, 0u, __ATOMIC_RELEASE);
     __atomic_store_n(&s.hs->state, 1u, __ATOMIC_RELEASE);
     s.level = level;
+    s.lds = lds;
     SvcHost *hsDev = nullptr;
     QZ_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&hsDev), s.hs, 0), "hipHostGetDevicePointer");
     uint32_t ctlOff = (uint32_t)(lds - 96u - kLdsBase), spin = (uint32_t)cfg.spinLimit;

@@ -90,7 +90,7 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
     uint32_t k;
     (void)device;
     if ((v && atoi(v) == 0) || gSvcBroken) return 1;
-    if (qzo_profile_for_level(level, r->srcLen, &pf) || pf.longSize) return 1; /* levels 3-4: not served by the real one either */
+    if (qzo_profile_for_level(level, r->srcLen, &pf)) return 1;
     if (pf.chainDepth && !r->dWork) { snprintf(gErr, sizeof gErr, "mock: the chain levels need dWork"); return -1; }
     if (r->nItems < 1 || r->nItems > QZSTD_HIP_SVC_MAX_ITEMS || r->slot >= QZSTD_HIP_SVC_MAX_SLOTS || (r->itemBytes & ((1u << pf.segLog) - 1u)) ||
         (size_t)(r->nItems - 1) * r->itemBytes >= r->srcLen) {

@@ -30,7 +30,7 @@ def check_request(oracle, lane, blk, level, item_bytes=4096):
             assert (g.offset, g.litLength, g.matchLength) == (w.offset, w.litLength, w.matchLength), "item %d sequence %d" % (k, i)
 
 
-@pytest.mark.parametrize("level", [1, 2, 0x101, 0x102])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 0x101, 0x102, 0x103])
 def test_service_items_equal_the_oracle(gpu_plugin, oracle, level):
     """every work item of a request — 4 KiB items, coarser items, ragged block sizes, degenerate content — bit-exact against
     qzo_find_sequences_from; the count words are the only completion signal"""
@@ -52,11 +52,9 @@ def test_service_items_equal_the_oracle(gpu_plugin, oracle, level):
 @pytest.mark.parametrize("level", [5, 6, 9, 12, 0x106])
 def test_service_chain_levels(gpu_plugin, oracle, level):
     """the chain levels through the service (every item links the block before it in its own scratch: the history pass of
-    qz_item), item by item against the oracle; levels 3-4 are not served (a worker would fill its CU's LDS and starve every
-    other launch)"""
+    qz_item), item by item against the oracle"""
     lane = gpu_plugin.service_lane(slot=9)
     try:
-        assert lane.run(K.text(5, 65536), 3) is None and lane.run(K.text(5, 65536), 4) is None
         data = K.by_name("system", 2 * 131072, seed=5)
         check_request(oracle, lane, data[:131072], level)
         check_request(oracle, lane, data[131072:][:100001], level)
@@ -198,3 +196,26 @@ print("RESULT", out[3][0], out[1][0], out[3][1][0], out[1][1][0], out[3][1][6], 
     assert res[0] > 100 and res[1] > 100, res          # both made progress (a stall would leave a handful of blocks)
     assert res[2] == 0 and res[3] == 0, res            # no producer errors
     assert res[4] == 0 and res[5] == 0, res            # nothing timed out in the service and was redone
+
+
+def test_wide_service_and_batch_launches_take_turns(gpu_plugin, oracle):
+    """a worker of levels 3-4 fills its CU's LDS: no batch workgroup fits beside it.  A batch launch asks such a service to leave first
+    and the service does not come back while the launch is in flight; results stay the oracle's on both paths, nothing hangs"""
+    L = gpu_plugin.lib
+    info = (C.c_ulong * 8)()
+    lane = gpu_plugin.service_lane(slot=11)
+    try:
+        data = K.by_name("system", 8 * 131072, seed=21)
+        blocks = [data[o:o + 131072] for o in range(0, len(data), 131072)]
+        for rnd in range(6):
+            check_request(oracle, lane, blocks[rnd], 3)                 # the level-3 service (launched again if it had to leave)
+            for lv in (1, 3, 6):                                        # batch launches of every size: the service leaves for each
+                counts, seqs, stride = gpu_plugin.find_batch(blocks[:4], lv)
+                for b, n in zip(blocks[:4], counts):
+                    want_n, _ = oracle.find(oracle.profile(lv, len(b)), b, cap=stride)
+                    assert n == want_n
+                assert L.qzstd_hip_service_info(0, info) == 0 and info[4] == 0, "a launch ran beside a level-3 worker"
+        check_request(oracle, lane, blocks[7], 1)                       # and a level-1 service after it
+        assert L.qzstd_hip_service_stop(0) == 0
+    finally:
+        lane.close()

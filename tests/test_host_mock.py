@@ -515,8 +515,8 @@ def test_service_path_serves_unchanged_callers(mock, zstd, oracle, level, chunk)
 
 
 def test_service_coarser_items_and_other_levels(mock, zstd, oracle):
-    """QZSTD_HIP_SERVICE_ITEM: items of several segments; the chain levels (6, 12: a scratch per item) are served too, levels
-    3-4 (a worker would fill its CU's LDS) are not; requests the dispatcher hands back (another level is resident) take the launch path"""
+    """QZSTD_HIP_SERVICE_ITEM: items of several segments; levels 3-4 and the chain levels (6, 12: a scratch per item) are served
+    too; requests the dispatcher hands back (another level is resident) take the launch path"""
     chunk = 131072
     data = K.by_name("system", 3 * chunk, seed=3)
     buf = (C.c_char * len(data)).from_buffer_copy(data)
@@ -527,7 +527,7 @@ def test_service_coarser_items_and_other_levels(mock, zstd, oracle):
         assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1) == oracle_frames(zstd, oracle, data, chunk, 1)
         assert fail_stats(mock, st)[7] == 3
         L.QZSTD_freeSeqProdState(st)
-    for level, served in ((3, 0), (6, 1), (12, 1)):  # levels 3-4 fill a CU's LDS: batches
+    for level, served in ((3, 1), (6, 1), (12, 1)):
         st = L.QZSTD_createSeqProdState()
         assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), chunk, chunk, level) == oracle_frames(zstd, oracle, data[:chunk], chunk, level)
         assert fail_stats(mock, st)[7] == served and stats_of(mock, st)[1] == 1
