@@ -697,7 +697,7 @@ def main():
                 with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
                     f.write(sample[:len(sample) // 4])
                     f6 = f.name
-                for key, lv, blk in (("level6", 6, block), ("level12_32k", 12, 32768)):
+                for key, lv, blk in (("level3", 3, block), ("level6", 6, block), ("level12_32k", 12, 32768)):  # level 3 = libzstd's default
                     swl = c_benchmark(f6, blk, lv, base_t, mode=0, loops=1)
                     sw14l = c_benchmark(f6, blk, lv, base_t, mode=0, loops=2, tool="benchmark_sw")
                     pl = c_benchmark(f6, blk, lv, base_t, mode=1, hint=8, loops=2)

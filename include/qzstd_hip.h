@@ -155,7 +155,8 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
  * Resident kernels (one worker workgroup per CU + a one-wave dispatcher) are launched by the first request and leave
  * after QZSTD_HIP_SERVICE_IDLE_US (default 20000) without work, when memory is freed, or on qzstd_hip_service_stop().
  * Served: every level; the workers serve ONE level (profile) at a time — a request of another level is handed back while they are
- * resident — and leave when a launch needs the LDS they hold (levels 3-4 fill a CU).
+ * resident — and leave when a launch needs the LDS they hold: a launch and a service whose workgroups do not fit a CU's 160 KB
+ * together take turns (batch launches of levels 3-4 against any service, any batch launch against a service of levels 3-4).
  *
  *   qzstd_hip_service_submit   0 = queued;  1 = not served (level, QZSTD_HIP_SERVICE=0, another level is resident, the
  *                              service is down): the caller takes the launch path;  < 0 = error
