@@ -700,8 +700,8 @@ def main():
                 for key, lv, blk in (("level3", 3, block), ("level6", 6, block), ("level12_32k", 12, 32768)):  # level 3 = libzstd's default
                     swl = c_benchmark(f6, blk, lv, base_t, mode=0, loops=1)
                     sw14l = c_benchmark(f6, blk, lv, base_t, mode=0, loops=2, tool="benchmark_sw")
-                    pl = c_benchmark(f6, blk, lv, base_t, mode=1, hint=8, loops=2)
-                    pp = c_benchmark(f6, blk, lv, base_t, mode=1, loops=2)
+                    pl = c_benchmark(f6, blk, lv, base_t, mode=1, hint=8, loops=10)  # (about a second each: the device layer's start-up is inside the wall clock)
+                    pp = c_benchmark(f6, blk, lv, base_t, mode=1, loops=10)
                     if "csize" in pl and "csize" in swl:
                         pl["csize_vs_sw"] = round(pl["csize"] / swl["csize"], 4)
                         pl["ratio_within_2pct"] = pl["csize"] <= swl["csize"] * 1.02
