@@ -2092,11 +2092,17 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
 #ifdef QZ_DEBUG_DUMP
     { const char *ab = getenv("QZSTD_HIP_ABLATE"); a.dbg = ab ? (uint32_t)atoi(ab) : 0u; }
 #endif
+#ifdef QZ_DEBUG_DUMP
+    size_t ldsLaunch = lds; /* profiling: QZSTD_HIP_LDS_PAD = extra bytes per workgroup (fewer workgroups per CU: what occupancy is worth) */
+    { const char *pad = getenv("QZSTD_HIP_LDS_PAD"); if (pad) ldsLaunch += (size_t)atoi(pad); }
+#else
+    const size_t ldsLaunch = lds;
+#endif
     const dim3 grid(nBlocks), wg(kThreads);
     const void *kernel = variants[a.prof.longSize ? 1 : 0][a.prof.repWin ? 1 : 0][a.prof.chainDepth ? 2 : (a.prof.subTileLog ? 1 : 0)];
     void *kargs[1] = { &a };
     if (!kernel) return fail_msg("qzstd_hip_find_sequences: unsupported profile (no kernel variant)");
-    QZ_CHECK(hipLaunchKernel(kernel, grid, wg, kargs, lds, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
+    QZ_CHECK(hipLaunchKernel(kernel, grid, wg, kargs, ldsLaunch, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     if (big && bigLock.owns_lock()) {
         Service &sv = g_svc[device];
