@@ -180,7 +180,8 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
 int qzstd_hip_service_stop(int device);          /* asks the resident kernels to leave and waits for them; 0 = stopped */
 /* called by a caller that waits for its request: if the service has left meanwhile (idle exit, a free, a launch that needed the LDS)
  * and requests wait in the ring, it is launched again (0); 1 = not now (memory is being freed, a launch that fills the LDS is in
- * flight, the service is out of use): keep waiting, poke again */
+ * flight): keep waiting, poke again; 2 = the service has been taken out of use (a request timed out) and has left: requests it
+ * has not answered will not be answered */
 int qzstd_hip_service_poke(int device, int level);
 void qzstd_hip_service_mark_broken(int device);  /* a request timed out: stop and do not use the service again */
 /* out[0] launches of the service, [1] requests queued, [2] requests refused (another level resident), [3] broken,

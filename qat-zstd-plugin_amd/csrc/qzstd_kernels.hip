@@ -2313,8 +2313,9 @@ int qzstd_hip_service_poke(int device, int level)
 {
     if (device < 0 || device >= 64) return -1;
     Service &s = g_svc[device];
-    if (!s.hs || s.broken) return 1;
+    if (!s.hs) return 1;
     if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) != 0u) return 0;
+    if (s.broken) return 2; /* out of use and gone: what it has not answered by now it never will */
     if (g_svcFreeze.load() > 0) return 1;
     std::lock_guard<std::mutex> g(s.mu);
     if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) != 0u) return 0;

@@ -1077,7 +1077,8 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
             if ((++polls & 63u) == 0u) {
                 const unsigned long dt = qzNowNs() - t0;
                 if (dt > limitNs) { bad = 1; break; }
-                if ((polls & 1023u) == 0u) (void)qzstd_hip_service_poke(sl->device, level); /* the service may have left with this request in its ring */
+                /* the service may have left with this request in its ring: it is launched again; or for good (another request timed out) */
+                if ((polls & 1023u) == 0u && qzstd_hip_service_poke(sl->device, level) == 2 && __atomic_load_n(&sl->vCount[k], __ATOMIC_ACQUIRE) == 0u) { bad = 1; break; }
                 if (dt > spinNs) { const struct timespec nap = { 0, dt < 20000000ul ? 5000 : 200000 }; nanosleep(&nap, NULL); }
             }
         }
@@ -1088,10 +1089,10 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
             unsigned long in[8] = { 0 }, dg[8] = { 0 };
             (void)qzstd_hip_service_info(sl->device, in);
             (void)qzstd_hip_service_debug(sl->device, dg);
-            QZ_LOG(1, "device %d: service request timed out after %d ms (service: %lu launch(es), %lu request(s), state %lu; dispatcher: %lu poll(s), "
+            QZ_LOG(1, "device %d: service request not answered after %lu ms (limit %d; service: %lu launch(es), %lu request(s), state %lu; dispatcher: %lu poll(s), "
                       "%lu request(s) taken, %lu item(s) queued; workers: %lu started, %lu item(s) picked up, %lu finished, %lu gave up on a slice; ring: %lu "
                       "consumed, %lu reserved, quit %lu, frozen %lu; this request: %zu item(s), level %#x)\n",
-                   sl->device, gProc.timeoutMs, in[0], in[1], in[4], dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], in[6], dg[6],
+                   sl->device, (qzNowNs() - t0) / 1000000ul, gProc.timeoutMs, in[0], in[1], in[4], dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], in[6], dg[6],
                    dg[7] & 0x1FFFFFFFFFFFFFFFul, dg[7] >> 62, (dg[7] >> 61) & 1ul, nItems, (unsigned)level);
         }
         sl->vStuck = 1;

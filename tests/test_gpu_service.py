@@ -112,24 +112,26 @@ def test_service_concurrent_callers_idle_exit_and_frees(gpu_plugin, oracle):
         ln.close()
 
 
-@pytest.mark.parametrize("service", ["1", "0"])
-def test_unchanged_callers_through_the_plugin(gpu_plugin, zstd, oracle, service, tmp_path):
+@pytest.mark.parametrize("service,level", [("1", 1), ("0", 1), ("1", 3), ("1", 6)])
+def test_unchanged_callers_through_the_plugin(gpu_plugin, zstd, oracle, service, level, tmp_path):
     """the callback path in a child process (the switch is read at QZSTD_startQatDevice): frames of libzstd + plugin equal the
-    frames of libzstd + oracle with the service on and off, 8 threads; the service counter says who served"""
+    frames of libzstd + oracle with the service on and off, 8 threads, levels 1 / 3 (libzstd's default) / 6; the service counter says who
+    served"""
     import subprocess
     import sys
     code = r'''
 import ctypes as C, os, sys, threading
 sys.path.insert(0, %r)
 import qz_bind as B, qz_corpus as K
+LEVEL = int(os.environ["QZ_TEST_LEVEL"])
 z, orc, plug = B.Zstd(), B.Oracle(), B.Plugin()
 assert plug.lib.QZSTD_startQatDevice() == 0
 data = K.by_name("system", 24 * 131072, seed=21)
 bad = []
 def run(t):
     st = plug.lib.QZSTD_createSeqProdState()
-    zc = z.cctx(1, producer=plug.producer_addr, state=st, fallback=False, validate=True)
-    zo = z.cctx(1, producer=orc.producer_addr, state=None, fallback=False, validate=True)
+    zc = z.cctx(LEVEL, producer=plug.producer_addr, state=st, fallback=False, validate=True)
+    zo = z.cctx(LEVEL, producer=orc.producer_addr, state=None, fallback=False, validate=True)
     for c in range(t, 24, 8):
         blk = data[c * 131072:(c + 1) * 131072][:131072 - 1000 * (c %% 3)]
         if z.compress2(zc, blk) != z.compress2(zo, blk): bad.append(c)
@@ -143,7 +145,7 @@ plug.lib.QZSTD_stopQatDevice()
 print("RESULT", len(bad), sum(a for a, _ in served), sum(b for _, b in served))
 ''' % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, QZSTD_HIP_SERVICE=service))
+                         env=dict(os.environ, QZSTD_HIP_SERVICE=service, QZ_TEST_LEVEL=str(level)))
     assert out.returncode == 0, out.stderr[-2000:]
     res = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert int(res[1]) == 0 and int(res[3]) == 0, res
