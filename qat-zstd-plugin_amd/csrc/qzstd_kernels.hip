@@ -696,6 +696,66 @@ __device__ __forceinline__ uint32_t chain_insert_window(uint32_t *tbl, uint32_t 
     return vk ? (predLane != lane ? fromLane : prd) : 0u;
 }
 
+/* Chain levels: the INSERTS of one tile (512 positions), by ONE wave — the parse wave, which has next to nothing to do at these
+ * levels, one tile ahead of the matchers: it hashes the tile's positions itself (the bytes are in the ring long before the matchers get
+ * there), updates the head table window by window in position order and leaves every position's exact predecessor in its slot
+ * ((position + 1) << 14 | tag, 0 = none) in P1[0..512).  LDS operations of one wave execute in order, so the eight windows are
+ * pipelined back to back and still see each other exactly as sequential inserts would.  `ordered`: this device's LDS serves the
+ * lanes of one returning ds_max that hit the same address in lane order (probed, probe_lds_order) — what a lane gets back then IS its
+ * predecessor; otherwise the positions of one window that share a slot are ordered with ballots.  The head table belongs to this
+ * wave alone (the matchers only read P1). */
+__device__ __forceinline__ void chain_insert_tile(const qzstd_hip_profile_t &pf, const Src &src, uint32_t *tbl, uint32_t *P1, uint32_t t0,
+                                                  uint32_t n, uint32_t nh, uint32_t lane, bool ordered)
+{
+    const uint32_t segE = rdfirst(seg_end(pf, t0, n)); /* a tile lies inside one segment */
+    uint32_t stv[kWin];
+#pragma unroll
+    for (uint32_t k = 0; k < kWin; k++) {
+        const uint32_t p = t0 + 64u * k + lane;
+        const uint32_t mixH = rd32u(src, p, false) * kPrime1; /* the chain levels hash four bytes */
+        stv[k] = (p < nh && p + 4u <= segE) ? (__umulhi(mixH, pf.tableSize) | (((mixH >> 3) & kTagMask) << 16)) : kNone;
+    }
+    if (ordered) {
+#pragma unroll
+        for (uint32_t k = 0; k < kWin; k++) {
+            const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
+            uint32_t pred = 0u;
+            if (stv[k] != kNone) pred = atomicMax(&tbl[stv[k] & 0xFFFFu], mineK);
+            P1[64u * k + lane] = pred;
+        }
+    } else {
+        /* the portable path, one window at a time (it is there for devices whose LDS does not pass the probe, not for speed: kept out
+         * of the kernel's register budget) */
+#pragma unroll 1
+        for (uint32_t k = 0; k < kWin; k++) {
+            const uint32_t st = stv[k];
+            const bool vk = st != kNone;
+            const uint32_t slotK = st & 0xFFFFu;
+            const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (st >> 16);
+            uint32_t prd = 0u, fin = mineK;
+            if (vk) {
+                uint32_t *e = &tbl[slotK];
+                prd = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                atomicMax(e, mineK);
+                fin = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            /* lanes that are not the newest of their slot in this window have a same-slot lane above them */
+            u64 rem = __ballot(fin != mineK);
+            uint32_t predLane = lane;
+            while (rem) {
+                const uint32_t s0 = rdlane(slotK, (uint32_t)__builtin_ctzll(rem));
+                const bool in = vk && slotK == s0;
+                const u64 grp = __ballot(in);
+                const u64 lower = grp & below(lane);
+                if (in && lower) predLane = 63u - (uint32_t)__builtin_clzll(lower); /* the nearest lower lane of the group */
+                rem &= ~grp;
+            }
+            const uint32_t fromLane = (uint32_t)__shfl((int)mineK, (int)predLane);
+            P1[64u * k + lane] = vk ? (predLane != lane ? fromLane : prd) : 0u;
+        }
+    }
+}
+
 /* One work item (a block, or a run of whole segments of one): `blk` describes it, gsrc = the block's bytes in device memory,
  * out = the item's result region, chainB = its chain entries (CHAIN), p1B = its array of first links (CHAIN, segment items).  Returns, in the parse wave, the item's sequence
  * count including the delimiter or QZSTD_HIP_NSEQ_ERROR (every thread returns that for an item that is refused); the matcher
@@ -740,7 +800,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
     uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kPvStride] per-position parse words         */
     uint32_t *turnCtr = pv + 2u * kPvStride;           /* whose turn it is to update the tables (TURNS)   */
-    uint32_t *slotTag = turnCtr + 16u;                 /* [kTile] (CHAIN) slot | tag << 16 of the tile's positions, for the insert wave */
+    uint32_t *P1odd = turnCtr + 16u;                   /* [kTile] (CHAIN) predecessors of the odd tiles' positions (the even tiles': nearTab's words) */
     const uint4 *g128 = reinterpret_cast<const uint4 *>(gsrc);
     Src src;
     src.ring = (LdsWords)ring32;
@@ -948,11 +1008,12 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     if (lane == 0u) srecT[0] = st.nseq; /* the records carry indices relative to this */
                     parse_rep_span(pf, src, pvT, base, base + 64u * kSplit, n, nh, lane, st);
                 }
+                if (CHAIN && it == itBegin && it < nTiles) chain_insert_tile(pf, src, tbl, (it & 1u) ? P1odd : nearTab, it << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
-                if (CHAIN) __syncthreads(); /* B1b: the matchers' insert step */
                 QZ_PLAP(pW1)
                 if (work) parse_rep_span(pf, src, pvT, base, base + kTile, n, nh, lane, st);
+                if (CHAIN && it + 1u < nTiles) chain_insert_tile(pf, src, tbl, ((it + 1u) & 1u) ? P1odd : nearTab, (it + 1u) << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI2)
                 __syncthreads(); /* B2 */
                 QZ_PLAP(pW2)
@@ -967,13 +1028,14 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 if (work)
                     parse_tile<0, kSplit>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
                                           k << kTileLog, n, lane, st);
+                if (CHAIN && it == itBegin && it < nTiles) chain_insert_tile(pf, src, tbl, (it & 1u) ? P1odd : nearTab, it << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
-                if (CHAIN) __syncthreads(); /* B1b: the matchers' insert step */
                 QZ_PLAP(pW1)
                 if (work)
                     parse_tile<kSplit, kWin>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
                                              k << kTileLog, n, lane, st);
+                if (CHAIN && it + 1u < nTiles) chain_insert_tile(pf, src, tbl, ((it + 1u) & 1u) ? P1odd : nearTab, (it + 1u) << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI2)
                 __syncthreads(); /* B2 */
                 QZ_PLAP(pW2)
@@ -1049,7 +1111,6 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             slot = __umulhi(mix, pf.tableSize);
             nslot = mix >> nearShift;
             if (!TURNS) old = tbl[slot]; /* with turns the slot is read when the wave's turn comes */
-            if (CHAIN) old = tbl[slot];  /* the slot before the tile: if no earlier position of this tile shares it, that IS the predecessor */
             if (pf.nearTab && !history) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
             if (validL) { /* second table, keyed by the first 8 bytes */
                 const uint32_t m8 = (v * kPrime1) ^ (oa[1] * kPrime2);
@@ -1059,11 +1120,11 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             }
         }
         uint4 pre = make_uint4(0u, 0u, 0u, 0u);
-        if (CHAIN) {
-            /* the chain entry of that probable predecessor, fetched now so that it is there when the inserts are done (a
-             * position of an earlier tile: its entry was stored at least one barrier ago) */
-            if (valid && old != 0u) pre = chainB[(old >> kTagBits) - 1u];
-            slotTag[tid] = valid ? (slot | (((mix >> 3) & kTagMask) << 16)) : kNone;
+        if (CHAIN && it != itBegin) {
+            /* the chain entry of the predecessor (left by the parse wave during the previous tile), fetched now if that is a position of an
+             * earlier tile: its entry was stored at least one barrier ago */
+            old = valid ? ((it & 1u) ? P1odd : nearTab)[tid] : 0u;
+            if (old != 0u && (old >> kTagBits) - 1u < t0) pre = chainB[(old >> kTagBits) - 1u];
         }
         QZ_LAP(dI1)
         __syncthreads(); /* B1 */
@@ -1080,76 +1141,22 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         if (CHAIN) {
             /* Levels >= 5: exact hash chains (oracle: qzo_candidates_chain): every position gets its exact predecessor in
              * its slot, and walks chainDepth links from there.
-             *  - INSERT.  One wave (wave 2) updates the head table for the whole tile, window by window: read the slot,
-             *    ds_max the own entry, read the slot back.  LDS operations of one wave execute in order, so the eight
-             *    windows are pipelined back to back and still see each other exactly as sequential inserts would; no
-             *    hand-over between waves.  Positions of one window that share a slot are ordered with ballots (the
-             *    read-back differs from the own entry for all but the newest of them).  Result: P1T[i] = predecessor
-             *    entry ((position + 1) << 14 | tag, 0 = none) of position t0 + i.
+             *  - INSERT.  Done by the parse wave one tile ahead (chain_insert_tile): P1T[i] = predecessor entry
+             *    ((position + 1) << 14 | tag, 0 = none) of position t0 + i is there when the matchers arrive; no barrier, no wave
+             *    of theirs spent on it (it used to be a serial section of wave 2 with the other seven waiting: 4 % of a tile).
              *  - CHAIN ENTRIES hold up to FOUR links (predecessor, its predecessor, ...), so a walk needs a dependent
              *    load only every fourth link.  The entry of p = {P1} + the first three links of P1's entry: prefetched in
              *    interval 1 when P1 lies in an earlier tile; hopped together from P1T when it lies in this tile (an
              *    entry may then be shorter than four — the walk simply continues from its last link).  Entries go to
              *    device memory (args.chain, 16 B per position); later tiles find them there. */
-            uint32_t *P1T = nearTab; /* [kTile] */
+            const uint32_t *P1T = (it & 1u) ? P1odd : nearTab; /* [kTile] this tile's predecessors */
             const uint32_t tag = (mix >> 3) & kTagMask;
-            if (wave == 2u) { /* not wave 0 or 4: those share their SIMD with the parse wave */
-                uint32_t stv[kWin];
-#pragma unroll
-                for (uint32_t k = 0; k < kWin; k++) stv[k] = slotTag[64u * k + lane];
-                if (args.orderedLds) {
-                    /* ONE returning ds_max per window: the LDS serves the lanes of an instruction that hit the same address in
-                     * lane order, so what a lane gets back — the slot before its own insert — is exactly its predecessor: the
-                     * nearest lower lane of its slot in this window, else the newest earlier position (or 0).  Not an
-                     * architectural promise: probe_lds_order() checks it on every device before this path is used. */
-#pragma unroll
-                    for (uint32_t k = 0; k < kWin; k++) {
-                        const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
-                        uint32_t pred = 0u;
-                        if (stv[k] != kNone) pred = atomicMax(&tbl[stv[k] & 0xFFFFu], mineK);
-                        P1T[64u * k + lane] = pred;
-                    }
-                } else {
-                    uint32_t prd[kWin], fin[kWin];
-#pragma unroll
-                    for (uint32_t k = 0; k < kWin; k++) {
-                        const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
-                        prd[k] = 0u;
-                        fin[k] = mineK;
-                        if (stv[k] != kNone) {
-                            uint32_t *e = &tbl[stv[k] & 0xFFFFu];
-                            prd[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            atomicMax(e, mineK);
-                            fin[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t k = 0; k < kWin; k++) {
-                        const bool vk = stv[k] != kNone;
-                        const uint32_t slotK = stv[k] & 0xFFFFu;
-                        const uint32_t mineK = ((t0 + 64u * k + lane + 1u) << kTagBits) | (stv[k] >> 16);
-                        /* lanes that are not the newest of their slot in this window have a same-slot lane above them */
-                        u64 rem = __ballot(fin[k] != mineK);
-                        uint32_t predLane = lane;
-                        while (rem) {
-                            const uint32_t s0 = rdlane(slotK, (uint32_t)__builtin_ctzll(rem));
-                            const bool in = vk && slotK == s0;
-                            const u64 grp = __ballot(in);
-                            const u64 lower = grp & below(lane);
-                            if (in && lower) predLane = 63u - (uint32_t)__builtin_clzll(lower); /* the nearest lower lane of the group */
-                            rem &= ~grp;
-                        }
-                        const uint32_t fromLane = (uint32_t)__shfl((int)mineK, (int)predLane);
-                        P1T[64u * k + lane] = vk ? (predLane != lane ? fromLane : prd[k]) : 0u;
-                    }
-                }
-            }
-            __syncthreads(); /* B1b */
             /* the entry of the own position */
             uint32_t E[4] = { 0u, 0u, 0u, 0u };
             if (valid) {
                 E[0] = P1T[tid];
-                if (E[0] != 0u && (E[0] >> kTagBits) - 1u < t0) { /* predecessor in an earlier tile: == `old`, whose entry is here */
+                if (E[0] != 0u && (E[0] >> kTagBits) - 1u < t0) { /* predecessor in an earlier tile: its entry is here (the item's first tile: fetched now) */
+                    if (it == itBegin) pre = chainB[(E[0] >> kTagBits) - 1u];
                     E[1] = pre.x; E[2] = pre.y; E[3] = pre.z;
                 } else {
 #pragma unroll
