@@ -1020,9 +1020,9 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
 {
     QZSTD_Slot_T *sl;
     qzstd_hip_svc_req_t rq;
-    size_t itemBytes, nItems, k, out = 0, carry = 0, total = 1;
+    size_t itemBytes, nItems, k, out = 0, carry = 0;
     unsigned long t0, spinNs, limitNs;
-    int i, rc, rejected = 0, bad = 0;
+    int i, rc, rejected = 0, bad = 0, wrong = 0;
 
     if (!gProc.service || srcSize == 0) return QZ_NOT_SERVED;
     itemBytes = (size_t)gProc.svcItemBytes;
@@ -1066,11 +1066,13 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
         QZ_LOG(1, "service request not queued: %s\n", qzstd_hip_last_error());
         return QZ_NOT_SERVED; /* the launch path may still work */
     }
-    /* poll the count words, last item first (the one with the longest history in front of it): busy for svcSpinUs, then naps */
+    /* poll the count words in item order — the items finish roughly in that order (the later, the more history in front of it) — and
+     * JOIN every item's list as it arrives (the trailing literals of one flow into the first sequence of the next): by the time the
+     * last item is in, the rest of the block's list stands.  Busy for svcSpinUs, then naps. */
     t0 = qzNowNs();
     spinNs = (unsigned long)gProc.svcSpinUs * 1000ul;
     limitNs = (unsigned long)gProc.timeoutMs * 1000000ul;
-    for (k = nItems; k-- > 0; ) {
+    for (k = 0; k < nItems; k++) {
         unsigned polls = 0;
         while (__atomic_load_n(&sl->vCount[k], __ATOMIC_ACQUIRE) == 0u) {
             __builtin_ia32_pause();
@@ -1083,6 +1085,19 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
             }
         }
         if (bad) break;
+        if (!wrong) { /* (after a wrong item the rest is only waited for: the slot's buffers are in use until every count is in) */
+            const unsigned int cnt = sl->vCount[k];
+            const ZSTD_Sequence *q = sl->vSeqs + k * rq.seqCapPerItem;
+            if (cnt == QZSTD_HIP_NSEQ_REJECTED) { rejected = 1; break; } /* handed back whole: nothing of it was queued */
+            if (cnt == QZSTD_HIP_NSEQ_ERROR || cnt > rq.seqCapPerItem || out + cnt >= outSeqsCapacity - 1) { wrong = 1; continue; } /* capacity rule, reference :1318-1322 */
+            if (cnt > 1) {
+                memcpy(outSeqs + out, q, (cnt - 1) * sizeof(ZSTD_Sequence));
+                outSeqs[out].litLength += (unsigned int)carry;
+                out += cnt - 1;
+                carry = 0;
+            }
+            carry += q[cnt - 1].litLength;
+        }
     }
     if (bad) { /* reference: the 2 s poll limit, :1261-1285 */
         {
@@ -1103,29 +1118,11 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
         s->redoneAlone++;
         return QZ_NOT_SERVED;
     }
-    for (k = 0; k < nItems && !bad; k++) {
-        const unsigned int cnt = sl->vCount[k];
-        if (cnt == QZSTD_HIP_NSEQ_REJECTED) rejected = 1;
-        else if (cnt == QZSTD_HIP_NSEQ_ERROR || cnt > rq.seqCapPerItem) bad = 1; /* an item's region was too small: capacity rule */
-        else total += cnt - 1u;
-    }
     if (rejected) { qzReleaseSlot(i); return QZ_NOT_SERVED; }
-    if (bad || total >= outSeqsCapacity - 1) { /* reference :1318-1322 */
+    if (wrong) {
         qzReleaseSlot(i);
         qzCause = QZ_CAUSE_CAPACITY;
         return ZSTD_SEQUENCE_PRODUCER_ERROR;
-    }
-    /* join the items' lists: the trailing literals of one flow into the first sequence of the next */
-    for (k = 0; k < nItems; k++) {
-        const ZSTD_Sequence *q = sl->vSeqs + k * rq.seqCapPerItem;
-        const size_t count = sl->vCount[k];
-        if (count > 1) {
-            memcpy(outSeqs + out, q, (count - 1) * sizeof(ZSTD_Sequence));
-            outSeqs[out].litLength += (unsigned int)carry;
-            out += count - 1;
-            carry = 0;
-        }
-        carry += q[count - 1].litLength;
     }
     outSeqs[out].offset = 0;
     outSeqs[out].litLength = (unsigned int)carry;
