@@ -29,8 +29,11 @@ def test_fuzz_host_logic_under_asan_ubsan_over_the_mock(tmp_path):
                            "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-pthread"] + INC + ["-o", exe] + srcs +
                           [zlib, "-Wl,-rpath," + os.path.dirname(zlib)])
     # bounded for the CPU suite (the oracle under ASan walks ~1 MB/s at the chain levels): buffers up to 384 KiB
-    for seed, iters, env in ((1, 40, {}), (2, 30, {"QZSTD_HIP_LOOKAHEAD": "1"}), (3, 20, {"QZSTD_HIP_COALESCE": "0"}),
-                             (4, 20, {"QZSTD_MOCK_DEVICES": "3", "QZSTD_HIP_EXT_REPCODES": "1"})):
+    # (the mock's service runs the oracle once per work item, each over the block up to the item's end: the default 32 items per block
+    # only in the first run, coarser items in the others)
+    for seed, iters, env in ((1, 16, {}), (2, 30, {"QZSTD_HIP_LOOKAHEAD": "1", "QZSTD_HIP_SERVICE_ITEM": "32768"}),
+                             (3, 20, {"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SERVICE_ITEM": "65536"}),
+                             (4, 20, {"QZSTD_MOCK_DEVICES": "3", "QZSTD_HIP_EXT_REPCODES": "1", "QZSTD_HIP_SERVICE_ITEM": "32768"})):
         out = subprocess.run([exe, str(seed), str(iters), "384"], capture_output=True, text=True, timeout=900,
                              env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", **env))
         assert out.returncode == 0 and "fuzz ok" in out.stdout, (env, (out.stdout + out.stderr)[-1500:])
