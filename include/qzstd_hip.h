@@ -76,7 +76,9 @@ typedef struct {
     uint32_t srcLen;  /* <= QZSTD_HIP_BLOCK_MAX                                                  */
     uint32_t seqCap;  /* capacity of the output region, >= ZSTD_sequenceBound(srcLen - parseFrom) */
     uint32_t parseFrom; /* 0 = the whole block                                                    */
-    uint32_t reserved;  /* 0                                                                       */
+    uint32_t mark;      /* written into the fourth word (ZSTD_Sequence.rep) of every entry the item produces, the delimiter included; 0 on
+                         * the launch paths (there the end of the kernel orders results and completion); the resident service puts the
+                         * request's epoch there */
 } qzstd_hip_block_t;
 
 const char *qzstd_hip_last_error(void);
@@ -149,8 +151,10 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
  * segment size, 1 << profile.segLog; the last item takes the rest); item k parses [k * itemBytes, min(srcLen, (k + 1) *
  * itemBytes)), writes its sequences to hSeqs + k * seqCapPerItem and then — last, with a system-scope release — its count
  * (sequences including the item's delimiter, QZSTD_HIP_NSEQ_ERROR, or QZSTD_HIP_NSEQ_REJECTED) to hCount[k], which the
- * caller has zeroed and polls: the count is the completion flag, no stream, no query.  The items' lists, joined with
- * the trailing literals carried over, are the sequences of the block.
+ * caller has zeroed and polls: no stream, no query.  The count says how many entries the item has; every ENTRY is one 16-byte
+ * store that carries the request's epoch in its fourth word (ZSTD_Sequence.rep): the caller takes an entry when it shows the
+ * epoch — nothing orders the count behind the entries of other waves on their ways to host memory (measured: up to microseconds
+ * apart under load).  The items' lists, joined with the trailing literals carried over, are the sequences of the block.
  *
  * Resident kernels (one worker workgroup per CU + a one-wave dispatcher) are launched by the first request and leave
  * after QZSTD_HIP_SERVICE_IDLE_US (default 20000) without work, when memory is freed, or on qzstd_hip_service_stop().

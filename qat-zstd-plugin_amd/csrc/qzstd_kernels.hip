@@ -596,7 +596,7 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
 template <bool REP>
 __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *srec,
                                             const uint32_t *pvW, uint32_t off, uint32_t len, uint32_t w0, uint32_t rpE,
-                                            uint32_t lane, uint4 *out, uint32_t seqCap, uint32_t tileSeq)
+                                            uint32_t lane, uint4 *out, uint32_t seqCap, uint32_t tileSeq, uint32_t mark)
 {
     bool ch;
     uint32_t prevEnd, idx;
@@ -645,7 +645,7 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
             const uint32_t x = pb ^ qb;
             b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
         }
-        if (idx < seqCap) out[idx] = make_uint4(off, lit - b, len + b, 0u);
+        if (idx < seqCap) out[idx] = make_uint4(off, lit - b, len + b, mark); /* ONE 16-byte store: entry and mark arrive together */
     }
 }
 
@@ -1049,7 +1049,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #endif
         /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
         uint32_t count = nseqEnd + 1u;
-        if (lane == 0 && nseqEnd < blk.seqCap) out[nseqEnd] = make_uint4(0u, n - anchorEnd, 0u, 0u);
+        if (lane == 0 && nseqEnd < blk.seqCap) out[nseqEnd] = make_uint4(0u, n - anchorEnd, 0u, blk.mark);
         if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
         return count;
     }
@@ -1097,7 +1097,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         if (it >= 2u + firstTile && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
             emit_window<REP>(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, pv + (it & 1u) * kPvStride + 64u * wave,
                              offB, lenB, t0 - 2u * kTile + 64u * wave, ring_back(rp, 2u * kTile), lane, out, blk.seqCap,
-                             REP ? srec[(it & 1u) * kWin * kSrecWords] : 0u);
+                             REP ? srec[(it & 1u) * kWin * kSrecWords] : 0u, blk.mark);
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
         const bool validL = HAS_LONG && valid && p + 8u <= segE;
         uint32_t oa[4]; /* the position's first 16 bytes, byte-aligned: hashed now, compared against every candidate later */
@@ -1520,12 +1520,13 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
         uint4 *out = (uint4 *)q2;
         uint32_t *countWord = (uint32_t *)q3;
         qzstd_hip_block_t blk;
-        blk.srcOff = 0; blk.seqOff = 0; blk.reserved = 0;
+        blk.srcOff = 0; blk.seqOff = 0;
         blk.srcLen = (uint32_t)q4 & 0x3FFFFu;
         blk.parseFrom = (uint32_t)(q4 >> 18) & 0x3FFFFu;
         blk.seqCap = (uint32_t)q5 & 0xFFFFFFu;
         const uint32_t k = (uint32_t)(q4 >> 36) & 63u, slotIdx = (uint32_t)(q4 >> 42) & (kSvcSlots - 1u);
         const uint32_t epoch = (uint32_t)q6 & 0xFFFFFFu;
+        blk.mark = epoch; /* every entry of the item's result carries the request's epoch: see qzstd_hip_svc_req_t */
         /* ---- the item's slice: pinned host memory -> the request's device staging buffer, written through ---- */
         {
             const uint32_t end = (blk.srcLen + 15u) & ~15u;

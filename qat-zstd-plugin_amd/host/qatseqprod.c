@@ -496,7 +496,7 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         for (sg = 0; sg < r->nSeg; sg++, k++) {
             qzstd_hip_block_t *d = &bt->hDesc[k];
             d->srcOff = (size_t)order[j] * QZ_SRC_STRIDE;
-            d->reserved = 0;
+            d->mark = 0;
             if (r->nSeg == 1) {
                 d->seqOff = (size_t)order[j] * QZ_BATCH_PITCH;
                 d->srcLen = (unsigned int)r->srcSize;
@@ -947,7 +947,7 @@ static size_t qzRunBlock(QZSTD_Slot_T *sl, ZSTD_Sequence *outSeqs, size_t outSeq
     sl->hDesc->srcLen = (unsigned int)srcSize;
     sl->hDesc->seqCap = (unsigned int)cap;
     sl->hDesc->parseFrom = 0;
-    sl->hDesc->reserved = 0;
+    sl->hDesc->mark = 0;
     {
         const size_t work = qzstd_hip_workspace_bytes(level, 1, (unsigned int)srcSize);
         if (work) sl->dWork = qzGrowDev(sl->device, sl->dWork, &sl->dWorkCap, work);
@@ -1090,9 +1090,29 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
             const ZSTD_Sequence *q = sl->vSeqs + k * rq.seqCapPerItem;
             if (cnt == QZSTD_HIP_NSEQ_REJECTED) { rejected = 1; break; } /* handed back whole: nothing of it was queued */
             if (cnt == QZSTD_HIP_NSEQ_ERROR || cnt > rq.seqCapPerItem || out + cnt >= outSeqsCapacity - 1) { wrong = 1; continue; } /* capacity rule, reference :1318-1322 */
+            /* The count says how many entries there are, not that they are all there: the entries are stored by eight waves, the
+             * count by a ninth, and on their ways to host memory nothing orders the one behind the others (measured: under load an
+             * item's last entries arrive up to microseconds after its count).  Every entry is ONE 16-byte store that carries the
+             * request's epoch in its fourth word (qzstd_hip_block_t.mark): an entry is taken when it shows it. */
+            {
+                size_t j;
+                for (j = 0; j < cnt && !bad; j++) {
+                    unsigned spins = 0;
+                    while (__atomic_load_n(&q[j].rep, __ATOMIC_ACQUIRE) != rq.epoch) {
+                        __builtin_ia32_pause();
+                        if ((++spins & 1023u) == 0u && qzNowNs() - t0 > limitNs) { bad = 1; break; }
+                    }
+                    if (bad) break;
+                    if (j + 1 < cnt) {
+                        outSeqs[out + j].offset = q[j].offset;
+                        outSeqs[out + j].litLength = q[j].litLength + (j == 0 ? (unsigned int)carry : 0u);
+                        outSeqs[out + j].matchLength = q[j].matchLength;
+                        outSeqs[out + j].rep = 0;
+                    }
+                }
+                if (bad) break;
+            }
             if (cnt > 1) {
-                memcpy(outSeqs + out, q, (cnt - 1) * sizeof(ZSTD_Sequence));
-                outSeqs[out].litLength += (unsigned int)carry;
                 out += cnt - 1;
                 carry = 0;
             }
@@ -1609,7 +1629,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
             h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
             h->hDesc[b].seqCap = (unsigned int)h->pitch;
             h->hDesc[b].parseFrom = 0;
-            h->hDesc[b].reserved = 0;
+            h->hDesc[b].mark = 0;
             h->hCount[b] = QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
             if (!speculative && h->keys && nb <= h->keysCap && nb <= QZ_CONTENT_LOOKUP_BLOCKS)
                 h->keys[b] = h->hDesc[b].srcLen >= 16 ? qzBlockKey(h->hSrc + o, h->hDesc[b].srcLen) : 0ull;

@@ -105,6 +105,10 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
         if (gSvcLevel && gSvcLevel != level) { r->hCount[k] = QZSTD_HIP_NSEQ_REJECTED; continue; }
         memcpy((uint8_t *)r->dSrc + from, (const uint8_t *)r->hSrc + from, upTo - from); /* the item's slice */
         n = qzo_find_sequences_from(&pf, (const uint8_t *)r->dSrc, upTo, from, (qzo_seq_t *)r->hSeqs + (size_t)k * r->seqCapPerItem, r->seqCapPerItem);
+        if (n != QZO_ERROR) { /* every entry carries the request's epoch in its fourth word, as the real workers' do */
+            size_t j;
+            for (j = 0; j < n; j++) ((uint32_t *)r->hSeqs)[((size_t)k * r->seqCapPerItem + j) * 4u + 3u] = r->epoch;
+        }
         __atomic_store_n(&r->hCount[k], n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n, __ATOMIC_RELEASE);
     }
     return 0;

@@ -236,7 +236,7 @@ class HipProfile(OracleProfile):
 
 class HipBlock(C.Structure):
     _fields_ = [("srcOff", C.c_uint64), ("seqOff", C.c_uint64), ("srcLen", C.c_uint32), ("seqCap", C.c_uint32),
-                ("parseFrom", C.c_uint32), ("reserved", C.c_uint32)]
+                ("parseFrom", C.c_uint32), ("mark", C.c_uint32)]
 
 
 NSEQ_ERROR = 0xFFFFFFFF
@@ -426,7 +426,16 @@ class ServiceLane:
         t0 = time.perf_counter()
         while not all(self.cnt[k] for k in range(nit)):
             assert time.perf_counter() - t0 < timeout_s, "service request timed out: counts %s" % [self.cnt[k] for k in range(nit)]
-        return [self.cnt[k] for k in range(nit)], self.seqs, cap, item_bytes
+        counts = [self.cnt[k] for k in range(nit)]
+        # the counts say how many entries; every entry carries the epoch in its fourth word when it has arrived (include/qzstd_hip.h)
+        import numpy as np
+        words = np.frombuffer((C.c_uint32 * (self.MAX_ITEMS * self.ITEM_CAP * 4)).from_address(self.hseq), dtype=np.uint32)
+        for k, n in enumerate(counts):
+            if n in (NSEQ_ERROR, NSEQ_REJECTED) or n > cap:
+                continue
+            while not (words[k * cap * 4 + 3:(k * cap + n) * 4:4] == self.epoch).all():
+                assert time.perf_counter() - t0 < timeout_s, "entries of item %d never arrived" % k
+        return counts, self.seqs, cap, item_bytes
 
     def close(self):
         L = self.L
