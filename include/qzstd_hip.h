@@ -176,10 +176,11 @@ typedef struct {
     uint32_t srcLen, itemBytes, nItems, seqCapPerItem;
     uint32_t slot;      /* < QZSTD_HIP_SVC_MAX_SLOTS: one request in flight per slot (its slices' flags) */
     uint32_t epoch;     /* 1 .. 0xFFFFFF, different from the slot's previous request */
-    void *dWork;        /* chain levels (>= 5): device scratch, nItems x QZSTD_HIP_SVC_WORK_BYTES (every item links the block before it
-                         * there); NULL at the other levels */
+    void *dWork;        /* chain levels (>= 5): device scratch of the request, QZSTD_HIP_SVC_WORK_BYTES, shared by its items (every item
+                         * links the block before it, and leaves the chain entries of one item's range to the items after it);
+                         * NULL at the other levels */
 } qzstd_hip_svc_req_t;
-#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 20u)
+#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 36u)
 int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *req);
 int qzstd_hip_service_stop(int device);          /* asks the resident kernels to leave and waits for them; 0 = stopped */
 /* called by a caller that waits for its request: if the service has left meanwhile (idle exit, a free, a launch that needed the LDS)

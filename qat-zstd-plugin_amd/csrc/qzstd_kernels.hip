@@ -121,6 +121,9 @@ typedef unsigned long long u64;
  * waited for where their registers are used. */
 #define QZ_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+#define QZ_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define QZ_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+
 /* v_readlane_b32 with an unsigned result (the builtin returns int: a set bit 31 would sign-extend) */
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -756,6 +759,20 @@ __device__ __forceinline__ void chain_insert_tile(const qzstd_hip_profile_t &pf,
     }
 }
 
+/* Chain levels, items of ONE request of the resident service: they share one device scratch.  Every item still inserts and links the
+ * whole block before it (the head table is its own, in LDS; the dense first links it writes are the same values whoever writes them),
+ * but it completes the four-link ENTRIES only for the item's range before its own — 4 KiB instead of up to 124 — and picks up the
+ * entries of the earlier ranges from the items before it: they were handed out earlier, have less history in front of them and have
+ * long said so (flags[j] = epoch: item j has stored the entries of range j - 1, written through) by the time this item is done
+ * inserting.  flags == nullptr: a scratch of its own, all entries built here (the launch paths: workgroups of a launch do not start
+ * in order). */
+struct HistShare {
+    uint32_t *flags;    /* [kSvcMaxItems] of the request's slot */
+    uint32_t item;      /* this item's index in the request (>= 1 where it matters) */
+    uint32_t epoch;     /* of the request */
+    uint32_t spinLimit; /* bound of the wait for the items before this one */
+};
+
 /* One work item (a block, or a run of whole segments of one): `blk` describes it, gsrc = the block's bytes in device memory,
  * out = the item's result region, chainB = its chain entries (CHAIN), p1B = its array of first links (CHAIN, segment items).  Returns, in the parse wave, the item's sequence
  * count including the delimiter or QZSTD_HIP_NSEQ_ERROR (every thread returns that for an item that is refused); the matcher
@@ -763,7 +780,7 @@ __device__ __forceinline__ void chain_insert_tile(const qzstd_hip_profile_t &pf,
  * (qzstd_find_sequences_kernel), or a resident worker that takes items from a queue (qzstd_service_worker). */
 template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
 __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_hip_block_t &blk, const uint8_t *gsrc, uint4 *out,
-                                            uint4 *chainB, uint32_t *p1B)
+                                            uint4 *chainB, uint32_t *p1B, const HistShare hsh)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -925,7 +942,9 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
          * about 1.8 us per dependent gather under load); eight independent chases per thread in flight (sixteen push the kernel past
          * 104 VGPRs: one workgroup per CU, level 6 26 -> 37 ms per 256 MiB) */
         constexpr uint32_t kChase = 8u;
-        for (uint32_t p0 = tid; p0 < histEnd && !QZ_ABLATED(512u); p0 += kChase * (uint32_t)kThreads) {
+        /* (shared scratch: only the range of the item before this one, the rest comes from the items before it) */
+        const uint32_t chaseFrom = hsh.flags ? histEnd - histEnd / hsh.item : 0u; /* (a history implies item >= 1) */
+        for (uint32_t p0 = chaseFrom + tid; p0 < histEnd && !QZ_ABLATED(512u); p0 += kChase * (uint32_t)kThreads) {
             uint32_t e0[kChase], e1[kChase], e2[kChase], e3[kChase];
 #pragma unroll
             for (uint32_t i = 0; i < kChase; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e0[i] = pp < histEnd ? p1B[pp] : 0u; }
@@ -936,7 +955,36 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #pragma unroll
             for (uint32_t i = 0; i < kChase; i++) e3[i] = e2[i] ? p1B[(e2[i] >> kTagBits) - 1u] : 0u;
 #pragma unroll
-            for (uint32_t i = 0; i < kChase; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; if (pp < histEnd) chainB[pp] = make_uint4(e0[i], e1[i], e2[i], e3[i]); }
+            for (uint32_t i = 0; i < kChase; i++) {
+                const uint32_t pp = p0 + i * (uint32_t)kThreads;
+                if (pp < histEnd) {
+                    if (hsh.flags) { /* written through: other items (other XCDs) read these */
+                        u64 *e = reinterpret_cast<u64 *>(chainB + pp);
+                        __hip_atomic_store(e, (u64)e0[i] | ((u64)e1[i] << 32), QZ_RLX_AGENT);
+                        __hip_atomic_store(e + 1, (u64)e2[i] | ((u64)e3[i] << 32), QZ_RLX_AGENT);
+                    } else {
+                        chainB[pp] = make_uint4(e0[i], e1[i], e2[i], e3[i]);
+                    }
+                }
+            }
+        }
+        if (hsh.flags) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every storing wave drains before the flag */
+            __syncthreads();
+            if (wave == 0u) {
+                if (lane == 0u) __hip_atomic_store(&hsh.flags[hsh.item], hsh.epoch, QZ_RLX_AGENT);
+                uint32_t spins = 0u, ok = 1u;
+                for (;;) { /* items 1 .. item - 1 have stored the ranges 0 .. item - 2 */
+                    const bool there = lane == 0u || lane >= hsh.item || __hip_atomic_load(&hsh.flags[lane], QZ_RLX_AGENT) == hsh.epoch;
+                    if (__all(there)) break;
+                    if (++spins > hsh.spinLimit) { ok = 0u; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane == 0u) turnCtr[2] = ok;
+            }
+            __syncthreads();
+            if (rdfirst(turnCtr[2]) == 0u) return QZSTD_HIP_NSEQ_ERROR; /* (uniform; the worker counts it with the slices given up on) */
         }
         __syncthreads();
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
@@ -1055,6 +1103,13 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     }
 
     /* ---------------- the 8 matcher waves ---------------- */
+    /* Chain entries: of the positions before the item (its history) in chainB; of the item's own positions in ownB — the same array
+     * on the launch paths, an array of its own where the items of a request share chainB (HistShare): there the entries of an
+     * item's range are stored by the item AFTER it, written through, and nobody else may leave half-written lines of them in an
+     * L2 that a reader on the same XCD would hit. */
+    uint4 *const ownB = (CHAIN && hsh.flags) ? chainB + QZSTD_HIP_BLOCK_MAX : chainB;
+    const uint32_t ownFrom = blk.parseFrom;
+    auto entryOf = [&](uint32_t q) -> uint4 { return (q >= ownFrom ? ownB : chainB)[q]; };
     const uint32_t hiMask = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
     const uint32_t nearShift = 32u - kTileLog;
     const uint32_t stampShift = kTileLog + kTagBits;
@@ -1124,7 +1179,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             /* the chain entry of the predecessor (left by the parse wave during the previous tile), fetched now if that is a position of an
              * earlier tile: its entry was stored at least one barrier ago */
             old = valid ? ((it & 1u) ? P1odd : nearTab)[tid] : 0u;
-            if (old != 0u && (old >> kTagBits) - 1u < t0) pre = chainB[(old >> kTagBits) - 1u];
+            if (old != 0u && (old >> kTagBits) - 1u < t0) pre = entryOf((old >> kTagBits) - 1u);
         }
         QZ_LAP(dI1)
         __syncthreads(); /* B1 */
@@ -1156,7 +1211,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             if (valid) {
                 E[0] = P1T[tid];
                 if (E[0] != 0u && (E[0] >> kTagBits) - 1u < t0) { /* predecessor in an earlier tile: its entry is here (the item's first tile: fetched now) */
-                    if (it == itBegin) pre = chainB[(E[0] >> kTagBits) - 1u];
+                    if (it == itBegin) pre = entryOf((E[0] >> kTagBits) - 1u);
                     E[1] = pre.x; E[2] = pre.y; E[3] = pre.z;
                 } else {
 #pragma unroll
@@ -1166,7 +1221,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         E[i] = P1T[q - t0];
                     }
                 }
-                chainB[p] = make_uint4(E[0], E[1], E[2], E[3]);
+                ownB[p] = make_uint4(E[0], E[1], E[2], E[3]);
             }
             /* the walk: chainDepth links, newest first; a link whose tag differs is a slot collision (skipped without
              * touching its bytes); the candidate with the highest gain stays, the nearer one on a tie */
@@ -1183,7 +1238,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     const uint32_t cnt = E[3] ? 4u : (E[2] ? 3u : (E[1] ? 2u : 1u));
                     if (walked + cnt < pf.chainDepth) {
                         if (ql < t0) {
-                            const uint4 v = chainB[ql];
+                            const uint4 v = entryOf(ql);
                             N[0] = v.x; N[1] = v.y; N[2] = v.z; N[3] = v.w;
                         } else {
                             N[0] = P1T[ql - t0];
@@ -1402,7 +1457,8 @@ __global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchAr
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
                                                                 CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr,
-                                                                CHAIN ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr);
+                                                                CHAIN ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
+                                                                HistShare{ nullptr, 0u, 0u, 0u });
     if (threadIdx.x == (uint32_t)kMatchThreads) args.nseq[blockIdx.x] = count; /* lane 0 of the parse wave */
 }
 
@@ -1433,7 +1489,6 @@ constexpr uint32_t kSvcQueue = 4096u;  /* entries of the device work queue */
 constexpr uint32_t kSvcRing = 256u;    /* entries of the host request ring */
 constexpr uint32_t kSvcMaxItems = 32u; /* work items per request */
 constexpr uint32_t kSvcSlots = 1024u;  /* request slots (one per caller in flight): slice flags */
-constexpr u64 kSvcChainBytes = (u64)QZSTD_HIP_BLOCK_MAX * 20ull; /* scratch of one work item: 16 B of chain entry + 4 B of first link per position of a 128 KiB block */
 constexpr uint32_t kSvcRejected = 0xFFFFFFFEu; /* count word: the service does not serve this request (other level): launch path */
 
 struct SvcDev { /* device memory, zeroed before every launch of the service */
@@ -1446,6 +1501,7 @@ struct SvcDev { /* device memory, zeroed before every launch of the service */
     uint32_t taken;     /* items a worker has picked up (diagnostics) */
     uint32_t pad[2];
     uint32_t sliceFlag[kSvcSlots][kSvcMaxItems]; /* epoch of the request whose slice k is in the slot's staging buffer */
+    uint32_t histFlag[kSvcSlots][kSvcMaxItems];  /* chain levels: epoch of the request whose item k has stored the entries of range k - 1 */
 };
 
 struct SvcHost { /* pinned host memory */
@@ -1461,8 +1517,6 @@ struct SvcHost { /* pinned host memory */
 
 typedef __attribute__((address_space(1))) u64 *gu64p;
 typedef __attribute__((address_space(1))) uint32_t *gu32p;
-#define QZ_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define QZ_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 
 __device__ __forceinline__ u64 svc_tag(u64 n, uint32_t entries) { return (n / entries) % 255ull + 1ull; }
 __device__ __forceinline__ u64 svc_payload(u64 g) { return g & 0x00FFFFFFFFFFFFFFull; }
@@ -1470,7 +1524,7 @@ __device__ __forceinline__ u64 svc_payload(u64 g) { return g & 0x00FFFFFFFFFFFFF
 /* request granules (host -> dispatcher):
  *   0 hSrc   1 dSrc   2 hSeqs   3 hCount   (pointers, 56 bits)
  *   4 srcLen (18) | itemBytes (18) << 18 | nItems (6) << 36 | slot (10) << 42
- *   5 seqCapPerItem (24)        6 epoch (24) | level (8) << 24        7 dWork: chain scratch, nItems regions of kSvcChainBytes (chain levels)
+ *   5 seqCapPerItem (24)        6 epoch (24) | level (8) << 24        7 dWork: the request's chain scratch, QZSTD_HIP_SVC_WORK_BYTES, shared by its items (chain levels)
  *   (one field per word where a word is multiplied: hipcc 7.2 folded the mask of a packed seqCap away in the dispatcher's
  *   64-bit multiply and the items' result regions landed 256 MiB apart)
  * item granules (dispatcher -> worker):
@@ -1554,8 +1608,10 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
             __syncthreads();
         }
         uint32_t count = QZSTD_HIP_NSEQ_ERROR;
+        /* the request's scratch: entries of the history [BLOCK_MAX], entries of the items' own positions [BLOCK_MAX], first links [BLOCK_MAX] */
         if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, dSrc, out, CHAIN ? (uint4 *)q7 : nullptr,
-                                                                               CHAIN ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 16ull) : nullptr);
+                                                                               CHAIN ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 32ull) : nullptr,
+                                                                               HistShare{ CHAIN ? &sv->histFlag[slotIdx][0] : nullptr, k, epoch, spinLimit });
         else if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->spinFails, 1u, QZ_RLX_AGENT);
         /* ---- completion: every wave's result stores are performed, then the count — the host's flag — with a system-scope release ---- */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1614,7 +1670,7 @@ __global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcD
                     __hip_atomic_store(e + 4, tg | upTo | ((u64)from << 18) | ((u64)lane << 36) | ((u64)slotIdx << 42), QZ_RLX_AGENT);
                     __hip_atomic_store(e + 5, tg | cap, QZ_RLX_AGENT);
                     __hip_atomic_store(e + 6, tg | epoch, QZ_RLX_AGENT);
-                    __hip_atomic_store(e + 7, tg | (r7 ? r7 + (u64)lane * kSvcChainBytes : 0ull), QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 7, tg | r7, QZ_RLX_AGENT); /* the items of a request share its scratch (HistShare) */
                 }
                 tail += nItems;
             }

@@ -100,7 +100,7 @@ typedef struct {
     unsigned char *vdSrc;  /* device */
     ZSTD_Sequence *vSeqs;  /* pinned, QZ_SVC_ITEMS_MAX x QZ_SVC_ITEM_CAP */
     unsigned int *vCount;  /* pinned, QZ_SVC_ITEMS_MAX */
-    void *vdWork;          /* device: chain scratch of the items (levels >= 5), QZ_SVC_ITEMS_MAX x QZSTD_HIP_SVC_WORK_BYTES, on first use */
+    void *vdWork;          /* device: chain scratch of a request (levels >= 5: shared by its items), QZSTD_HIP_SVC_WORK_BYTES, on first use */
     unsigned int vEpoch, vItems; /* the last request: its epoch, its item count */
     int vStuck;            /* that request timed out: the slot serves no request before all its count words have arrived */
 } QZSTD_Slot_T;
@@ -1050,7 +1050,7 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
     rq.slot = (uint32_t)i; rq.epoch = sl->vEpoch;
     rq.dWork = NULL;
     if (qzstd_hip_workspace_bytes(level, 1, QZSTD_HIP_BLOCK_MAX) != 0) { /* a chain level: every item links the block before it in its own scratch */
-        if (!sl->vdWork) sl->vdWork = qzstd_hip_malloc(sl->device, (size_t)QZ_SVC_ITEMS_MAX * QZSTD_HIP_SVC_WORK_BYTES);
+        if (!sl->vdWork) sl->vdWork = qzstd_hip_malloc(sl->device, QZSTD_HIP_SVC_WORK_BYTES);
         if (!sl->vdWork) {
             memset(sl->vCount, 0xFF, nItems * sizeof(unsigned int));
             qzReleaseSlot(i);
@@ -1156,6 +1156,13 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
         for (k = 0; k < out; k++) sum += (size_t)outSeqs[k].litLength + outSeqs[k].matchLength;
         if (sum != srcSize) {
             QZ_LOG(1, "service result does not add up: %zu of %zu bytes\n", sum, srcSize);
+            for (k = 0; k < nItems; k++) { /* which item: every item's own list adds up to its range */
+                const ZSTD_Sequence *q = sl->vSeqs + k * rq.seqCapPerItem;
+                const size_t from = k * itemBytes, upTo = (k + 1) * itemBytes < srcSize ? (k + 1) * itemBytes : srcSize;
+                size_t isum = 0, j;
+                for (j = 0; j < sl->vCount[k] && j < rq.seqCapPerItem; j++) isum += (size_t)q[j].litLength + q[j].matchLength;
+                if (isum != upTo - from) QZ_LOG(1, "  item %zu of %zu: %u sequences cover %zu of %zu bytes\n", k, nItems, sl->vCount[k], isum, upTo - from);
+            }
             qzstd_hip_service_mark_broken(sl->device);
             qzCause = QZ_CAUSE_RUNTIME;
             return ZSTD_SEQUENCE_PRODUCER_ERROR;
