@@ -39,6 +39,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <emmintrin.h>
 #include <sys/prctl.h>
 #include <sys/types.h>
 #include <sys/uio.h>
@@ -1094,23 +1095,25 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
              * count by a ninth, and on their ways to host memory nothing orders the one behind the others (measured: under load an
              * item's last entries arrive up to microseconds after its count).  Every entry is ONE 16-byte store that carries the
              * request's epoch in its fourth word (qzstd_hip_block_t.mark): an entry is taken when it shows it. */
-            {
+            {   /* one aligned 16-byte load per entry (it arrived as one store), the mark checked and cleared on the way */
+                const __m128i keep = _mm_set_epi32(0, -1, -1, -1);
                 size_t j;
-                for (j = 0; j < cnt && !bad; j++) {
-                    unsigned spins = 0;
-                    while (__atomic_load_n(&q[j].rep, __ATOMIC_ACQUIRE) != rq.epoch) {
-                        __builtin_ia32_pause();
-                        if ((++spins & 1023u) == 0u && qzNowNs() - t0 > limitNs) { bad = 1; break; }
+                for (j = 0; j < cnt; j++) {
+                    __m128i v = _mm_load_si128((const __m128i *)(const void *)(q + j));
+                    if ((unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(v, 12)) != rq.epoch) { /* not there yet: rare */
+                        unsigned spins = 0;
+                        do {
+                            __builtin_ia32_pause();
+                            __asm__ volatile("" ::: "memory"); /* (a fresh load every time round) */
+                            if ((++spins & 1023u) == 0u && qzNowNs() - t0 > limitNs) { bad = 1; break; }
+                            v = _mm_load_si128((const __m128i *)(const void *)(q + j));
+                        } while ((unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(v, 12)) != rq.epoch);
+                        if (bad) break;
                     }
-                    if (bad) break;
-                    if (j + 1 < cnt) {
-                        outSeqs[out + j].offset = q[j].offset;
-                        outSeqs[out + j].litLength = q[j].litLength + (j == 0 ? (unsigned int)carry : 0u);
-                        outSeqs[out + j].matchLength = q[j].matchLength;
-                        outSeqs[out + j].rep = 0;
-                    }
+                    if (j + 1 < cnt) _mm_storeu_si128((__m128i *)(void *)(outSeqs + out + j), _mm_and_si128(v, keep));
                 }
                 if (bad) break;
+                if (cnt > 1) outSeqs[out].litLength += (unsigned int)carry;
             }
             if (cnt > 1) {
                 out += cnt - 1;
