@@ -1021,7 +1021,7 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
 {
     QZSTD_Slot_T *sl;
     qzstd_hip_svc_req_t rq;
-    size_t itemBytes, nItems, k, out = 0, carry = 0;
+    size_t itemBytes, nItems, k, out = 0, carry = 0, covered = 0;
     unsigned long t0, spinNs, limitNs;
     int i, rc, rejected = 0, bad = 0, wrong = 0;
 
@@ -1097,6 +1097,7 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
              * request's epoch in its fourth word (qzstd_hip_block_t.mark): an entry is taken when it shows it. */
             {   /* one aligned 16-byte load per entry (it arrived as one store), the mark checked and cleared on the way */
                 const __m128i keep = _mm_set_epi32(0, -1, -1, -1);
+                __m128i acc = _mm_setzero_si128();
                 size_t j;
                 for (j = 0; j < cnt; j++) {
                     __m128i v = _mm_load_si128((const __m128i *)(const void *)(q + j));
@@ -1111,8 +1112,10 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
                         if (bad) break;
                     }
                     if (j + 1 < cnt) _mm_storeu_si128((__m128i *)(void *)(outSeqs + out + j), _mm_and_si128(v, keep));
+                    acc = _mm_add_epi32(acc, v); /* literal and match lengths add up in lanes 1 and 2 (a block is 128 KiB at most) */
                 }
                 if (bad) break;
+                covered += (size_t)(unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(acc, 4)) + (unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(acc, 8));
                 if (cnt > 1) outSeqs[out].litLength += (unsigned int)carry;
             }
             if (cnt > 1) {
@@ -1153,10 +1156,9 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
     outSeqs[out].rep = 0;
     out++;
     qzReleaseSlot(i);
-    {   /* what arrived has to add up to the block (a torn or stale result must never reach libzstd, which does not validate
-         * sequences by default): one pass of additions */
-        size_t sum = 0;
-        for (k = 0; k < out; k++) sum += (size_t)outSeqs[k].litLength + outSeqs[k].matchLength;
+    {   /* what arrived has to add up to the block (a wrong result must never reach libzstd, which does not validate sequences by
+         * default): the lengths were added up on the way */
+        const size_t sum = covered;
         if (sum != srcSize) {
             QZ_LOG(1, "service result does not add up: %zu of %zu bytes\n", sum, srcSize);
             for (k = 0; k < nItems; k++) { /* which item: every item's own list adds up to its range */
