@@ -842,9 +842,9 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     const uint32_t hi = umin(nPad, histEnd + kLook + (itBegin ? 0u : kTile));
     const uint32_t lo = hi > kRing ? (hi - kRing + 15u) & ~15u : 0u;
     constexpr uint32_t kStep = (uint32_t)kThreads * 16u;
-    uint32_t fo = (itBegin ? 0u : lo) + tid * 16u;
-    uint4 fa0 = make_uint4(0u, 0u, 0u, 0u), fb0 = fa0, fa1 = fa0, fb1 = fa0;
     const uint32_t hashEnd = CHAIN ? 0u : histEnd; /* the chain levels link their history in a pass of its own (below) */
+    uint32_t fo = (hashEnd ? 0u : lo) + tid * 16u; /* (nothing to hash here: only what the ring needs) */
+    uint4 fa0 = make_uint4(0u, 0u, 0u, 0u), fb0 = fa0, fa1 = fa0, fb1 = fa0;
     if (fo < hi) { fa0 = g128[fo >> 4]; if (fo < hashEnd) fb0 = g128[(fo >> 4) + 1u]; }
     if (fo + kStep < hi) { fa1 = g128[(fo + kStep) >> 4]; if (fo + kStep < hashEnd) fb1 = g128[((fo + kStep) >> 4) + 1u]; }
     for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
