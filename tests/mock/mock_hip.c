@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #include <time.h>
 
@@ -83,6 +84,24 @@ static int gSvcRequests, gSvcBroken, gSvcStops, gSvcLevel;
 void qzstd_mock_service_level(int level) { gSvcLevel = level; }
 int qzstd_mock_service_requests(void) { return gSvcRequests; }
 void *qzstd_hip_host_alloc_coherent(size_t bytes) { return malloc(bytes ? bytes : 1); }
+static volatile int gLateMarks; /* test hook (qzstd_mock_late_marks) */
+void qzstd_mock_late_marks(int on) { gLateMarks = on; }
+typedef struct { uint32_t *w, *real; size_t n; uint32_t epoch; int us; } late_t;
+static void *late_marks(void *p)
+{
+    late_t *lt = (late_t *)p;
+    size_t j;
+    struct timespec nap = { 0, 0 };
+    nap.tv_nsec = (long)lt->us * 1000l;
+    nanosleep(&nap, NULL);
+    for (j = lt->n; j-- > 0; ) { /* last entries first; an entry's mark with (here: after) its three other words */
+        lt->w[j * 4u] = lt->real[j * 4u]; lt->w[j * 4u + 1u] = lt->real[j * 4u + 1u]; lt->w[j * 4u + 2u] = lt->real[j * 4u + 2u];
+        __atomic_store_n(&lt->w[j * 4u + 3u], lt->epoch, __ATOMIC_RELEASE);
+    }
+    free(lt->real);
+    free(lt);
+    return NULL;
+}
 int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r)
 {
     const char *v = getenv("QZSTD_MOCK_SERVICE");
@@ -107,7 +126,18 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
         n = qzo_find_sequences_from(&pf, (const uint8_t *)r->dSrc, upTo, from, (qzo_seq_t *)r->hSeqs + (size_t)k * r->seqCapPerItem, r->seqCapPerItem);
         if (n != QZO_ERROR) { /* every entry carries the request's epoch in its fourth word, as the real workers' do */
             size_t j;
-            for (j = 0; j < n; j++) ((uint32_t *)r->hSeqs)[((size_t)k * r->seqCapPerItem + j) * 4u + 3u] = r->epoch;
+            if (gLateMarks) { /* test hook: the counts first, the entries' marks a while later (the order host memory may see them in) */
+                late_t *lt = (late_t *)malloc(sizeof *lt);
+                pthread_t th;
+                lt->w = (uint32_t *)r->hSeqs + (size_t)k * r->seqCapPerItem * 4u; lt->n = n; lt->epoch = r->epoch; lt->us = 300 + 50 * (int)k;
+                lt->real = (uint32_t *)malloc(n * 16u);
+                memcpy(lt->real, lt->w, n * 16u);
+                memset(lt->w, 0xEE, n * 16u); /* what is there before the entries arrive: anything */
+                if (pthread_create(&th, NULL, late_marks, lt) == 0) pthread_detach(th);
+                else { late_marks(lt); }
+            } else {
+                for (j = 0; j < n; j++) ((uint32_t *)r->hSeqs)[((size_t)k * r->seqCapPerItem + j) * 4u + 3u] = r->epoch;
+            }
         }
         __atomic_store_n(&r->hCount[k], n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n, __ATOMIC_RELEASE);
     }

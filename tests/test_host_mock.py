@@ -514,6 +514,27 @@ def test_service_path_serves_unchanged_callers(mock, zstd, oracle, level, chunk)
         assert got == want and L.qzstd_mock_service_requests() == before and fs[7] == 0
 
 
+def test_service_entries_that_arrive_after_their_count(mock, zstd, oracle):
+    """the count says how many entries an item has, not that they are there: the mock stores the counts first and marks the entries (the
+    request's epoch in their fourth word) up to a couple of milliseconds later, last entry first — the join waits for every entry's mark
+    and the frames are the oracle's"""
+    chunk = 131072
+    data = K.by_name("system", 3 * chunk + 777, seed=8)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_late_marks.argtypes = [C.c_int]
+    L.qzstd_mock_late_marks(1)
+    try:
+        st = L.QZSTD_createSeqProdState()
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1)
+        fs = fail_stats(mock, st)
+        L.QZSTD_freeSeqProdState(st)
+    finally:
+        L.qzstd_mock_late_marks(0)
+    assert got == oracle_frames(zstd, oracle, data, chunk, 1)
+    assert fs[7] == 4 and fs[0] == 0, fs
+
+
 def test_service_coarser_items_and_other_levels(mock, zstd, oracle):
     """QZSTD_HIP_SERVICE_ITEM: items of several segments; levels 3-4 and the chain levels (6, 12: a scratch per item) are served
     too; requests the dispatcher hands back (another level is resident) take the launch path"""
