@@ -1250,63 +1250,70 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                             }
                         }
                     }
-                    /* The four links of an entry, TWO AT A TIME: a wave's time is the chain of its LDS (and, for far candidates,
+                    /* The four links of an entry TOGETHER (QZ_LINKS_PER_STEP; first two at a time: -2 %, then all four): a wave's time is the chain of its LDS (and, for far candidates,
                      * device-memory) round trips, one after the other — test, first 16 bytes, the next 32 ... — and the SIMDs are
-                     * half idle while 4.5 waves each wait for theirs.  The second link of a pair is tested against the best
-                     * BEFORE the first (a weaker test, still a necessary condition: it survives a little more often), both
-                     * tests are one round trip, both heads another; the updates follow in link order, so the result is
+                     * half idle while 4.5 waves each wait for theirs.  The later links of a step are tested against the best
+                     * BEFORE the earlier ones (a weaker test, still a necessary condition: they survive a little more often), all
+                     * tests are one round trip, all heads another; the updates follow in link order, so the result is
                      * the sequential one. */
+#ifndef QZ_LINKS_PER_STEP
+#define QZ_LINKS_PER_STEP 4 /* measured: 2 -> 4 another -1 to -2.6 % at levels 5-12 (76 VGPRs: still two workgroups per CU) */
+#endif
+                    constexpr int kG = QZ_LINKS_PER_STEP;
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk += 2) {
-                        const uint32_t lA = E[kk], lB = E[kk + 1];
-                        const uint32_t qA = (lA >> kTagBits) - 1u, qB = (lB >> kTagBits) - 1u;
-                        const bool farA = p - qA > kNear, farB = p - qB > kNear;
-                        bool mA = lA != 0u && walked + (uint32_t)kk < pf.chainDepth && (lA & kTagMask) == tag && (pf.window == 0u || p - qA <= pf.window) &&
-                                  !QZ_ABLATED(2u) && !(QZ_ABLATED(64u) && farA); /* profiling: 64 = what the HBM-side candidates cost */
-                        bool mB = lB != 0u && walked + (uint32_t)kk + 1u < pf.chainDepth && (lB & kTagMask) == tag && (pf.window == 0u || p - qB <= pf.window) &&
-                                  !QZ_ABLATED(2u) && !(QZ_ABLATED(64u) && farB);
-                        const uint32_t rqA = ring_back(rp, p - qA), rqB = ring_back(rp, p - qB);
-                        if ((mA || mB) && cl != 0u) {
+                    for (int kk = 0; kk < 4; kk += kG) {
+                        uint32_t q[kG], rq[kG];
+                        bool far[kG], m[kG];
+#pragma unroll
+                        for (int g = 0; g < kG; g++) {
+                            const uint32_t l = E[kk + g];
+                            q[g] = (l >> kTagBits) - 1u;
+                            far[g] = p - q[g] > kNear;
+                            m[g] = l != 0u && walked + (uint32_t)(kk + g) < pf.chainDepth && (l & kTagMask) == tag && (pf.window == 0u || p - q[g] <= pf.window) &&
+                                   !QZ_ABLATED(2u) && !(QZ_ABLATED(64u) && far[g]); /* profiling: 64 = what the HBM-side candidates cost */
+                            rq[g] = ring_back(rp, p - q[g]);
+                        }
+                        bool any = false;
+#pragma unroll
+                        for (int g = 0; g < kG; g++) any = any || m[g];
+                        if (any && cl != 0u) {
                             /* links come nearest first, so a later one can only win with MORE matching bytes than the best so
                              * far (its offset costs at least as much): it has to match at byte cl, in particular.  Four bytes
                              * ending there are compared before anything else (what zstd's chain search does too); a best
                              * that already fills the cap cannot be beaten at all.  Skips most of the full compares. */
-                            uint32_t vA = 0, vB = 0;
-                            const bool tA = mA && cl < cap, tB = mB && cl < cap;
-                            if (tA) vA = rd32_r(src, qA + cl - 3u, ring_fwd(rqA, cl - 3u), farA);
-                            if (tB) vB = rd32_r(src, qB + cl - 3u, ring_fwd(rqB, cl - 3u), farB);
+                            uint32_t v[kG];
+#pragma unroll
+                            for (int g = 0; g < kG; g++) {
+                                m[g] = m[g] && cl < cap;
+                                v[g] = 0u;
+                                if (m[g]) v[g] = rd32_r(src, q[g] + cl - 3u, ring_fwd(rq[g], cl - 3u), far[g]);
+                            }
                             const uint32_t pw = rd32_r(src, p + cl - 3u, ring_fwd(rp, cl - 3u), false);
-                            mA = tA && vA == pw;
-                            mB = tB && vB == pw;
+#pragma unroll
+                            for (int g = 0; g < kG; g++) m[g] = m[g] && v[g] == pw;
                         }
-                        uint32_t QA[5] = { 0u, 0u, 0u, 0u, 0u }, QB[5] = { 0u, 0u, 0u, 0u, 0u };
-                        if (mA) load_dw_r<5>(src, qA, rqA, farA, QA);
-                        if (mB) load_dw_r<5>(src, qB, rqB, farB, QB);
-                        if (mA) {
-                            uint32_t l = head_cmp(oa, QA, qA & 3u);
-                            if (l == 16u && cap > 16u) {
-                                for (;;) {
-                                    const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - qA, farA);
-                                    l += c;
-                                    if (c < 32u || l >= cap) break;
-                                }
-                            }
-                            l = umin(l, cap);
-                            const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - qA + 1u));
-                            if (l >= 4u && (cl == 0u || g > bg)) { cl = l; off = p - qA; bg = g; }
+                        uint32_t Q[kG][5];
+#pragma unroll
+                        for (int g = 0; g < kG; g++) {
+#pragma unroll
+                            for (int i = 0; i < 5; i++) Q[g][i] = 0u;
+                            if (m[g]) load_dw_r<5>(src, q[g], rq[g], far[g], Q[g]);
                         }
-                        if (mB && cl < cap) { /* (a best that fills the cap cannot be beaten: the sequential walk would not have looked) */
-                            uint32_t l = head_cmp(oa, QB, qB & 3u);
-                            if (l == 16u && cap > 16u) {
-                                for (;;) {
-                                    const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - qB, farB);
-                                    l += c;
-                                    if (c < 32u || l >= cap) break;
+#pragma unroll
+                        for (int g = 0; g < kG; g++) {
+                            if (m[g] && cl < cap) { /* (a best that fills the cap cannot be beaten: the sequential walk would not have looked) */
+                                uint32_t l = head_cmp(oa, Q[g], q[g] & 3u);
+                                if (l == 16u && cap > 16u) {
+                                    for (;;) {
+                                        const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q[g], far[g]);
+                                        l += c;
+                                        if (c < 32u || l >= cap) break;
+                                    }
                                 }
+                                l = umin(l, cap);
+                                const int gn = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q[g] + 1u));
+                                if (l >= 4u && (cl == 0u || gn > bg)) { cl = l; off = p - q[g]; bg = gn; }
                             }
-                            l = umin(l, cap);
-                            const int g = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - qB + 1u));
-                            if (l >= 4u && (cl == 0u || g > bg)) { cl = l; off = p - qB; bg = g; }
                         }
                     }
                     walked += cnt;
