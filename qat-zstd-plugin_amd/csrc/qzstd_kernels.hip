@@ -1811,6 +1811,8 @@ struct Service {
     size_t bigLds[kBig] = {};   /* LDS per workgroup of the launch the event stands for */
     int bigNext = 0;
     size_t lds = 0;             /* LDS of one worker of the service that runs (or ran last) */
+    long long launchNs = 0;     /* when it was launched last (CLOCK_MONOTONIC) */
+    bool sawWorkers = false;    /* its dispatcher has reported workers that began */
     bool wide = false;          /* a service whose workers leave no room for ANY batch workgroup on their CU (levels 3-4) has run on this
                                  * device: from then on every launch is remembered by an event */
 };
@@ -2279,6 +2281,13 @@ int svc_launch_locked(int device, Service &s, int level)
     QZ_CHECK(hipMemsetAsync(s.dv, 0, sizeof(SvcDev), s.sWork), "hipMemsetAsync(service queue)");
     QZ_CHECK(hipStreamSynchronize(s.sWork), "hipStreamSynchronize(service worker stream)");
     __atomic_store_n(&s.hs->quitReq, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&s.hs->dbg[3], 0ull, __ATOMIC_RELAXED); /* "workers started", refreshed by the dispatcher */
+    s.sawWorkers = false;
+    {
+        struct timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        __atomic_store_n(&s.launchNs, (long long)t.tv_sec * 1000000000ll + t.tv_nsec, __ATOMIC_RELAXED); /* (before `state` says "running") */
+    }
     __atomic_store_n(&s.hs->state, 1u, __ATOMIC_RELEASE);
     s.level = level;
     s.lds = lds;
@@ -2385,7 +2394,24 @@ int qzstd_hip_service_poke(int device, int level)
     if (device < 0 || device >= 64) return -1;
     Service &s = g_svc[device];
     if (!s.hs) return 1;
-    if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) != 0u) return 0;
+    if (__atomic_load_n(&s.hs->state, __ATOMIC_ACQUIRE) != 0u) {
+        /* resident — but do its workers run?  Another PROCESS's resident kernels may hold the LDS of every CU (nothing in this one
+         * can ask them to leave): a service whose dispatcher has seen no worker begin 200 ms after the launch is taken out of use at
+         * once, instead of after the callers' full time-out */
+        if (!s.sawWorkers) {
+            if (__atomic_load_n(&s.hs->dbg[3], __ATOMIC_RELAXED) != 0ull) s.sawWorkers = true;
+            else {
+                struct timespec t;
+                clock_gettime(CLOCK_MONOTONIC, &t);
+                if ((long long)t.tv_sec * 1000000000ll + t.tv_nsec - s.launchNs > 200000000ll) {
+                    s.broken = 1;
+                    __atomic_store_n(&s.hs->quitReq, 1u, __ATOMIC_RELEASE);
+                    return 2;
+                }
+            }
+        }
+        return 0;
+    }
     if (s.broken) return 2; /* out of use and gone: what it has not answered by now it never will */
     if (g_svcFreeze.load() > 0) return 1;
     std::lock_guard<std::mutex> g(s.mu);
