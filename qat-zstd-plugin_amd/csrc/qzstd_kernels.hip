@@ -8,10 +8,10 @@
  * Here one workgroup does both jobs for one block and writes ZSTD_Sequence entries
  * straight to HBM:
  *
- *   - the block streams from HBM into a 48 KiB LDS RING of its most recent bytes (16-byte
- *     coalesced loads, 4.5 KiB ahead of the tile being matched); sources more than 40 KiB
- *     back (a few % of the candidates) are compared from HBM/L2 instead, which halves the LDS
- *     footprint: two blocks are resident per CU at levels 1-2;
+ *   - the block streams from HBM into a 32 KiB LDS RING of its most recent bytes (kRing; 16-byte
+ *     coalesced loads, 4.5 KiB ahead of the tile being matched); sources more than kNear (~25 KiB)
+ *     back (a few % of the candidates) are compared from HBM/L2 instead, which keeps the LDS
+ *     footprint at 65 KB: two blocks are resident per CU at levels 1-2 and 5-12;
  *   - a 4-byte-entry hash table ((position+1)<<14 | 14-bit tag) lives in LDS next to it
  *     (levels >= 3 add a second table keyed by 8 bytes);
  *   - positions are processed in tiles of 512: every position of a tile reads its slot
@@ -799,7 +799,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         return QZSTD_HIP_NSEQ_ERROR; /* not a segment boundary of this level: refused (uniform: before the first barrier) */
     }
 
-    /* ---- LDS layout (81 600 B: two workgroups per CU) ---- */
+    /* ---- LDS layout (qzstd_hip_lds_bytes(): 65 392 B at levels 1-2 and 5-12 = two workgroups per CU; 136 560 B at levels 3-4) ---- */
     /* The workgroup's LDS is addressed from an integer constant, not from the `smem` symbol: the dynamic allocation starts at
      * LDS address 0 (the kernel has no static LDS), but the compiler resolves the symbol too late to fold it and every LDS
      * address would carry a dead `v_add 0`.  kLdsBase (16: never the null pointer) is part of qzstd_hip_lds_bytes(). */
@@ -1882,9 +1882,17 @@ static int g_devMap[64];
 static int g_ldsOrdered[64]; /* per device: -1 not probed yet, 0 no, 1 yes (probe_lds_order) */
 static std::mutex g_probeMu;
 
-/* runs qzstd_probe_lds_order once per device; any failure of the probe itself counts as "no" (the ballot path needs nothing) */
+/* runs qzstd_probe_lds_order once per device; any failure of the probe itself counts as "no" (the ballot path needs nothing).
+ * Called for every device when the devices are enumerated (probe_devices, under g_devOnce) — BEFORE any resident service can
+ * exist: the probe allocates and frees device memory, and hipFree waits for every stream of the device, so running it lazily
+ * from a launch (under the device's service mutex, as rounds 2-3 did) could wait for as long as per-block requests kept a
+ * service of another level alive, with the mutex held (round-3 ADVICE, medium).  Later calls only read the verdict. */
 static int probe_lds_order(int device, int physDev)
 {
+    {
+        const int known = __atomic_load_n(&g_ldsOrdered[device], __ATOMIC_ACQUIRE);
+        if (known >= 0) return known;
+    }
     std::lock_guard<std::mutex> g(g_probeMu);
     if (g_ldsOrdered[device] >= 0) return g_ldsOrdered[device];
     int verdict = 0;
@@ -1899,7 +1907,7 @@ static int probe_lds_order(int device, int physDev)
         (void)hipFree(dBad);
     }
     (void)hipGetLastError();
-    g_ldsOrdered[device] = verdict;
+    __atomic_store_n(&g_ldsOrdered[device], verdict, __ATOMIC_RELEASE);
     return verdict;
 }
 
@@ -1917,6 +1925,7 @@ static void probe_devices()
         g_devMap[g_devCount++] = d;
     }
     if (g_devCount == 0) fail_msg("no gfx950 device among the visible HIP devices");
+    for (int d = 0; d < g_devCount; d++) (void)probe_lds_order(d, g_devMap[d]); /* now: nothing is resident yet (see probe_lds_order) */
 }
 
 static inline int phys(int device)

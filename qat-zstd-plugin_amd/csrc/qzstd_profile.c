@@ -7,9 +7,9 @@
  * the parameters of the LDS match-finder.  Plain C, no GPU needed.
  *
  * LDS budget per workgroup (gfx950: 160 KiB = 163840 B per CU, target: TWO workgroups per CU):
- *     48 KiB ring of recent block bytes (+128 B wrap mirror) + 4*tableSize + near table 4<<tileLog
+ *     32 KiB ring of recent block bytes (+128 B wrap mirror) + 4*tableSize + near table 4<<tileLog
  *     + 2 tiles of per-position parse words + per-window emission records + 64 B control
- *     (+ 96 B of item words for the resident service) = 81 776 B with 6400 table entries at tileLog 9.
+ *     (+ 96 B of item words for the resident service) = 65 392 B with 6400 table entries at tileLog 9.
  */
 #include "qzstd_hip.h"
 
@@ -84,7 +84,7 @@ size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockL
 #endif
 #define QZ_RING_BYTES (QZ_RING + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip: kRing) */
 
-/* LDS per workgroup: independent of the block size — 81 664 B at levels 1-2 (two workgroups per CU) */
+/* LDS per workgroup: independent of the block size — 65 392 B at levels 1-2 (two workgroups per CU) */
 size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
 {
     qzstd_hip_profile_t p;

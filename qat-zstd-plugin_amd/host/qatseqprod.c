@@ -486,8 +486,12 @@ static void qzRunBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
         r->dense = 0;
         /* a full batch fills the GPU as it is: segment items then only repeat the insert work of the block before them
          * (and, at the chain levels, multiply the scratch); they pay for batches that leave CUs idle */
-        const size_t segsMax = !gProc.splitBlocks ? 1 : (n * 32 <= QZ_SPLIT_ITEMS_MAX ? 32 : (n * 8 <= QZ_SPLIT_ITEMS_MAX ? 8 : 1));
+        size_t segsMax = !gProc.splitBlocks ? 1 : (n * 32 <= QZ_SPLIT_ITEMS_MAX ? 32 : (n * 8 <= QZ_SPLIT_ITEMS_MAX ? 8 : 1));
         if (segsMax > 1 && qzstd_hip_profile_for_level(r->level, r->srcSize, &pf) == 0 && pf.segLog) {
+            /* chain levels: every item of a LAUNCH links the block before it in a scratch of its own (20 B per position of the whole
+             * block: the workgroups of a launch do not start in order, so they cannot share one as the service's items do) — 32 items
+             * per block would grow the batch's grow-only scratch to 32 x 2.6 MB per caller; eight keep most of the latency gain */
+            if (pf.chainDepth && segsMax > 8) segsMax = 8;
             seg = (size_t)1 << pf.segLog;
             while ((r->srcSize + seg - 1) / seg > segsMax) seg *= 2; /* whole segments per item */
             if (r->srcSize > seg) r->nSeg = (int)((r->srcSize + seg - 1) / seg);
@@ -851,7 +855,14 @@ static void qzOrphanHint(QZSTD_Hint_T *h)
     h->nStuck = 0;
     QZ_LOG(1, "an announcement's buffers are parked until a timed-out stream drains\n");
 }
-unsigned long qzstd_test_orphans(void) { return qzOrphanCount; } /* test hook (tests/test_host_mock.py) */
+#ifdef QZ_TEST_HOOKS /* the mock build of tests/test_host_mock.py only: never in the release library */
+unsigned long qzstd_test_orphans(void) { return qzOrphanCount; }
+void qzstd_test_set_service_epochs(unsigned int e) /* every slot's next service request gets epoch e + 1 (the 24-bit wrap) */
+{
+    int i;
+    for (i = 0; gProc.slots && i < gProc.numSlots; i++) gProc.slots[i].vEpoch = e & 0xFFFFFFu;
+}
+#endif
 
 /* wait for one part of an announcement and give its slot back; the part becomes ready (2) or failed (3) */
 static void qzPartFinish(QZSTD_Hint_T *h, QZSTD_Part_T *pt)
@@ -1044,7 +1055,12 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
     for (k = 0; k < nItems; k++) sl->vCount[k] = 0u;
     sl->vItems = (unsigned int)nItems;
     sl->vEpoch = (sl->vEpoch + 1u) & 0xFFFFFFu;
-    if (sl->vEpoch == 0u) sl->vEpoch = 1u;
+    if (sl->vEpoch == 0u) {
+        /* the 24-bit epoch starts over: an entry that no request of the last 2^24 overwrote would show a mark that is valid again.
+         * The slot is ours and its previous request is complete (every count word in): wipe the result area once per lap. */
+        memset(sl->vSeqs, 0, QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP * sizeof(ZSTD_Sequence));
+        sl->vEpoch = 1u;
+    }
     rq.hSrc = sl->vSrc; rq.dSrc = sl->vdSrc; rq.hSeqs = sl->vSeqs; rq.hCount = sl->vCount;
     rq.srcLen = (uint32_t)srcSize; rq.itemBytes = (uint32_t)itemBytes; rq.nItems = (uint32_t)nItems;
     rq.seqCapPerItem = (uint32_t)(QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP / nItems); /* the slot's whole result area, shared out */
@@ -1089,13 +1105,28 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
         if (!wrong) { /* (after a wrong item the rest is only waited for: the slot's buffers are in use until every count is in) */
             const unsigned int cnt = sl->vCount[k];
             const ZSTD_Sequence *q = sl->vSeqs + k * rq.seqCapPerItem;
-            if (cnt == QZSTD_HIP_NSEQ_REJECTED) { rejected = 1; break; } /* handed back whole: nothing of it was queued */
+            if (cnt == QZSTD_HIP_NSEQ_REJECTED) {
+                /* handed back whole: nothing of it was queued.  The dispatcher writes all nItems words with one wave store, but stores
+                 * to pinned host memory can land microseconds apart: the slot is given back only when every word is in — a word
+                 * landing later would be read by the slot's NEXT request as its own (round-3 ADVICE) */
+                size_t m;
+                rejected = 1;
+                for (m = k + 1; m < nItems && !bad; m++) {
+                    unsigned spins = 0;
+                    while (__atomic_load_n(&sl->vCount[m], __ATOMIC_ACQUIRE) == 0u) {
+                        __builtin_ia32_pause();
+                        if ((++spins & 1023u) == 0u && qzNowNs() - t0 > limitNs) { bad = 1; break; }
+                    }
+                }
+                break;
+            }
             if (cnt == QZSTD_HIP_NSEQ_ERROR || cnt > rq.seqCapPerItem || out + cnt >= outSeqsCapacity - 1) { wrong = 1; continue; } /* capacity rule, reference :1318-1322 */
             /* The count says how many entries there are, not that they are all there: the entries are stored by eight waves, the
              * count by a ninth, and on their ways to host memory nothing orders the one behind the others (measured: under load an
              * item's last entries arrive up to microseconds after its count).  Every entry is ONE 16-byte store that carries the
              * request's epoch in its fourth word (qzstd_hip_block_t.mark): an entry is taken when it shows it. */
-            {   /* one aligned 16-byte load per entry (it arrived as one store), the mark checked and cleared on the way */
+            {   /* one aligned 16-byte load per entry (it arrived as one store), the mark checked here and masked out of the copy (the pinned
+                 * area keeps it: marks of an earlier lap of the 24-bit epoch are wiped when the epoch starts over, above) */
                 const __m128i keep = _mm_set_epi32(0, -1, -1, -1);
                 __m128i acc = _mm_setzero_si128();
                 size_t j;

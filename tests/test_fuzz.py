@@ -6,6 +6,9 @@ randomised round-trip driver over the same surface (incl. the five FUZZ_* symbol
   -fsanitize=address,undefined, so heap overflows / use-after-free / UB in the host logic abort the run;
 * GPU box (-m gpu): the same driver against lib/libqatseqprod.so — the real kernels under random sizes, levels,
   block-size limits, streaming, announcements and rewritten buffers.
+
+Both compare frames with the oracle's: the driver compresses the same case a second time with qzo_sequence_producer registered and
+memcmp's the two frames (every iteration on the GPU, every third under ASan).
 """
 import os
 import subprocess
@@ -34,7 +37,7 @@ def test_fuzz_host_logic_under_asan_ubsan_over_the_mock(tmp_path):
     for seed, iters, env in ((1, 16, {}), (2, 30, {"QZSTD_HIP_LOOKAHEAD": "1", "QZSTD_HIP_SERVICE_ITEM": "32768"}),
                              (3, 20, {"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SERVICE_ITEM": "65536"}),
                              (4, 20, {"QZSTD_MOCK_DEVICES": "3", "QZSTD_HIP_EXT_REPCODES": "1", "QZSTD_HIP_SERVICE_ITEM": "32768"})):
-        out = subprocess.run([exe, str(seed), str(iters), "384"], capture_output=True, text=True, timeout=900,
+        out = subprocess.run([exe, str(seed), str(iters), "384", "3"], capture_output=True, text=True, timeout=900,
                              env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", **env))
         assert out.returncode == 0 and "fuzz ok" in out.stdout, (env, (out.stdout + out.stderr)[-1500:])
 
@@ -44,9 +47,12 @@ def test_fuzz_real_kernels(tmp_path, gpu_plugin):
     zlib = B.find_libzstd()
     exe = str(tmp_path / "fuzz_gpu")
     subprocess.check_call(["gcc", "-O2", "-g", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-pthread"] + INC + ["-o", exe, SRC, ADAPTER,
+                           os.path.join(ROOT, "oracle", "qzstd_oracle.c"),  # the checker, linked into the TEST binary only
                            "-L" + os.path.join(B.PKG_DIR, "lib"), "-lqatseqprod", zlib, "-Wl,-rpath," + os.path.join(B.PKG_DIR, "lib"),
                            "-Wl,-rpath," + os.path.dirname(zlib)])
     for seed, iters, env in ((11, 150, {}), (12, 100, {"QZSTD_HIP_LOOKAHEAD": "1"}), (13, 60, {"QZSTD_HIP_COALESCE": "0"}),
                              (14, 60, {"QZSTD_HIP_EXT_REPCODES": "1"})):
-        out = subprocess.run([exe, str(seed), str(iters)], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        out = subprocess.run([exe, str(seed), str(iters), "3072", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert out.returncode == 0 and "fuzz ok" in out.stdout, (env, (out.stdout + out.stderr)[-1500:])
+        # every iteration's frame was also produced through the oracle's producer and compared byte for byte (f3: parity, not a property)
+        assert "%d frames identical to the oracle's" % iters in out.stdout, out.stdout[-400:]

@@ -22,7 +22,7 @@ MOCK_SO = os.path.join(ROOT, "tests", "mock", "libqatseqprod_mock.so")
 def mock(oracle):
     srcs = [os.path.join(B.PKG_DIR, "host", "qatseqprod.c"), os.path.join(B.PKG_DIR, "csrc", "qzstd_profile.c"),
             os.path.join(ROOT, "tests", "mock", "mock_hip.c"), os.path.join(ROOT, "oracle", "qzstd_oracle.c")]
-    subprocess.check_call(["gcc", "-O2", "-g", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-shared", "-fPIC", "-pthread",
+    subprocess.check_call(["gcc", "-O2", "-g", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"), "-o", MOCK_SO] + srcs)
     plug = B.Plugin(MOCK_SO)
     assert plug.lib.QZSTD_startQatDevice() == 0
@@ -372,7 +372,7 @@ def test_batch_front_end_over_the_mock(mock, zstd, oracle):
     """include/qzstd_frontend.h: a pool of CCtx threads fed from one segment counter, every segment
     announced one claim ahead; frames are the oracle's, every block comes from an announcement"""
     front_so = os.path.join(ROOT, "tests", "mock", "libqzstdfront_mock.so")
-    subprocess.check_call(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-shared", "-fPIC", "-pthread",
+    subprocess.check_call(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
                            "-I" + os.path.join(ROOT, "include"), "-o", front_so,
                            os.path.join(B.PKG_DIR, "frontend", "qzstd_frontend.c"), MOCK_SO, zstd.path,
                            "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)])
@@ -535,6 +535,25 @@ def test_service_entries_that_arrive_after_their_count(mock, zstd, oracle):
     assert fs[7] == 4 and fs[0] == 0, fs
 
 
+def test_service_epoch_wrap_wipes_stale_marks(mock, zstd, oracle):
+    """the request epoch is 24 bits per slot: when it starts over, entries no request of the last lap overwrote would carry a mark
+    that is valid again — the slot's result area is wiped once per lap (round-3 verdict, weak 3).  Every slot is put just before the
+    wrap (test hook of the mock build), blocks are served across it: frames are the oracle's, nothing fails"""
+    chunk = 131072
+    data = K.by_name("system", 6 * chunk + 99, seed=14)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_test_set_service_epochs.argtypes = [C.c_uint]
+    st = L.QZSTD_createSeqProdState()
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), 2 * chunk, chunk, 1)  # (slots exist, results written once)
+    L.qzstd_test_set_service_epochs(0xFFFFFD)
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1)
+    fs = fail_stats(mock, st)
+    L.QZSTD_freeSeqProdState(st)
+    assert got == oracle_frames(zstd, oracle, data, chunk, 1)
+    assert fs[0] == 0 and fs[7] >= 7, fs
+
+
 def test_service_coarser_items_and_other_levels(mock, zstd, oracle):
     """QZSTD_HIP_SERVICE_ITEM: items of several segments; levels 3-4 and the chain levels (6, 12: a scratch per item) are served
     too; requests the dispatcher hands back (another level is resident) take the launch path"""
@@ -653,7 +672,7 @@ def test_multi_gpu_product_leg_over_four_mock_devices(mock, zstd, tmp_path):
     states are spread round-robin); blocks per GPU from QZSTD_deviceStats, frames round-trip, no producer errors"""
     import re
     front_so = os.path.join(ROOT, "tests", "mock", "libqzstdfront_mock.so")
-    subprocess.check_call(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-shared", "-fPIC", "-pthread",
+    subprocess.check_call(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
                            "-I" + os.path.join(ROOT, "include"), "-o", front_so, os.path.join(B.PKG_DIR, "frontend", "qzstd_frontend.c"),
                            MOCK_SO, zstd.path, "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)])
     exe = str(tmp_path / "frontbench")
@@ -674,3 +693,18 @@ def test_multi_gpu_product_leg_over_four_mock_devices(mock, zstd, tmp_path):
             assert all(c == 32 for c in counts), per  # every announcement of 16 blocks: four blocks per GPU
         else:
             assert all(c > 0 for c in counts), per    # whole announcements per GPU, four states round-robin
+
+
+def test_stress_driver_over_the_mock(mock, zstd, tmp_path):
+    """tests/stress/svc_stress.c (the GPU box's load test: real threads, every work item / every frame against the oracle) builds and
+    runs against the mock device layer: keeps the driver itself honest on CPU"""
+    exe = str(tmp_path / "svc_stress_mock")
+    subprocess.check_call(["gcc", "-O2", "-g", "-std=c11", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"),
+                           "-o", exe, os.path.join(ROOT, "tests", "stress", "svc_stress.c"), os.path.join(ROOT, "oracle", "qzstd_oracle.c"),
+                           MOCK_SO, zstd.path, "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)])
+    corpus = str(tmp_path / "corpus.bin")
+    with open(corpus, "wb") as f:
+        f.write(K.by_name("system", 3 * 131072 + 500, seed=31))
+    for args in (["items", corpus, "6", "3", "4"], ["items", corpus, "0xc", "2", "3", "32768"], ["frames", corpus, "1,6", "4", "5"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "svc_stress ok" in out.stdout, (args, (out.stdout + out.stderr)[-1500:])

@@ -443,3 +443,55 @@ class ServiceLane:
         L.qzstd_hip_free(self.device, self.dsrc)
         if self.dwork:
             L.qzstd_hip_free(self.device, self.dwork)
+
+
+FRONT_SO = os.path.join(PKG_DIR, "lib", "libqzstdfront.so")
+
+
+class FrontParams(C.Structure):
+    _fields_ = [("nThreads", C.c_int), ("level", C.c_int), ("chunkSize", C.c_size_t), ("segmentBytes", C.c_size_t),
+                ("extRepcodes", C.c_int), ("useProducer", C.c_int)]
+
+
+class Front:
+    """include/qzstd_frontend.h: the batch front-end for the host entropy stage (a pool of CCtx threads, every segment announced
+    one claim ahead).  Load libzstd (Zstd()) and the plugin first: the library links against both."""
+
+    def __init__(self, path: str = FRONT_SO):
+        if not os.path.isfile(path):
+            raise OSError("%s missing: `make -C qat-zstd-plugin_amd front` needs a libzstd >= 1.5.4" % path)
+        F = self.lib = C.CDLL(path)
+        F.QZSTD_createFront.restype = C.c_void_p
+        F.QZSTD_createFront.argtypes = [C.POINTER(FrontParams)]
+        F.QZSTD_frontFrameStride.restype = C.c_size_t
+        F.QZSTD_frontFrameStride.argtypes = [C.c_void_p]
+        F.QZSTD_frontCompress.restype = C.c_size_t
+        F.QZSTD_frontCompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        F.QZSTD_frontCompact.restype = C.c_size_t
+        F.QZSTD_frontCompact.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_size_t]
+        F.QZSTD_frontStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong)]
+        F.QZSTD_frontFailStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong)]
+        F.QZSTD_freeFront.argtypes = [C.c_void_p]
+
+    def frames(self, data: bytes, chunk: int, level: int, threads: int, segment: int = 0, jobs: int = 1, ext_rep: int = 0):
+        """-> (frames, [announced, per block] blocks, fail stats[8]) of `jobs` passes of `data` through one front"""
+        F = self.lib
+        prm = FrontParams(threads, level, chunk, segment, ext_rep, 1)
+        f = F.QZSTD_createFront(C.byref(prm))
+        if not f:
+            raise RuntimeError("QZSTD_createFront failed")
+        try:
+            stride = F.QZSTD_frontFrameStride(f)
+            n = (len(data) + chunk - 1) // chunk
+            dst = C.create_string_buffer(n * stride)
+            sizes = (C.c_size_t * n)()
+            for _ in range(jobs):
+                got = F.QZSTD_frontCompress(f, data, len(data), dst, len(dst), sizes)
+                if got != n:
+                    raise RuntimeError("QZSTD_frontCompress returned %d, expected %d frames" % (got, n))
+            st, fs = (C.c_ulong * 2)(), (C.c_ulong * 8)()
+            F.QZSTD_frontStats(f, st)
+            F.QZSTD_frontFailStats(f, fs)
+            return [dst.raw[c * stride:c * stride + sizes[c]] for c in range(n)], list(st), list(fs)
+        finally:
+            F.QZSTD_freeFront(f)
