@@ -311,3 +311,17 @@ def test_fuzz_adapter_exports_the_five_hooks():
               "FUZZ_thirdPartySeqProd"):
         assert re.search(r" T %s$" % s, syms, re.M), s
     assert " U qatSequenceProducer" in syms and " U QZSTD_stopQatDevice" not in syms
+
+
+def test_bench_rank_sees_its_own_gpu_only(monkeypatch):
+    """bench.py --gpus N: one process per GPU, and the plugin INSIDE rank r (front-end, slots, services) must use GPU r and no other —
+    the rank narrows HIP_VISIBLE_DEVICES before HIP starts, indexing into whatever the job was started with"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("qz_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    assert bench.narrow_to_own_gpu(1, 0) is None and "HIP_VISIBLE_DEVICES" not in os.environ  # one rank: nothing is narrowed
+    assert bench.narrow_to_own_gpu(8, 5) is None and os.environ["HIP_VISIBLE_DEVICES"] == "5"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
+    assert bench.narrow_to_own_gpu(4, 2) == "4,5,6,7" and os.environ["HIP_VISIBLE_DEVICES"] == "6"
