@@ -144,7 +144,9 @@ void QZSTD_failStats(void *sequenceProducerState, unsigned long stats[8]);
 /* Process-wide, per GPU (the blocks shard across the GPUs of a node with no exchange step; reference analogue: instances
  * interleaved across devices, src/qatseqprod.c:601-630): stats[0] = blocks queued on that GPU from announcements (an
  * announcement is cut into contiguous ranges, one per GPU), [1] = blocks that went through its batches, [2] = blocks served by
- * its resident service, [3] = 0, since QZSTD_startQatDevice().  Returns the number of GPUs in use (stats may be NULL). */
+ * its resident service, since QZSTD_startQatDevice(); [3] = the host NUMA node the GPU is attached to + 1 (0 = unknown): pinned staging
+ * buffers, result areas and request rings of a GPU are allocated on that node, and a state's GPU is picked among the GPUs of the socket
+ * its thread runs on when it is first used (QZSTD_HIP_NUMA=0 turns both off; reference: qaeMemAllocNUMA, src/qatseqprod.c:216-246).  Returns the number of GPUs in use (stats may be NULL). */
 int QZSTD_deviceStats(int device, unsigned long stats[4]);
 
 #if defined(__cplusplus)

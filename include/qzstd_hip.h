@@ -197,6 +197,17 @@ int qzstd_hip_service_info(int device, unsigned long out[8]);
 int qzstd_hip_service_debug(int device, unsigned long out[8]);
 void *qzstd_hip_host_alloc_coherent(size_t bytes); /* pinned + mapped + fine-grained: what the host polls while a kernel writes it */
 
+/* ---- NUMA placement (reference: every DMA buffer is allocated on a NUMA node, qaeMemAllocNUMA(size, node, 64),
+ * /root/reference/src/qatseqprod.c:216-246): on a two-socket node half the GPUs hang off each socket, and pinned staging buffers,
+ * result areas and request rings that sit on the other socket cross the inter-socket link on every access. */
+/* host NUMA node the GPU is attached to (hipDeviceAttributeHostNumaId, else sysfs numa_node of its PCI function); -1 = unknown */
+int qzstd_hip_device_numa_node(int device);
+/* qzstd_hip_host_alloc() / _coherent() with the pages on `node` (node < 0: wherever the calling thread's policy puts them).
+ * Best effort: where the kernel does not let the process set a memory policy, the allocation still succeeds, unplaced. */
+void *qzstd_hip_host_alloc_on_node(size_t bytes, int node, int coherent);
+/* NUMA node that holds the first page of a host buffer (-1 = cannot tell): diagnostics, tests */
+int qzstd_hip_host_node_of(const void *hptr);
+
 #if defined(__cplusplus)
 }
 #endif

@@ -52,6 +52,8 @@
 #include <mutex>
 #include <sched.h>
 #include <time.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "qzstd_hip.h"
 
@@ -1998,6 +2000,59 @@ void *qzstd_hip_host_alloc_coherent(size_t bytes)
     return p;
 }
 
+/* The GPU's host NUMA node: the runtime's attribute first, the PCI function's sysfs entry second */
+int qzstd_hip_device_numa_node(int device)
+{
+    const int pd = phys(device);
+    if (pd < 0) return -1;
+    int node = -1;
+    if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, pd) == hipSuccess && node >= 0) return node;
+    (void)hipGetLastError();
+    char bus[32] = "", path[96];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), pd) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a'); /* sysfs spells the address in lower case */
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+/* Pinned host memory on a NUMA node: hipHostMallocNumaUser makes the runtime allocate under the CALLING THREAD's memory policy, so
+ * the policy is set to "prefer `node`" around the call (raw system calls: no libnuma in the image) and put back afterwards.  A
+ * process that may not set a policy (seccomp, containers without CAP_SYS_NICE for other nodes) gets the memory anyway, unplaced. */
+void *qzstd_hip_host_alloc_on_node(size_t bytes, int node, int coherent)
+{
+    const unsigned flags = hipHostMallocPortable | hipHostMallocMapped | (coherent ? hipHostMallocCoherent : 0u);
+    void *p = nullptr;
+    if (node >= 0 && node < 1024) {
+        unsigned long want[16] = { 0 }, old[16] = { 0 };
+        int oldMode = 0;
+        want[node / (8 * sizeof(unsigned long))] = 1ul << (node % (8 * sizeof(unsigned long)));
+        const bool got = syscall(SYS_get_mempolicy, &oldMode, old, (unsigned long)(8 * sizeof(old)), nullptr, 0ul) == 0;
+        if (got && syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, want, (unsigned long)(8 * sizeof(want))) == 0) {
+            const hipError_t e = hipHostMalloc(&p, bytes, flags | hipHostMallocNumaUser);
+            (void)syscall(SYS_set_mempolicy, oldMode, oldMode == 0 /* MPOL_DEFAULT takes no mask */ ? nullptr : old,
+                          oldMode == 0 ? 0ul : (unsigned long)(8 * sizeof(old)));
+            if (e == hipSuccess) return p;
+            (void)hipGetLastError();
+            p = nullptr;
+        }
+    }
+    const hipError_t e = hipHostMalloc(&p, bytes, flags);
+    if (e != hipSuccess) { fail(coherent ? "hipHostMalloc(coherent)" : "hipHostMalloc", e); return nullptr; }
+    return p;
+}
+
+int qzstd_hip_host_node_of(const void *hptr)
+{
+    int node = -1;
+    if (!hptr) return -1;
+    if (syscall(SYS_get_mempolicy, &node, nullptr, 0ul, hptr, 3ul /* MPOL_F_NODE | MPOL_F_ADDR */) != 0) return -1;
+    return node;
+}
+
 void qzstd_hip_host_free(void *hptr)
 {
     if (!hptr) return;
@@ -2251,7 +2306,13 @@ int svc_launch_locked(int device, Service &s, int level)
         s.workers = cfg.workers > 0 ? cfg.workers : prop.multiProcessorCount;
         if (s.workers > 1024) s.workers = 1024;
         void *h = nullptr, *d = nullptr;
-        QZ_CHECK(hipHostMalloc(&h, sizeof(SvcHost), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(service ring)");
+        /* the request ring the dispatcher polls and the callers write: on the GPU's own NUMA node (QZSTD_HIP_NUMA=0: wherever) */
+        {
+            const char *nm = getenv("QZSTD_HIP_NUMA");
+            h = qzstd_hip_host_alloc_on_node(sizeof(SvcHost), (nm && atoi(nm) == 0) ? -1 : qzstd_hip_device_numa_node(device), 1);
+            if (!h) return fail_msg("service: no pinned memory for the request ring");
+            QZ_SET_DEVICE(device); /* (the node query may have looked at other devices) */
+        }
         memset(h, 0, sizeof(SvcHost));
         /* streams of the highest priority: hardware queues of their own, so that neither kernel is serialised behind a batch
          * kernel that happens to share a queue with it */

@@ -41,6 +41,7 @@
 #include <string.h>
 #include <emmintrin.h>
 #include <sys/prctl.h>
+#include <sys/syscall.h>
 #include <sys/types.h>
 #include <sys/uio.h>
 #include <time.h>
@@ -165,6 +166,7 @@ typedef struct {
     unsigned long launches, blocks, batches;
 } QZSTD_Coalescer_T;
 #define QZ_SRC_STRIDE ((size_t)QZSTD_HIP_BLOCK_MAX + 64)
+#define QZ_NUMA_NODES_MAX 16
 
 typedef struct {
     int status; /* QZSTD_Status_e */
@@ -184,9 +186,16 @@ typedef struct {
     int svcSpinUs;           /* QZSTD_HIP_SERVICE_SPIN_US (default 400): busy polling of the count words before napping */
     unsigned long devBlocks[QZ_MAX_DEVICES][3]; /* per GPU: blocks queued from announcements, blocks through batches, blocks through the service */
     pthread_mutex_t mutex;
+    /* NUMA (reference: qaeMemAllocNUMA(size, node, 64) for every DMA buffer, src/qatseqprod.c:216-246): the host node every GPU hangs
+     * off, so that a slot's / batch's / announcement's pinned memory sits next to its GPU and a state lands on a GPU of the socket
+     * its thread runs on */
+    int numa;                      /* QZSTD_HIP_NUMA (default 1) */
+    int numaThreadNode;            /* QZSTD_HIP_NUMA_NODE: treat every calling thread as running on this node (-1: ask the kernel) */
+    int devNode[QZ_MAX_DEVICES];   /* -1 = unknown */
+    unsigned int nodeNext[QZ_NUMA_NODES_MAX], anyNext; /* round-robin counters: per node, and the fallback over all GPUs */
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER, 1, -1, { 0 }, { 0 }, 0 };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
  * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
@@ -338,6 +347,45 @@ static void qzFreeSlot(QZSTD_Slot_T *s)
     }
 }
 
+/* ---- NUMA placement ---- */
+/* pinned host memory that device `dev` reads or writes: on the NUMA node the GPU is attached to (reference: qaeMemAllocNUMA on the
+ * instance's node, src/qatseqprod.c:216-246).  QZSTD_HIP_NUMA=0 or an unknown node: wherever the calling thread's policy puts it */
+static void *qzHostAlloc(size_t bytes, int dev, int coherent)
+{
+    const int node = (gProc.numa && dev >= 0 && dev < QZ_MAX_DEVICES) ? gProc.devNode[dev] : -1;
+    return qzstd_hip_host_alloc_on_node(bytes, node, coherent);
+}
+
+/* the NUMA node the calling thread runs on right now (-1 = unknown) */
+static int qzThreadNode(void)
+{
+    unsigned int cpu = 0, node = 0;
+    if (gProc.numaThreadNode >= 0) return gProc.numaThreadNode;
+#ifdef SYS_getcpu
+    if (syscall(SYS_getcpu, &cpu, &node, NULL) == 0) return (int)node;
+#endif
+    (void)cpu;
+    return -1;
+}
+
+/* The sticky hint of a state at its first use: hint % numDevices is its GPU, hint / numDevices where its slot sweeps start.  A GPU of
+ * the socket the calling thread runs on if there is one (round-robin among those), else round-robin over all GPUs — the reference
+ * interleaves its instances across devices (src/qatseqprod.c:601-630) and leaves locality to the instance's node. */
+static int qzPickHint(void)
+{
+    const int nd = gProc.numDevices, node = gProc.numa ? qzThreadNode() : -1;
+    if (nd <= 0) return 0;
+    if (node >= 0) {
+        int local[QZ_MAX_DEVICES], n = 0, d;
+        for (d = 0; d < nd && d < QZ_MAX_DEVICES; d++) if (gProc.devNode[d] == node) local[n++] = d;
+        if (n > 0 && n < nd) { /* (every GPU on this node = plain round-robin below) */
+            const unsigned int k = __sync_fetch_and_add(&gProc.nodeNext[(unsigned)node % QZ_NUMA_NODES_MAX], 1u) & 0xFFFFFu;
+            return local[k % (unsigned)n] + nd * (int)(k / (unsigned)n);
+        }
+    }
+    return (int)(__sync_fetch_and_add(&gProc.anyNext, 1u) & 0x3FFFFFFFu);
+}
+
 /* lazy per-slot setup, first use only (reference: QZSTD_allocInstMem, :685-822); `full` also creates the buffers of the
  * one-block path (an announced batch only needs the stream and the grow-only batch buffers) */
 static int qzSetupSlot(QZSTD_Slot_T *s, int full)
@@ -351,10 +399,10 @@ static int qzSetupSlot(QZSTD_Slot_T *s, int full)
     }
     if (!full || s->ready) return QZSTD_OK;
     s->seqCap = qzstd_hip_sequence_bound(QZSTD_HIP_BLOCK_MAX);
-    s->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZSTD_HIP_BLOCK_MAX + 64);
-    s->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(s->seqCap * sizeof(ZSTD_Sequence));
-    s->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(sizeof(qzstd_hip_block_t));
-    s->hCount = (unsigned int *)qzstd_hip_host_alloc(64);
+    s->hSrc = (unsigned char *)qzHostAlloc(QZSTD_HIP_BLOCK_MAX + 64, s->device, 0);
+    s->hSeqs = (ZSTD_Sequence *)qzHostAlloc(s->seqCap * sizeof(ZSTD_Sequence), s->device, 0);
+    s->hDesc = (qzstd_hip_block_t *)qzHostAlloc(sizeof(qzstd_hip_block_t), s->device, 0);
+    s->hCount = (unsigned int *)qzHostAlloc(64, s->device, 0);
     s->dSrc = (unsigned char *)qzstd_hip_malloc(s->device, QZSTD_HIP_BLOCK_MAX + 64);
     s->dSeqs = (ZSTD_Sequence *)qzstd_hip_malloc(s->device, s->seqCap * sizeof(ZSTD_Sequence));
     s->dDesc = (qzstd_hip_block_t *)qzstd_hip_malloc(s->device, sizeof(qzstd_hip_block_t));
@@ -446,10 +494,10 @@ static int qzSetupBatch(QZSTD_Coalescer_T *c, QZSTD_Batch_T *bt)
     if (bt->ready) return QZSTD_OK;
     bt->stream = qzstd_hip_stream_create(c->device);
     bt->dSrc = (unsigned char *)qzstd_hip_malloc(c->device, QZ_BATCH_MAX * QZ_SRC_STRIDE);
-    bt->hSrc = (unsigned char *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_SRC_STRIDE);
-    bt->hSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc(QZ_BATCH_MAX * QZ_BATCH_PITCH * sizeof(ZSTD_Sequence));
-    bt->hDesc = (qzstd_hip_block_t *)qzstd_hip_host_alloc(QZ_DESC_MAX * sizeof(qzstd_hip_block_t));
-    bt->hCount = (unsigned int *)qzstd_hip_host_alloc(QZ_DESC_MAX * sizeof(unsigned int));
+    bt->hSrc = (unsigned char *)qzHostAlloc(QZ_BATCH_MAX * QZ_SRC_STRIDE, c->device, 0);
+    bt->hSeqs = (ZSTD_Sequence *)qzHostAlloc(QZ_BATCH_MAX * QZ_BATCH_PITCH * sizeof(ZSTD_Sequence), c->device, 0);
+    bt->hDesc = (qzstd_hip_block_t *)qzHostAlloc(QZ_DESC_MAX * sizeof(qzstd_hip_block_t), c->device, 0);
+    bt->hCount = (unsigned int *)qzHostAlloc(QZ_DESC_MAX * sizeof(unsigned int), c->device, 0);
     bt->dvSeqs = qzstd_hip_host_device_ptr(bt->hSeqs);
     bt->dvDesc = qzstd_hip_host_device_ptr(bt->hDesc);
     bt->dvCount = qzstd_hip_host_device_ptr(bt->hCount);
@@ -719,6 +767,14 @@ static int qzBuildSlots(void)
     gProc.numSlots = nDev * perDev;
     memset(gProc.devBlocks, 0, sizeof(gProc.devBlocks));
     for (i = 0; i < gProc.numSlots; i++) gProc.slots[i].device = i % nDev;
+    gProc.numa = qzEnvInt("QZSTD_HIP_NUMA", 1, 0, 1);
+    gProc.numaThreadNode = qzEnvInt("QZSTD_HIP_NUMA_NODE", -1, -1, 1023);
+    memset(gProc.nodeNext, 0, sizeof(gProc.nodeNext));
+    gProc.anyNext = 0;
+    for (i = 0; i < nDev && i < QZ_MAX_DEVICES; i++) {
+        gProc.devNode[i] = qzstd_hip_device_numa_node(i);
+        QZ_LOG(2, "device %d: host NUMA node %d\n", i, gProc.devNode[i]);
+    }
     gProc.coalesce = qzEnvInt("QZSTD_HIP_COALESCE", 1, 0, 1);
     gProc.split = qzEnvInt("QZSTD_HIP_SPLIT", nDev < QZ_HINT_PARTS ? nDev : QZ_HINT_PARTS, 1, nDev < QZ_HINT_PARTS ? nDev : QZ_HINT_PARTS);
     gProc.coal = (QZSTD_Coalescer_T *)calloc((size_t)nDev, sizeof(QZSTD_Coalescer_T));
@@ -1002,9 +1058,9 @@ fail:
 static int qzSetupSlotService(QZSTD_Slot_T *sl)
 {
     if (sl->vSrc) return 0;
-    sl->vSrc = (unsigned char *)qzstd_hip_host_alloc_coherent(QZSTD_HIP_BLOCK_MAX + 64);
-    sl->vSeqs = (ZSTD_Sequence *)qzstd_hip_host_alloc_coherent(QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP * sizeof(ZSTD_Sequence));
-    sl->vCount = (unsigned int *)qzstd_hip_host_alloc_coherent(QZ_SVC_ITEMS_MAX * sizeof(unsigned int));
+    sl->vSrc = (unsigned char *)qzHostAlloc(QZSTD_HIP_BLOCK_MAX + 64, sl->device, 1);
+    sl->vSeqs = (ZSTD_Sequence *)qzHostAlloc(QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP * sizeof(ZSTD_Sequence), sl->device, 1);
+    sl->vCount = (unsigned int *)qzHostAlloc(QZ_SVC_ITEMS_MAX * sizeof(unsigned int), sl->device, 1);
     sl->vdSrc = (unsigned char *)qzstd_hip_malloc(sl->device, QZSTD_HIP_BLOCK_MAX + 64);
     if (!sl->vSrc || !sl->vSeqs || !sl->vCount || !sl->vdSrc) {
         QZ_LOG(1, "service buffers of a slot on device %d: %s\n", sl->device, qzstd_hip_last_error());
@@ -1394,11 +1450,8 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
         }
     }
 
-    {
-        /* sticky device per state, states spread round-robin over the GPUs */
-        static volatile unsigned int nextDev = 0;
-        if (s->slotHint < 0) s->slotHint = (int)(__sync_fetch_and_add(&nextDev, 1u) & 0x3FFFFFFFu);
-    }
+    /* sticky device per state: a GPU of the calling thread's socket if there is one, states spread round-robin (qzPickHint) */
+    if (s->slotHint < 0) s->slotHint = qzPickHint();
     rc = qzServiceBlock(s, s->slotHint % gProc.numDevices, outSeqs, outSeqsCapacity, src, srcSize, compressionLevel | gProc.levelFlags);
     if (rc != QZ_NOT_SERVED) {
         QZ_LOG(2, "block %zu B level %d -> %zu sequences (service, device %d)\n", srcSize, compressionLevel, rc, s->slotHint % gProc.numDevices);
@@ -1418,13 +1471,13 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
 /* ---------------------------------------------------------------- look-ahead ----- */
 
 /* grow-only buffers: returns the (possibly new) pointer, NULL on failure */
-static void *qzGrowHost(void *old, size_t *cap, size_t need)
+static void *qzGrowHost(void *old, size_t *cap, size_t need, int dev)
 {
     void *p;
     if (old && *cap >= need) return old;
     if (old) memset(old, 0, *cap); /* staged caller data: scrubbed before the pages go back */
     qzstd_hip_host_free(old);
-    p = qzstd_hip_host_alloc(need);
+    p = qzHostAlloc(need, dev, 0); /* next to the state's own GPU (the first of the GPUs an announcement is split across) */
     *cap = p ? need : 0;
     return p;
 }
@@ -1444,7 +1497,10 @@ int QZSTD_deviceStats(int device, unsigned long stats[4])
     int k;
     if (stats) for (k = 0; k < 4; k++) stats[k] = 0;
     if (stats && device >= 0 && device < gProc.numDevices && device < QZ_MAX_DEVICES)
+    {
         for (k = 0; k < 3; k++) stats[k] = __atomic_load_n(&gProc.devBlocks[device][k], __ATOMIC_RELAXED);
+        stats[3] = (unsigned long)(gProc.devNode[device] + 1); /* host NUMA node of the GPU + 1 (0 = unknown) */
+    }
     return gProc.numDevices;
 }
 
@@ -1628,10 +1684,12 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     blocksBytes = nb * sizeof(qzstd_hip_block_t);
     srcBytes = (srcSize + 63) & ~(size_t)63;
 
-    h->hSrc = (unsigned char *)qzGrowHost(h->hSrc, &h->hSrcCap, srcBytes);
-    h->hDesc = (qzstd_hip_block_t *)qzGrowHost(h->hDesc, &h->hDescCap, blocksBytes);
-    h->hCount = (unsigned int *)qzGrowHost(h->hCount, &h->hCountCap, nb * sizeof(unsigned int));
-    h->hSeqs = (ZSTD_Sequence *)qzGrowHost(h->hSeqs, &h->hSeqsCap, nb * h->pitch * sizeof(ZSTD_Sequence));
+    if (s->slotHint < 0) s->slotHint = qzPickHint(); /* the state's own GPU: sticky from its first use */
+    firstDev = s->slotHint % gProc.numDevices;
+    h->hSrc = (unsigned char *)qzGrowHost(h->hSrc, &h->hSrcCap, srcBytes, firstDev);
+    h->hDesc = (qzstd_hip_block_t *)qzGrowHost(h->hDesc, &h->hDescCap, blocksBytes, firstDev);
+    h->hCount = (unsigned int *)qzGrowHost(h->hCount, &h->hCountCap, nb * sizeof(unsigned int), firstDev);
+    h->hSeqs = (ZSTD_Sequence *)qzGrowHost(h->hSeqs, &h->hSeqsCap, nb * h->pitch * sizeof(ZSTD_Sequence), firstDev);
     h->dvDesc = qzstd_hip_host_device_ptr(h->hDesc);
     h->dvCount = qzstd_hip_host_device_ptr(h->hCount);
     h->dvSeqs = qzstd_hip_host_device_ptr(h->hSeqs);
@@ -1681,11 +1739,6 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     /* contiguous block ranges, one per GPU, starting at this state's own GPU; a range is worth a launch from 4 blocks */
     parts = speculative ? 1 : gProc.split;
     if ((size_t)parts > nb / 4) parts = nb / 4 ? (int)(nb / 4) : 1;
-    if (s->slotHint < 0) {
-        static volatile unsigned int nextHintDev = 0;
-        s->slotHint = (int)(__sync_fetch_and_add(&nextHintDev, 1u) & 0x3FFFFFFFu);
-    }
-    firstDev = s->slotHint % gProc.numDevices;
     h->nParts = 0;
     for (k = 0; k < parts; k++) {
         const size_t b0 = nb * (size_t)k / (size_t)parts, b1 = nb * (size_t)(k + 1) / (size_t)parts;

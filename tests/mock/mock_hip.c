@@ -48,6 +48,26 @@ int qzstd_hip_device_name(int device, char *buf, size_t bufLen)
 void *qzstd_hip_malloc(int device, size_t bytes) { (void)device; return malloc(bytes ? bytes : 1); }
 void qzstd_hip_free(int device, void *p) { (void)device; free(p); }
 void *qzstd_hip_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+/* NUMA, mocked: QZSTD_MOCK_NODES = k puts mock device d on node d % k (default: every device on node 0); allocations "on a node"
+ * are plain malloc, counted per node (test hook qzstd_mock_node_allocs) */
+static unsigned long gNodeAllocs[16], gUnplacedAllocs;
+int qzstd_hip_device_numa_node(int device)
+{
+    const char *v = getenv("QZSTD_MOCK_NODES");
+    const int k = v ? atoi(v) : 1;
+    if (k < 0) return -1; /* "unknown" */
+    return k > 1 ? device % k : 0;
+}
+void *qzstd_hip_host_alloc_on_node(size_t bytes, int node, int coherent)
+{
+    (void)coherent;
+    if (node >= 0 && node < 16) __atomic_fetch_add(&gNodeAllocs[node], 1ul, __ATOMIC_RELAXED);
+    else __atomic_fetch_add(&gUnplacedAllocs, 1ul, __ATOMIC_RELAXED);
+    return malloc(bytes ? bytes : 1);
+}
+int qzstd_hip_host_node_of(const void *h) { (void)h; return -1; }
+unsigned long qzstd_mock_node_allocs(int node) { return node >= 0 && node < 16 ? gNodeAllocs[node] : gUnplacedAllocs; }
+void qzstd_mock_node_allocs_reset(void) { memset(gNodeAllocs, 0, sizeof gNodeAllocs); gUnplacedAllocs = 0; }
 void *qzstd_hip_host_device_ptr(void *h) { return h; }
 void qzstd_hip_host_free(void *h) { free(h); }
 void *qzstd_hip_stream_create(int device) { (void)device; return malloc(1); }

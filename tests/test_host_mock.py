@@ -353,6 +353,64 @@ def test_announcement_is_split_across_the_gpus(mock, zstd, oracle):
     assert got == want and got1 == want
 
 
+def test_numa_states_pick_a_gpu_of_their_socket_and_buffers_follow_the_gpu(mock, zstd, oracle):
+    """four mock GPUs on two fake NUMA nodes (QZSTD_MOCK_NODES=2: GPU d on node d % 2; reference: qaeMemAllocNUMA per instance,
+    src/qatseqprod.c:216-246).  Threads that run on node 1 (QZSTD_HIP_NUMA_NODE=1 says so; the kernel is asked otherwise) get GPUs 1 and 3
+    only, round-robin; every pinned buffer of a GPU is allocated on that GPU's node; QZSTD_HIP_NUMA=0 gives plain round-robin over all
+    four and unplaced memory; QZSTD_deviceStats reports the node map; frames stay the oracle's"""
+    chunk = 65536
+    data = K.by_name("system", 6 * chunk, seed=5)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_node_allocs.restype = C.c_ulong
+    L.qzstd_mock_node_allocs.argtypes = [C.c_int]
+    L.QZSTD_deviceStats.argtypes = [C.c_int, C.POINTER(C.c_ulong * 4)]
+    want = oracle_frames(zstd, oracle, data, chunk, 1)
+
+    def run_states(n):
+        used = []
+        for _ in range(n):
+            before = [dev_stats(d)[2] + dev_stats(d)[1] for d in range(4)]
+            st = L.QZSTD_createSeqProdState()
+            assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1) == want
+            L.QZSTD_freeSeqProdState(st)
+            after = [dev_stats(d)[2] + dev_stats(d)[1] for d in range(4)]
+            used.append([d for d in range(4) if after[d] != before[d]])
+        return used
+
+    def dev_stats(d):
+        ds = (C.c_ulong * 4)()
+        assert L.QZSTD_deviceStats(d, C.byref(ds)) == 4
+        return list(ds)
+
+    with restarted(mock, QZSTD_MOCK_DEVICES="4", QZSTD_MOCK_NODES="2", QZSTD_HIP_NUMA_NODE="1"):
+        L.qzstd_mock_node_allocs_reset()
+        assert [dev_stats(d)[3] for d in range(4)] == [1, 2, 1, 2]  # node + 1
+        used = run_states(4)
+        assert used == [[1], [3], [1], [3]], used                # GPUs of node 1 only, round-robin
+        assert L.qzstd_mock_node_allocs(1) > 0 and L.qzstd_mock_node_allocs(0) == 0 and L.qzstd_mock_node_allocs(-1) == 0
+    with restarted(mock, QZSTD_MOCK_DEVICES="4", QZSTD_MOCK_NODES="2", QZSTD_HIP_NUMA_NODE="0"):
+        assert run_states(2) == [[0], [2]]
+    with restarted(mock, QZSTD_MOCK_DEVICES="4", QZSTD_MOCK_NODES="2", QZSTD_HIP_NUMA_NODE="1", QZSTD_HIP_NUMA="0"):
+        L.qzstd_mock_node_allocs_reset()
+        assert run_states(4) == [[0], [1], [2], [3]]             # plain round-robin
+        assert L.qzstd_mock_node_allocs(0) == 0 and L.qzstd_mock_node_allocs(1) == 0 and L.qzstd_mock_node_allocs(-1) > 0
+    with restarted(mock, QZSTD_MOCK_DEVICES="4", QZSTD_MOCK_NODES="2", QZSTD_HIP_NUMA_NODE="5"):
+        assert run_states(3) == [[0], [1], [2]]                   # a node without a GPU: round-robin over all of them
+    # an announcement's pinned buffers go next to the state's own GPU; the split still reaches every GPU
+    with restarted(mock, QZSTD_MOCK_DEVICES="4", QZSTD_MOCK_NODES="2", QZSTD_HIP_NUMA_NODE="1"):
+        L.qzstd_mock_node_allocs_reset()
+        big = K.by_name("system", 32 * chunk)
+        bbuf = (C.c_char * len(big)).from_buffer_copy(big)
+        st = L.QZSTD_createSeqProdState()
+        assert L.QZSTD_hintSource(st, bbuf, len(big), chunk, 1) == 0
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(bbuf), len(big), chunk, 1)
+        L.QZSTD_freeSeqProdState(st)
+        assert got == oracle_frames(zstd, oracle, big, chunk, 1)
+        assert L.qzstd_mock_node_allocs(1) >= 4 and L.qzstd_mock_node_allocs(0) == 0
+        assert all(dev_stats(d)[0] == 8 for d in range(4))        # 32 blocks announced, 8 per GPU
+
+
 def test_dense_block_is_redone_alone(mock, zstd, oracle):
     """a block with more sequences than a batch's result pitch (16384) is redone with the caller's full capacity"""
     import random
