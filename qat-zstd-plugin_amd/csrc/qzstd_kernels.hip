@@ -1460,8 +1460,13 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 }
 
 /* one launch, one work item per workgroup (the batch paths) */
+#ifdef QZ_WAVES_PER_EU /* A/B builds: cap the registers so that this many waves fit a SIMD (three workgroups per CU need 7) */
+#define QZ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(QZ_WAVES_PER_EU, QZ_WAVES_PER_EU)))
+#else
+#define QZ_OCCUPANCY
+#endif
 template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
-__global__ __launch_bounds__(kThreads) void qzstd_find_sequences_kernel(LaunchArgs args)
+__global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_kernel(LaunchArgs args)
 {
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,

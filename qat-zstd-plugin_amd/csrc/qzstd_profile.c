@@ -34,10 +34,19 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
      * head table hardly matters there (a collision costs one chain step): 5888 entries -> two blocks per CU */
     {
         const int chains = level >= 5;
-        out->tableSize = chains ? 5888u : (level >= 3 ? 16000u : 6400u);
+#ifndef QZ_CHAIN_TABLE
+#define QZ_CHAIN_TABLE 5888u /* head-table entries of the chain levels (A/B builds: make variant XFLAGS=-DQZ_CHAIN_TABLE=n) */
+#endif
+        out->tableSize = chains ? QZ_CHAIN_TABLE : (level >= 3 ? 16000u : 6400u);
         out->longSize = (!chains && level >= 3) ? 8192u : 0u;
         out->tileLog = 9;
-        out->capLen = level >= 9 ? 128u : (level >= 5 ? 64u : 48u); /* levels 1-4: one 32-byte step after the 16-byte head; capped matches are extended when taken */
+#ifndef QZ_CAP_HI
+#define QZ_CAP_HI 128u /* candidate cap of levels 9-12 (A/B builds) */
+#endif
+#ifndef QZ_DEPTH_HI
+#define QZ_DEPTH_HI 64u /* links walked at levels 9-12 (A/B builds) */
+#endif
+        out->capLen = level >= 9 ? QZ_CAP_HI : (level >= 5 ? 64u : 48u); /* levels 1-4: one 32-byte step after the 16-byte head; capped matches are extended when taken */
         out->minMatch = 4;
         out->farLog1 = 12;
         out->farLog2 = 16;
@@ -52,7 +61,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
         out->repWin = (repcodes || level >= 10) ? 16u : 0u;
         /* levels >= 5: links walked per position (software zstd: 2^searchLog = 4..128 attempts plus repcodes; the
          * producer API gives no repcodes below level 10, which deeper chains make up for) */
-        out->chainDepth = level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u)));
+        out->chainDepth = level >= 9 ? QZ_DEPTH_HI : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u)));
         /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
          * level 2, which buys its better ratio with them */
         out->subTileLog = (chains || level == 2) ? 6u : 0u;
