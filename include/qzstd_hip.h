@@ -143,6 +143,9 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
                              uint32_t maxBlockLen, void *d_seqs, uint32_t *d_nseq,
                              void *d_work, size_t workBytes);
 
+/* diagnostics: workgroups of the level's launch kernel that fit one CU according to the runtime (registers, LDS, wave slots) */
+int qzstd_hip_occupancy(int device, int level);
+
 /*
  * The resident service: one block per request WITHOUT a launch (reference: the synchronous submit + poll of one
  * request on a DC instance, src/qatseqprod.c:1243-1272; many instances per device :905-928).  A request names the caller's

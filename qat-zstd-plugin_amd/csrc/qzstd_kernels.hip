@@ -141,6 +141,9 @@ typedef const __attribute__((address_space(1))) uint32_t *HbmWords;
 struct Src {
     LdsWords ring; /* LDS, kRing + kMirror bytes */
     HbmWords g;    /* the block in HBM; 16-byte aligned, so aligned dword loads work */
+    uint32_t nearLimit; /* sources farther back than this are compared from device memory: kNear, or 0xFFFFFFFF in the NEAR kernels (every
+                         * block of the launch fits the ring: "offset > nearLimit" folds to false and the device-memory side of every
+                         * compare is compiled out) */
 };
 
 /* dword index inside the ring of byte position a (a < 3 * kRing) */
@@ -285,7 +288,7 @@ __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint3
 __device__ __forceinline__ uint32_t extend_match(const Src &s, uint32_t p, uint32_t off, uint32_t L, uint32_t lim,
                                                  uint32_t lane)
 {
-    const bool far = off > kNear; /* uniform: the whole match has one offset */
+    const bool far = off > s.nearLimit; /* uniform: the whole match has one offset */
     for (;;) {
         const uint32_t a = p + L + 16u * lane;
         uint32_t ok = 0; /* bytes of this lane's 16 that match and lie below lim */
@@ -489,7 +492,7 @@ __device__ __forceinline__ u64 rep_bitmap(const Src &src, uint32_t cur, uint32_t
 {
     const uint32_t bpos = cur + lane;
     bool eq = false;
-    if (rp != 0u && bpos < n) eq = ring_byte(src, bpos, false) == ring_byte(src, bpos - rp, rp > kNear);
+    if (rp != 0u && bpos < n) eq = ring_byte(src, bpos, false) == ring_byte(src, bpos - rp, rp > src.nearLimit);
     return __ballot(eq);
 }
 
@@ -529,7 +532,7 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
         uint32_t wd = 0;
         if (lane < V) wd = pvT[st.cur + lane - base]; /* the candidate of the window position: gain | offset << 10 */
         u64 M1, M2;
-        if (st.rep1 <= kNear && st.rep2 <= kNear) { /* the usual case: both sources inside the ring */
+        if (st.rep1 <= src.nearLimit && st.rep2 <= src.nearLimit) { /* the usual case: both sources inside the ring */
             /* 64 bytes from each of the three ring offsets: what runs over the ring's end is in the mirror (kMirror >= 64) */
             const uint32_t t1 = rc - st.rep1, t2 = rc - st.rep2; /* offsets never reach before the block */
             const uint32_t r1 = t1 & kRingMask, r2 = t2 & kRingMask;
@@ -641,7 +644,7 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
         if (maxb) {
             /* the 4 bytes before p and before q, top byte = nearest; count equal bytes from the top.  Through the ring the
              * reads simply wrap below position 0: what they find there is never counted (maxb <= q) */
-            const bool far = off > kNear;
+            const bool far = off > src.nearLimit;
             const uint32_t rp4 = ring_back(rpE, 4u);
             const uint32_t pb = rd32_r(src, p - 4u, rp4, false);
             uint32_t qb;
@@ -780,7 +783,7 @@ struct HistShare {
  * count including the delimiter or QZSTD_HIP_NSEQ_ERROR (every thread returns that for an item that is refused); the matcher
  * waves return 0.  Both kernels below are thin shells around it: one launch = one item per workgroup
  * (qzstd_find_sequences_kernel), or a resident worker that takes items from a queue (qzstd_service_worker). */
-template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
+template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS, bool NEAR>
 __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_hip_block_t &blk, const uint8_t *gsrc, uint4 *out,
                                             uint4 *chainB, uint32_t *p1B, const HistShare hsh)
 {
@@ -800,6 +803,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     if (blk.parseFrom != 0u && (pf.segLog == 0u || (blk.parseFrom & ((1u << pf.segLog) - 1u)) != 0u || blk.parseFrom >= n)) {
         return QZSTD_HIP_NSEQ_ERROR; /* not a segment boundary of this level: refused (uniform: before the first barrier) */
     }
+    if (NEAR && n > kRing) return QZSTD_HIP_NSEQ_ERROR; /* a descriptor longer than the launch's maxBlockLen: refused, never compared from a ring that lost its bytes */
 
     /* ---- LDS layout (qzstd_hip_lds_bytes(): 65 392 B at levels 1-2 and 5-12 = two workgroups per CU; 136 560 B at levels 3-4) ---- */
     /* The workgroup's LDS is addressed from an integer constant, not from the `smem` symbol: the dynamic allocation starts at
@@ -824,6 +828,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     Src src;
     src.ring = (LdsWords)ring32;
     src.g = (HbmWords)reinterpret_cast<const uint32_t *>(gsrc);
+    src.nearLimit = NEAR ? 0xFFFFFFFFu : kNear;
     const uint32_t nPad = (n + 15u) & ~15u; /* the caller keeps the buffer readable up to here */
 
     /* ---- clear the tables; segment mode below the chain levels: fast-forward over the tiles before the segment ---- */
@@ -1123,8 +1128,12 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #ifdef QZ_DEBUG_DUMP
     u64 dI1 = 0, dW1 = 0, dI2 = 0, dW2 = 0, tP = __builtin_amdgcn_s_memtime();
 #define QZ_LAP(acc) { const u64 tN = __builtin_amdgcn_s_memtime(); acc += tN - tP; tP = tN; }
+    /* chain walk, by phase: 0 entry build, 1 next-entry fetch issued, 2 four-byte tests, 3 heads + extensions, 4 wait for the next entry, 5 steps */
+    u64 dC[6] = { 0, 0, 0, 0, 0, 0 }, tC = 0;
+#define QZ_CLAP(k) { const u64 tN = __builtin_amdgcn_s_memtime(); dC[k] += tN - tC; tC = tN; }
 #else
 #define QZ_LAP(acc)
+#define QZ_CLAP(k)
 #endif
 
     for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
@@ -1188,6 +1197,27 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         QZ_LAP(dW1)
 
         /* ================= interval 2 ================= */
+#if defined(QZ_PAD_VALU) || defined(QZ_PAD_SALU) || defined(QZ_PAD_LDS)
+        /* calibration builds only (make variant XFLAGS=-DQZ_PAD_VALU=64 ...): what ONE more instruction of a kind costs per matcher wave
+         * and tile — the slope says which issue resource binds the kernel */
+        {
+            uint32_t padv = lane, pads = 1u;
+#ifdef QZ_PAD_VALU
+#pragma unroll
+            for (int i = 0; i < QZ_PAD_VALU; i++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(padv) : "v"(lane));
+#endif
+#ifdef QZ_PAD_SALU
+#pragma unroll
+            for (int i = 0; i < QZ_PAD_SALU; i++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pads) : : "scc");
+#endif
+#ifdef QZ_PAD_LDS
+#pragma unroll
+            for (int i = 0; i < QZ_PAD_LDS; i++) { uint32_t t; asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"((rp & ~3u) + 16u)); padv ^= t; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            if (padv == 0xDEADBEEFu && pads == 0u) pv[0] = padv; /* keeps the chain alive; never true in practice */
+        }
+#endif
         if (refill) {
             const uint32_t o = ring_dw(fpos) << 2;
             ring128[o >> 4] = fresh;
@@ -1208,6 +1238,9 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
              *    device memory (args.chain, 16 B per position); later tiles find them there. */
             const uint32_t *P1T = (it & 1u) ? P1odd : nearTab; /* [kTile] this tile's predecessors */
             const uint32_t tag = (mix >> 3) & kTagMask;
+#ifdef QZ_DEBUG_DUMP
+            tC = __builtin_amdgcn_s_memtime();
+#endif
             /* the entry of the own position */
             uint32_t E[4] = { 0u, 0u, 0u, 0u };
             if (valid) {
@@ -1231,6 +1264,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             uint32_t walked = 0;
             if (history) E[0] = 0u; /* a tile before the segment (segment mode): inserted and linked, not matched */
             int bg = 0;
+            QZ_CLAP(0)
             while (__ballot(E[0] != 0u)) {
                 uint32_t N[4] = { 0u, 0u, 0u, 0u };
                 if (E[0] != 0u) {
@@ -1262,6 +1296,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #define QZ_LINKS_PER_STEP 4 /* measured: 2 -> 4 another -1 to -2.6 % at levels 5-12 (76 VGPRs: still two workgroups per CU) */
 #endif
                     constexpr int kG = QZ_LINKS_PER_STEP;
+                    QZ_CLAP(1)
 #pragma unroll
                     for (int kk = 0; kk < 4; kk += kG) {
                         uint32_t q[kG], rq[kG];
@@ -1270,7 +1305,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         for (int g = 0; g < kG; g++) {
                             const uint32_t l = E[kk + g];
                             q[g] = (l >> kTagBits) - 1u;
-                            far[g] = p - q[g] > kNear;
+                            far[g] = p - q[g] > src.nearLimit;
                             m[g] = l != 0u && walked + (uint32_t)(kk + g) < pf.chainDepth && (l & kTagMask) == tag && (pf.window == 0u || p - q[g] <= pf.window) &&
                                    !QZ_ABLATED(2u) && !(QZ_ABLATED(64u) && far[g]); /* profiling: 64 = what the HBM-side candidates cost */
                             rq[g] = ring_back(rp, p - q[g]);
@@ -1294,6 +1329,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #pragma unroll
                             for (int g = 0; g < kG; g++) m[g] = m[g] && v[g] == pw;
                         }
+                        QZ_CLAP(2)
                         uint32_t Q[kG][5];
 #pragma unroll
                         for (int g = 0; g < kG; g++) {
@@ -1320,8 +1356,14 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     }
                     walked += cnt;
                 }
+                QZ_CLAP(3)
+#ifdef QZ_DEBUG_DUMP
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* (the next step starts with these values anyway) */
+                dC[5] += 1;
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) E[k] = N[k];
+                QZ_CLAP(4)
             }
         } else {
         if (TURNS) {
@@ -1358,14 +1400,14 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 if (pf.window == 0u || p - q <= pf.window) q1 = q;
             }
             if (QZ_ABLATED(2u)) q1 = kNone;
-            if (QZ_ABLATED(64u) && q1 != kNone && p - q1 > kNear) q1 = kNone; /* profiling: what the HBM-side candidates cost */
+            if (QZ_ABLATED(64u) && q1 != kNone && p - q1 > src.nearLimit) q1 = kNone; /* profiling: what the HBM-side candidates cost */
             uint32_t l1 = 0, l2 = 0, l3 = 0;
-            const bool far1 = q1 != kNone && p - q1 > kNear;
+            const bool far1 = q1 != kNone && p - q1 > src.nearLimit;
             if (q1 != kNone) l1 = head_len(src, oa, q1, ring_back(rp, p - q1), far1);
             /* candidate 3 (levels >= 3): newest earlier-tile position whose first 8 bytes hash alike */
             uint32_t q3 = kNone;
             if (HAS_LONG && validL && oldL != 0u && (oldL & kTagMask) == tagL && !QZ_ABLATED(2u)) q3 = (oldL >> kTagBits) - 1u;
-            const bool far3 = q3 != kNone && p - q3 > kNear;
+            const bool far3 = q3 != kNone && p - q3 > src.nearLimit;
             if (q3 != kNone) l3 = head_len(src, oa, q3, ring_back(rp, p - q3), far3);
             if (pf.nearTab && (en >> stampShift) == (stamp >> stampShift) && (en & kTagMask) == tag) {
                 const uint32_t q = t0 + ((en >> kTagBits) & (kTile - 1u));
@@ -1454,22 +1496,28 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     }
 #ifdef QZ_DEBUG_DUMP
     if (lane == 0) out[blk.seqCap - 3u - wave] = make_uint4((uint32_t)dI1, (uint32_t)dW1, (uint32_t)dI2, (uint32_t)dW2);
+    if (lane == 0) out[blk.seqCap - 24u - 2u * wave] = make_uint4((uint32_t)(dC[0] >> 4), (uint32_t)(dC[1] >> 4), (uint32_t)(dC[2] >> 4), (uint32_t)(dC[3] >> 4));
+    if (lane == 0) out[blk.seqCap - 25u - 2u * wave] = make_uint4((uint32_t)(dC[4] >> 4), (uint32_t)dC[5], 0u, 0u);
     if (lane == 0) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID */
 #endif
     return 0u;
 }
 
 /* one launch, one work item per workgroup (the batch paths) */
-#ifdef QZ_WAVES_PER_EU /* A/B builds: cap the registers so that this many waves fit a SIMD (three workgroups per CU need 7) */
-#define QZ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(QZ_WAVES_PER_EU, QZ_WAVES_PER_EU)))
-#else
-#define QZ_OCCUPANCY
+/* Two workgroups of nine waves per CU put five waves on two of the four SIMDs: the kernel must fit five waves' registers into a
+ * SIMD's 512.  (A/B builds: QZ_WAVES_PER_EU=7 caps them for three workgroups per CU — measured in round 4 with a smaller head table:
+ * the runtime reports three resident, 768 blocks take 1.56 x the time of 512: the third workgroup buys nothing.) */
+#ifndef QZ_WAVES_PER_EU
+#define QZ_WAVES_PER_EU 5
 #endif
-template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
+#define QZ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(QZ_WAVES_PER_EU)))
+/* NEAR: every block of the launch fits the ring (maxBlockLen <= kRing: BASELINE config 4's 32 KiB blocks) — nothing the ring held is
+ * ever overwritten, every source is compared from LDS, and the device-memory side of every compare is compiled out */
+template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS, bool NEAR>
 __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_kernel(LaunchArgs args)
 {
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
-    const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
+    const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS, NEAR>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
                                                                 CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr,
                                                                 CHAIN ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
                                                                 HistShare{ nullptr, 0u, 0u, 0u });
@@ -1623,7 +1671,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
         }
         uint32_t count = QZSTD_HIP_NSEQ_ERROR;
         /* the request's scratch: entries of the history [BLOCK_MAX], entries of the items' own positions [BLOCK_MAX], first links [BLOCK_MAX] */
-        if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, CHAIN, TURNS>(args, blk, dSrc, out, CHAIN ? (uint4 *)q7 : nullptr,
+        if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, CHAIN, TURNS, false>(args, blk, dSrc, out, CHAIN ? (uint4 *)q7 : nullptr,
                                                                                CHAIN ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 32ull) : nullptr,
                                                                                HistShare{ CHAIN ? &sv->histFlag[slotIdx][0] : nullptr, k, epoch, spinLimit });
         else if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->spinFails, 1u, QZ_RLX_AGENT);
@@ -2184,16 +2232,16 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         big = big || sv.wide;
         if (sv.hs && __atomic_load_n(&sv.hs->state, __ATOMIC_ACQUIRE) != 0u && lds + sv.lds > kLdsPerCu) (void)svc_stop_locked(sv, 2000);
     }
-    /* [long][rep][chain/turns: 0 none, 1 turns, 2 chain + turns] */
-    static const void *const variants[2][2][3] = {
-        { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, false>),
-            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, true>),
-            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, true, true>) },
-          { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, false>),
-            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, true>),
-            reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, true, true>) } },
-        { { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, false, false>), nullptr, nullptr },
-          { reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, false, false>), nullptr, nullptr } } };
+    /* [near][long][rep][chain/turns: 0 none, 1 turns, 2 chain + turns] */
+#define QZ_K(L, R, C, T, N) reinterpret_cast<const void *>(qzstd_find_sequences_kernel<L, R, C, T, N>)
+    static const void *const variants[2][2][2][3] = {
+        { { { QZ_K(false, false, false, false, false), QZ_K(false, false, false, true, false), QZ_K(false, false, true, true, false) },
+            { QZ_K(false, true, false, false, false), QZ_K(false, true, false, true, false), QZ_K(false, true, true, true, false) } },
+          { { QZ_K(true, false, false, false, false), nullptr, nullptr }, { QZ_K(true, true, false, false, false), nullptr, nullptr } } },
+        { { { QZ_K(false, false, false, false, true), QZ_K(false, false, false, true, true), QZ_K(false, false, true, true, true) },
+            { QZ_K(false, true, false, false, true), QZ_K(false, true, false, true, true), QZ_K(false, true, true, true, true) } },
+          { { QZ_K(true, false, false, false, true), nullptr, nullptr }, { QZ_K(true, true, false, false, true), nullptr, nullptr } } } };
+#undef QZ_K
     /* the LDS a variant may ask for is a per-function, per-device attribute (process-wide, not per thread): raise it
      * once per device to the most any level needs and never lower it */
     {
@@ -2207,8 +2255,8 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
                 const size_t b = qzstd_hip_lds_bytes(l, QZSTD_HIP_BLOCK_MAX);
                 if (b > most) most = b;
             }
-            for (int v = 0; v < 12; v++) {
-                const void *f = variants[v / 6][(v / 3) % 2][v % 3];
+            for (int v = 0; v < 24; v++) {
+                const void *f = variants[v / 12][(v / 6) % 2][(v / 3) % 2][v % 3];
                 if (f) QZ_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most),
                                 "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
             }
@@ -2241,7 +2289,9 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     const size_t ldsLaunch = lds;
 #endif
     const dim3 grid(nBlocks), wg(kThreads);
-    const void *kernel = variants[a.prof.longSize ? 1 : 0][a.prof.repWin ? 1 : 0][a.prof.chainDepth ? 2 : (a.prof.subTileLog ? 1 : 0)];
+    /* every block of the launch fits the ring: the kernels without a device-memory side of the compares (NEAR) */
+    const int nearK = maxBlockLen <= kRing ? 1 : 0;
+    const void *kernel = variants[nearK][a.prof.longSize ? 1 : 0][a.prof.repWin ? 1 : 0][a.prof.chainDepth ? 2 : (a.prof.subTileLog ? 1 : 0)];
     void *kargs[1] = { &a };
     if (!kernel) return fail_msg("qzstd_hip_find_sequences: unsupported profile (no kernel variant)");
     QZ_CHECK(hipLaunchKernel(kernel, grid, wg, kargs, ldsLaunch, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
@@ -2260,6 +2310,24 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         else (void)hipGetLastError();
     }
     return 0;
+}
+
+/* diagnostics: how many workgroups of the level's kernel the runtime says fit one CU (registers, LDS, wave slots); < 0 on error */
+int qzstd_hip_occupancy(int device, int level)
+{
+    qzstd_hip_profile_t p;
+    if (qzstd_hip_profile_for_level(level, QZSTD_HIP_BLOCK_MAX, &p)) return fail_msg("qzstd_hip_occupancy: bad level");
+    const size_t lds = qzstd_hip_lds_bytes(level, QZSTD_HIP_BLOCK_MAX);
+    QZ_SET_DEVICE(device);
+    const void *k;
+    if (p.chainDepth) k = p.repWin ? reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, true, true, false>) : reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, true, true, false>);
+    else if (p.longSize) k = p.repWin ? reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, true, false, false, false>) : reinterpret_cast<const void *>(qzstd_find_sequences_kernel<true, false, false, false, false>);
+    else if (p.subTileLog) k = p.repWin ? reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, true, false>) : reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, true, false>);
+    else k = p.repWin ? reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, true, false, false, false>) : reinterpret_cast<const void *>(qzstd_find_sequences_kernel<false, false, false, false, false>);
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int n = 0;
+    QZ_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, kThreads, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+    return n;
 }
 
 } /* extern "C" */

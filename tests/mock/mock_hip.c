@@ -66,6 +66,7 @@ void *qzstd_hip_host_alloc_on_node(size_t bytes, int node, int coherent)
     return malloc(bytes ? bytes : 1);
 }
 int qzstd_hip_host_node_of(const void *h) { (void)h; return -1; }
+int qzstd_hip_occupancy(int device, int level) { (void)device; (void)level; return 1; }
 unsigned long qzstd_mock_node_allocs(int node) { return node >= 0 && node < 16 ? gNodeAllocs[node] : gUnplacedAllocs; }
 void qzstd_mock_node_allocs_reset(void) { memset(gNodeAllocs, 0, sizeof gNodeAllocs); gUnplacedAllocs = 0; }
 void *qzstd_hip_host_device_ptr(void *h) { return h; }

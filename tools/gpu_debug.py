@@ -57,6 +57,14 @@ def timing():
             print("   ", pat, cnt)
         cu = ((hw[:, 0] >> 8) & 15) | (((hw[:, 0] >> 13) & 7) << 4) | (((hw[:, 0] >> 12) & 1) << 7)
         print("parse-wave SIMD histogram:", np.bincount(simd[:, 8], minlength=4).tolist())
+    if int(os.environ.get("QZ_LEVEL", "1"), 0) & 0xFF >= 5:
+        ntile = 256.0
+        for wv in range(8):
+            c0 = np.array([a[(i + 1) * stride - 24 - 2 * wv] for i in range(len(blocks))], dtype=np.float64) * 16
+            c1 = np.array([a[(i + 1) * stride - 25 - 2 * wv] for i in range(len(blocks))], dtype=np.float64)
+            m0, m1 = c0.mean(axis=0) / ntile, c1.mean(axis=0)
+            print("matcher wave %d chain walk per tile: entry build %.0f | per tile over %.1f steps: fetch issue %.0f, tests %.0f, heads+extensions %.0f, wait for next entry %.0f"
+                  % (wv, m0[0], m1[1] / ntile, m0[1], m0[2], m0[3], m1[0] * 16 / ntile))
     for wv in range(8):
         rw = np.array([a[(i + 1) * stride - 3 - wv] for i in range(len(blocks))], dtype=np.float64)
         print("matcher wave %d per tile: I1 %.0f waitB1 %.0f I2 %.0f waitB2 %.0f" % ((wv,) + tuple(rw.mean(axis=0) / 256)))

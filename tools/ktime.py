@@ -68,8 +68,9 @@ def main():
         ok = c[c != 0xFFFFFFFF]
         # a position-weighted checksum of the counts: two builds that should produce the same sequences print the same number
         chk = int((ok.astype("uint64") * (1 + (ok.size and (__import__("numpy").arange(ok.size, dtype="uint64") % 251)))).sum()) if ok.size else 0
-        print("level %#x block %d x %d %s: %.3f ms (min %.3f) = %.1f ms/GiB = %.2f GB/s in; %.1f seq/block, %d error blocks, counts checksum %d"
-              % (lv, blk, nb, name, med, ms[0], med * (1 << 30) / (blk * nb), blk * nb / med / 1e6, float(ok.mean()) if ok.size else 0.0,
+        occ = L.qzstd_hip_occupancy(0, lv) if hasattr(L, "qzstd_hip_occupancy") else -1
+        print("[%d WG/CU] level %#x block %d x %d %s: %.3f ms (min %.3f) = %.1f ms/GiB = %.2f GB/s in; %.1f seq/block, %d error blocks, counts checksum %d"
+              % (occ, lv, blk, nb, name, med, ms[0], med * (1 << 30) / (blk * nb), blk * nb / med / 1e6, float(ok.mean()) if ok.size else 0.0,
                  int((c == 0xFFFFFFFF).sum()), chk), flush=True)
         del d_src, d_seqs, d_cnt, d_desc, d_work
         torch.cuda.empty_cache()
