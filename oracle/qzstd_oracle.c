@@ -84,7 +84,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->repWin = (repcodes || level >= 10) ? 16u : 0u;
     /* levels >= 5: links walked per position (software zstd: 2^searchLog = 4..128 attempts plus repcodes; the
      * producer API gives no repcodes below level 10, which deeper chains make up for) */
-    out->chainDepth = level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u)));
+    out->chainDepth = level >= 10 ? 48u : (level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u))));
     /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
      * level 2, which buys its better ratio with them */
     out->subTileLog = (chains || level == 2) ? 6u : 0u;

@@ -44,7 +44,9 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
 #define QZ_CAP_HI 128u /* candidate cap of levels 9-12 (A/B builds) */
 #endif
 #ifndef QZ_DEPTH_HI
-#define QZ_DEPTH_HI 64u /* links walked at levels 9-12 (A/B builds) */
+#define QZ_DEPTH_HI 48u /* links walked at levels 10-12 (round 4: 64 -> 48; the repeat-aware parse of these levels leaves room in the 2 % bound:
+                         * compressed size +0.1 % over eleven corpora (web-log 32 KiB blocks 0.996 -> 0.994 of software), kernel time -14 % (config 4's
+                         * shape) to -18 % (128 KiB blocks): the walk's cost is linear in the links) */
 #endif
         out->capLen = level >= 9 ? QZ_CAP_HI : (level >= 5 ? 64u : 48u); /* levels 1-4: one 32-byte step after the 16-byte head; capped matches are extended when taken */
         out->minMatch = 4;
@@ -61,7 +63,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
         out->repWin = (repcodes || level >= 10) ? 16u : 0u;
         /* levels >= 5: links walked per position (software zstd: 2^searchLog = 4..128 attempts plus repcodes; the
          * producer API gives no repcodes below level 10, which deeper chains make up for) */
-        out->chainDepth = level >= 9 ? QZ_DEPTH_HI : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u)));
+        out->chainDepth = level >= 10 ? QZ_DEPTH_HI : (level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u))));
         /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
          * level 2, which buys its better ratio with them */
         out->subTileLog = (chains || level == 2) ? 6u : 0u;
