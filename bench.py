@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--e2e-seconds", type=float, default=5.5, help="continuous load per first-class end-to-end side leg")
     ap.add_argument("--e2e-blocks", type=int, default=4096, help="chunks per GPU per step of the timed ZSTD_compress2 leg (4096 x 128 KiB = 512 MiB)")
     ap.add_argument("--e2e-threads", type=int, default=0, help="front-end worker threads per rank (0 = usable host cores / ranks)")
+    ap.add_argument("--kernel-only", action="store_true", help="only the roofline leg (K timed launches of the dominant kernel, resident input): what "
+                    "tools/prof_stats.sh / prof_pmc.sh run under rocprofv3, so that the profile holds these launches and no others")
     ap.add_argument("--product-multi-gpu", type=int, default=0, help=argparse.SUPPRESS)  # internal: only that leg, in a process that sees every GPU
     return ap.parse_args()
 
@@ -576,6 +578,18 @@ def main():
     n_err = int((cnt == 0xFFFFFFFF).sum())
     seq_total = int(cnt[cnt != 0xFFFFFFFF].sum())
 
+    if a.kernel_only:
+        if rank == 0:
+            alg_bytes = size + 16 * seq_total
+            print(json.dumps({"kernel_only": True, "level": level, "block_bytes": block, "blocks": nb, "launches_timed": a.steps,
+                              "kernel_ms_avg": round(kern_avg_ms, 3), "kernel_input_MBps": round(size / (kern_avg_ms * 1e-3) / 1e6, 1),
+                              "algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": round(alg_bytes / (kern_avg_ms * 1e-3) / 1e9, 1),
+                              "frac_of_hbm_peak": round(alg_bytes / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                              "sequences_per_block": round(seq_total / max(nb - n_err, 1), 1), "error_blocks": n_err}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # ---- THE METRIC: input MB/s through ZSTD_compress2, plugin registered (module docstring); exactly a.steps timed passes
     ncpu, quota = host_cpu_budget()
     e2e_threads = a.e2e_threads if a.e2e_threads > 0 else max(1, min(int(quota) // world, 128))

@@ -6,5 +6,5 @@ timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -
 for LV in ${@:-1 3}; do
   B=8192; case $LV in 3|4) B=4096;; 5|6|7|8|9|10|11|12|0x101) B=2048;; esac
   echo -n "level $LV ($B blocks): "
-  timeout 300 python bench.py --no-cpu --steps 6 --warmup 2 --level $LV --blocks $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms', d.get('error_blocks'))"
+  timeout 300 python bench.py --kernel-only --steps 6 --warmup 2 --level $LV --blocks $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['kernel_ms_avg'], 'ms', d.get('error_blocks'))"
 done

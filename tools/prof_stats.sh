@@ -7,5 +7,5 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/stats_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python $R/bench.py --steps 10 --warmup 2 --no-cpu "$@" > $OUT/run.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python $R/bench.py --steps 10 --warmup 2 --kernel-only "$@" > $OUT/run.log 2>&1
 find $OUT -name '*kernel_stats.csv' -exec cat {} \;
