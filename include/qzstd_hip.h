@@ -183,7 +183,8 @@ typedef struct {
                          * links the block before it, and leaves the chain entries of one item's range to the items after it);
                          * NULL at the other levels */
 } qzstd_hip_svc_req_t;
-#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 36u)
+#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 36u + (size_t)QZSTD_HIP_SVC_MAX_ITEMS * 5888u * 4u) /* chain entries of the history and of the
+                                       * items' own positions, first links, and one published head table per item */
 int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *req);
 int qzstd_hip_service_stop(int device);          /* asks the resident kernels to leave and waits for them; 0 = stopped */
 /* called by a caller that waits for its request: if the service has left meanwhile (idle exit, a free, a launch that needed the LDS)

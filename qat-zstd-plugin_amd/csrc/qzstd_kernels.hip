@@ -772,11 +772,17 @@ __device__ __forceinline__ void chain_insert_tile(const qzstd_hip_profile_t &pf,
  * inserting.  flags == nullptr: a scratch of its own, all entries built here (the launch paths: workgroups of a launch do not start
  * in order). */
 struct HistShare {
-    uint32_t *flags;    /* [kSvcMaxItems] of the request's slot */
-    uint32_t item;      /* this item's index in the request (>= 1 where it matters) */
+    uint32_t *flags;    /* [kSvcMaxItems] of the request's slot: item j has published the chain entries of ITS range */
+    uint32_t item;      /* this item's index in the request */
     uint32_t epoch;     /* of the request */
-    uint32_t spinLimit; /* bound of the wait for the items before this one */
+    uint32_t spinLimit; /* bound of the waits for the items before this one */
+    /* round 4: the items of a request also share their HEAD TABLES (qz_item: "the shared history") */
+    uint32_t nItems;    /* items of the request */
+    uint32_t *tabFlags; /* [kSvcMaxItems]: item j has published the head table of its range */
+    uint32_t *linkFlags;/* [kSvcMaxItems]: item j has published the first links of its range */
+    uint32_t *tabs;     /* [kSvcMaxItems][kSvcTabStride] in the request's scratch */
 };
+constexpr uint32_t kSvcTabStride = 5888u; /* words per published head table (the chain levels' tableSize; QZSTD_HIP_SVC_WORK_BYTES counts 32 of them) */
 
 /* One work item (a block, or a run of whole segments of one): `blk` describes it, gsrc = the block's bytes in device memory,
  * out = the item's result region, chainB = its chain entries (CHAIN), p1B = its array of first links (CHAIN, segment items).  Returns, in the parse wave, the item's sequence
@@ -859,8 +865,162 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
         for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
     }
-    if (itBegin != 0u) __syncthreads(); /* the cleared tables, before the first insert */
-    if (CHAIN && itBegin != 0u) {
+    const bool sharedHist = CHAIN && hsh.flags != nullptr && hsh.nItems > 1u && pf.tableSize <= kSvcTabStride;
+    if (itBegin != 0u || sharedHist) __syncthreads(); /* the cleared tables, before the first insert */
+    if (sharedHist) {
+        /* Chain levels, the items of ONE request of the resident service: THE SHARED HISTORY (round 4).  Until now every item
+         * inserted and linked the whole block before its own range by itself — 131 us of ordered LDS inserts in front of a 128 KiB
+         * block's last item, the largest part of what an unchanged caller waits for at the chain levels.  But the head table is a
+         * MAXIMUM per slot (the newest position): the table after [0, a) is the element-wise maximum of the tables of the ranges
+         * before a.  So every item k handles ITS OWN range R_k = [parseFrom, n) only, all items at the same time:
+         *   1  hash + ordered insert of R_k into the (empty) table: T_k, and the first links of R_k as far as they stay inside R_k;
+         *   2  publish T_k (written through) and say so; wait for T_j of the items before it (they do the same at the same time:
+         *      nobody waits for a later item, the service hands the items of a request out in order);
+         *   3  table := max over j < k of T_j — the state the tile loop starts from — and the first links of R_k that found no
+         *      predecessor inside R_k become that table's entries; publish them;
+         *   4  complete the four-link entries of R_k by chasing first links (its own and the earlier ranges'); publish; wait for
+         *      the entries of the ranges before it; one agent-scope acquire; the tile loop starts at the item's first tile.
+         * The work in front of an item no longer grows with its position in the block: 4 KiB of inserts + k table reads instead of
+         * up to 124 KiB of inserts.  Bit-exact with the tile loop's own result (tests/test_gpu_service.py, tests/stress). */
+        constexpr uint32_t kGroup = 4096u;
+        uint32_t *hist = ring32;          /* [kGroup] slot | tag */
+        uint32_t *link = ring32 + kGroup; /* [kGroup] first links inside the range */
+        const uint32_t a0 = blk.parseFrom, b0 = n, k = hsh.item;
+        auto wait_for = [&](uint32_t *fl) -> bool { /* items 0 .. k - 1 have raised fl[j]; called by every thread, decided by wave 0 */
+            if (wave == 0u) {
+                uint32_t spins = 0u, ok = 1u;
+                for (;;) {
+                    const bool there = lane >= k || __hip_atomic_load(&fl[lane], QZ_RLX_AGENT) == hsh.epoch;
+                    if (__all(there)) break;
+                    if (++spins > hsh.spinLimit) { ok = 0u; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane == 0u) turnCtr[2] = ok;
+            }
+            __syncthreads();
+            const bool ok = rdfirst(turnCtr[2]) != 0u;
+            __syncthreads();
+            return ok;
+        };
+        auto hash_group = [&](uint32_t g0) { /* slot | tag of the group's positions -> hist[] (kNone: takes no part) */
+            if (tid < 256u) {
+                const uint32_t c = g0 + tid * 16u;
+                uint4 ha = make_uint4(0u, 0u, 0u, 0u), hb = ha;
+                if (c < b0) { ha = g128[c >> 4]; hb = g128[(c >> 4) + 1u]; } /* (the staging buffer is readable 64 bytes past the block) */
+                const uint32_t W[5] = { ha.x, ha.y, ha.z, ha.w, hb.x };
+                const uint32_t segEc = seg_end(pf, c, n);
+                uint32_t st16[16];
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; j++) {
+                    const uint32_t v = (j & 3u) ? __builtin_amdgcn_alignbyte(W[(j >> 2) + 1u], W[j >> 2], j & 3u) : W[j >> 2];
+                    const uint32_t mixH = v * kPrime1;
+                    const bool okp = c + j < nh && c + j + 4u <= segEc;
+                    st16[j] = okp ? (__umulhi(mixH, pf.tableSize) | (((mixH >> 3) & kTagMask) << 16)) : kNone;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++)
+                    reinterpret_cast<uint4 *>(hist)[tid * 4u + j] = make_uint4(st16[4u * j], st16[4u * j + 1u], st16[4u * j + 2u], st16[4u * j + 3u]);
+            }
+        };
+        /* 1: the range's own table and the links that stay inside the range */
+        for (uint32_t g0 = a0; g0 < b0; g0 += kGroup) {
+            hash_group(g0);
+            QZ_BARRIER_LDS();
+            if (wave == 2u || wave == 3u) {
+                const uint32_t nW = (umin(kGroup, b0 - g0) + 63u) >> 6;
+                const uint32_t par = wave & 1u;
+                for (uint32_t w0 = 0; w0 < nW; w0 += 16u) {
+                    uint32_t st[16], pred[16];
+#pragma unroll
+                    for (uint32_t j = 0; j < 16u; j++) st[j] = w0 + j < nW ? hist[64u * (w0 + j) + lane] : kNone;
+#pragma unroll
+                    for (uint32_t j = 0; j < 16u; j++) {
+                        const uint32_t pos = g0 + 64u * (w0 + j) + lane;
+                        const bool mine = st[j] != kNone && (st[j] & 1u) == par;
+                        pred[j] = 0u;
+                        if (mine) pred[j] = args.orderedLds != 0u ? atomicMax(&tbl[st[j] & 0xFFFFu], ((pos + 1u) << kTagBits) | (st[j] >> 16))
+                                                                   : chain_insert_window(tbl, st[j], ((pos + 1u) << kTagBits) | (st[j] >> 16), lane, false);
+                        else if (args.orderedLds == 0u) (void)chain_insert_window(tbl, kNone, 0u, lane, false); /* (the ballots of the portable path need every lane) */
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 16u; j++)
+                        if (w0 + j < nW && (st[j] == kNone || (st[j] & 1u) == par)) link[64u * (w0 + j) + lane] = pred[j];
+                }
+            }
+            QZ_BARRIER_LDS();
+            if (tid < 512u) { /* the group's links: plain stores (read back by this workgroup in step 3) */
+#pragma unroll
+                for (uint32_t j = 0; j < 2u; j++)
+                    if (g0 + (j * 512u + tid) * 4u < b0) reinterpret_cast<uint4 *>(p1B + g0)[j * 512u + tid] = reinterpret_cast<const uint4 *>(link)[j * 512u + tid];
+            }
+            QZ_BARRIER_LDS();
+        }
+        /* 2: publish the table */
+        {
+            uint32_t *mine = hsh.tabs + (size_t)k * kSvcTabStride;
+            for (uint32_t i = tid; i < pf.tableSize; i += kThreads) __hip_atomic_store(&mine[i], tbl[i], QZ_RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0u) __hip_atomic_store(&hsh.tabFlags[k], hsh.epoch, QZ_RLX_AGENT);
+        }
+        if (!wait_for(hsh.tabFlags)) return QZSTD_HIP_NSEQ_ERROR;
+        /* 3: the table before the range, and the links that leave the range */
+        for (uint32_t i = tid; i < pf.tableSize; i += kThreads) {
+            uint32_t m = 0u;
+            for (uint32_t j = 0; j < k; j++) m = umax(m, hsh.tabs[(size_t)j * kSvcTabStride + i]);
+            tbl[i] = m;
+        }
+        __syncthreads();
+        for (uint32_t g0 = a0; g0 < b0; g0 += kGroup) {
+            hash_group(g0);
+            QZ_BARRIER_LDS();
+            if (tid < 512u) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; j++) {
+                    const uint32_t i = j * 512u + tid, pos = g0 + i;
+                    if (pos < b0) {
+                        uint32_t l1 = p1B[pos];
+                        const uint32_t st = hist[i];
+                        if (l1 == 0u && st != kNone) l1 = tbl[st & 0xFFFFu];
+                        __hip_atomic_store(&p1B[pos], l1, QZ_RLX_AGENT);
+                    }
+                }
+            }
+            QZ_BARRIER_LDS();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0u) __hip_atomic_store(&hsh.linkFlags[k], hsh.epoch, QZ_RLX_AGENT);
+        if (!wait_for(hsh.linkFlags)) return QZSTD_HIP_NSEQ_ERROR;
+        /* 4: the entries of the range */
+        for (uint32_t p0 = a0 + tid; p0 < b0; p0 += 4u * (uint32_t)kThreads) {
+            uint32_t e0[4], e1[4], e2[4], e3[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e0[i] = pp < b0 ? __hip_atomic_load(&p1B[pp], QZ_RLX_AGENT) : 0u; }
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) e1[i] = e0[i] ? __hip_atomic_load(&p1B[(e0[i] >> kTagBits) - 1u], QZ_RLX_AGENT) : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) e2[i] = e1[i] ? __hip_atomic_load(&p1B[(e1[i] >> kTagBits) - 1u], QZ_RLX_AGENT) : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) e3[i] = e2[i] ? __hip_atomic_load(&p1B[(e2[i] >> kTagBits) - 1u], QZ_RLX_AGENT) : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) {
+                const uint32_t pp = p0 + i * (uint32_t)kThreads;
+                if (pp < b0) {
+                    u64 *e = reinterpret_cast<u64 *>(chainB + pp);
+                    __hip_atomic_store(e, (u64)e0[i] | ((u64)e1[i] << 32), QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 1, (u64)e2[i] | ((u64)e3[i] << 32), QZ_RLX_AGENT);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0u) __hip_atomic_store(&hsh.flags[k], hsh.epoch, QZ_RLX_AGENT);
+        if (!wait_for(hsh.flags)) return QZSTD_HIP_NSEQ_ERROR;
+        for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
+        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
+    } else if (CHAIN && itBegin != 0u) {
         /* Chain levels, segment item: the history [0, parseFrom) has to be INSERTED AND LINKED, exactly (every position's
          * predecessor in its slot), but not walked.  Going through the tile loop for that costs one exposed HBM round trip per tile
          * (the predecessor's entry): 5.5 us x 240 tiles in front of a block's last item.  Instead:
@@ -1520,7 +1680,7 @@ __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_ke
     const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS, NEAR>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
                                                                 CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr,
                                                                 CHAIN ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
-                                                                HistShare{ nullptr, 0u, 0u, 0u });
+                                                                HistShare{ nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr, nullptr });
     if (threadIdx.x == (uint32_t)kMatchThreads) args.nseq[blockIdx.x] = count; /* lane 0 of the parse wave */
 }
 
@@ -1563,7 +1723,9 @@ struct SvcDev { /* device memory, zeroed before every launch of the service */
     uint32_t taken;     /* items a worker has picked up (diagnostics) */
     uint32_t pad[2];
     uint32_t sliceFlag[kSvcSlots][kSvcMaxItems]; /* epoch of the request whose slice k is in the slot's staging buffer */
-    uint32_t histFlag[kSvcSlots][kSvcMaxItems];  /* chain levels: epoch of the request whose item k has stored the entries of range k - 1 */
+    uint32_t histFlag[kSvcSlots][kSvcMaxItems];  /* chain levels: epoch of the request whose item k has stored the entries of its range */
+    uint32_t tabFlag[kSvcSlots][kSvcMaxItems];   /* ... has published the head table of its range (qz_item: the shared history) */
+    uint32_t linkFlag[kSvcSlots][kSvcMaxItems];  /* ... has published the first links of its range */
 };
 
 struct SvcHost { /* pinned host memory */
@@ -1592,7 +1754,7 @@ __device__ __forceinline__ u64 svc_payload(u64 g) { return g & 0x00FFFFFFFFFFFFF
  * item granules (dispatcher -> worker):
  *   0 hSrc   1 dSrc   2 the item's result region   3 the item's count word
  *   4 srcLen (18: the block up to the item's end) | parseFrom (18) << 18 | item index (6) << 36 | slot (10) << 42
- *   5 seqCap (24)               6 epoch (24)                          7 the item's chain scratch (chain levels; else 0) */
+ *   5 seqCap (24) | items of the request (6) << 24      6 epoch (24)      7 the request's chain scratch (chain levels; else 0) */
 
 template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
 __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args, SvcDev *sv, uint32_t ctlOff, uint32_t spinLimit)
@@ -1640,6 +1802,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
         blk.srcLen = (uint32_t)q4 & 0x3FFFFu;
         blk.parseFrom = (uint32_t)(q4 >> 18) & 0x3FFFFu;
         blk.seqCap = (uint32_t)q5 & 0xFFFFFFu;
+        const uint32_t nItemsReq = (uint32_t)(q5 >> 24) & 63u;
         const uint32_t k = (uint32_t)(q4 >> 36) & 63u, slotIdx = (uint32_t)(q4 >> 42) & (kSvcSlots - 1u);
         const uint32_t epoch = (uint32_t)q6 & 0xFFFFFFu;
         blk.mark = epoch; /* every entry of the item's result carries the request's epoch: see qzstd_hip_svc_req_t */
@@ -1673,7 +1836,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
         /* the request's scratch: entries of the history [BLOCK_MAX], entries of the items' own positions [BLOCK_MAX], first links [BLOCK_MAX] */
         if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, CHAIN, TURNS, false>(args, blk, dSrc, out, CHAIN ? (uint4 *)q7 : nullptr,
                                                                                CHAIN ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 32ull) : nullptr,
-                                                                               HistShare{ CHAIN ? &sv->histFlag[slotIdx][0] : nullptr, k, epoch, spinLimit });
+                                                                               HistShare{ CHAIN ? &sv->histFlag[slotIdx][0] : nullptr, k, epoch, spinLimit, nItemsReq,
+                                                                                          &sv->tabFlag[slotIdx][0], &sv->linkFlag[slotIdx][0],
+                                                                                          CHAIN ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 36ull) : nullptr });
         else if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->spinFails, 1u, QZ_RLX_AGENT);
         /* ---- completion: every wave's result stores are performed, then the count — the host's flag — with a system-scope release ---- */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1730,7 +1895,7 @@ __global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcD
                     __hip_atomic_store(e + 2, tg | (r2 + (u64)lane * cap * 16ull), QZ_RLX_AGENT);
                     __hip_atomic_store(e + 3, tg | (r3 + 4ull * lane), QZ_RLX_AGENT);
                     __hip_atomic_store(e + 4, tg | upTo | ((u64)from << 18) | ((u64)lane << 36) | ((u64)slotIdx << 42), QZ_RLX_AGENT);
-                    __hip_atomic_store(e + 5, tg | cap, QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 5, tg | cap | ((u64)nItems << 24), QZ_RLX_AGENT);
                     __hip_atomic_store(e + 6, tg | epoch, QZ_RLX_AGENT);
                     __hip_atomic_store(e + 7, tg | r7, QZ_RLX_AGENT); /* the items of a request share its scratch (HistShare) */
                 }
