@@ -1754,10 +1754,18 @@ __device__ __forceinline__ u64 svc_payload(u64 g) { return g & 0x00FFFFFFFFFFFFF
  * item granules (dispatcher -> worker):
  *   0 hSrc   1 dSrc   2 the item's result region   3 the item's count word
  *   4 srcLen (18: the block up to the item's end) | parseFrom (18) << 18 | item index (6) << 36 | slot (10) << 42
- *   5 seqCap (24) | items of the request (6) << 24      6 epoch (24)      7 the request's chain scratch (chain levels; else 0) */
+ *   5 seqCap (24) | items of the request (6) << 24      6 epoch (24) | level (8) << 24      7 the request's chain scratch (chain levels; else 0) */
 
-template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS>
-__global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args, SvcDev *sv, uint32_t ctlOff, uint32_t spinLimit)
+/* MULTI (round 4): ONE resident worker for every level whose workgroup has the 65 KB layout (levels 1-2 and 5-12, with and without the
+ * repeat-aware parse): the item's granule 6 carries the request's level, the profile comes from a table in device memory and the item
+ * goes to the variant of qz_item() its profile asks for — callers of several levels on one GPU are all served without a launch (before:
+ * one level resident, the others through the batches, about 100 us more per call).  Levels 3-4 (136 KB per workgroup) keep a worker of
+ * their own and take turns with everything else.  The four variant flags are ignored when MULTI is set. */
+constexpr uint32_t kSvcProfiles = 24u; /* (level - 1) + 12 * repeat-aware */
+__device__ __forceinline__ uint32_t svc_profile_index(uint32_t levelByte) { return ((levelByte & 0x7Fu) - 1u) + ((levelByte & 0x80u) ? 12u : 0u); }
+
+template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS, bool MULTI>
+__global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args, SvcDev *sv, uint32_t ctlOff, uint32_t spinLimit, const qzstd_hip_profile_t *profs)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = rdfirst(tid >> 6);
@@ -1833,13 +1841,26 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
             __syncthreads();
         }
         uint32_t count = QZSTD_HIP_NSEQ_ERROR;
-        /* the request's scratch: entries of the history [BLOCK_MAX], entries of the items' own positions [BLOCK_MAX], first links [BLOCK_MAX] */
-        if (rdfirst(ctl[17]) != 0u) count = qz_item<HAS_LONG, REP, CHAIN, TURNS, false>(args, blk, dSrc, out, CHAIN ? (uint4 *)q7 : nullptr,
-                                                                               CHAIN ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 32ull) : nullptr,
-                                                                               HistShare{ CHAIN ? &sv->histFlag[slotIdx][0] : nullptr, k, epoch, spinLimit, nItemsReq,
-                                                                                          &sv->tabFlag[slotIdx][0], &sv->linkFlag[slotIdx][0],
-                                                                                          CHAIN ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 36ull) : nullptr });
-        else if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->spinFails, 1u, QZ_RLX_AGENT);
+        /* the request's scratch: entries of the history [BLOCK_MAX], entries of the items' own positions [BLOCK_MAX], first links [BLOCK_MAX],
+         * one head table per item [kSvcMaxItems][kSvcTabStride] */
+#define QZ_SVC_ITEM(A, L, R, C, T)                                                                                                            \
+    qz_item<L, R, C, T, false>(A, blk, dSrc, out, (C) ? (uint4 *)q7 : nullptr, (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 32ull) : nullptr, \
+                               HistShare{ (C) ? &sv->histFlag[slotIdx][0] : nullptr, k, epoch, spinLimit, nItemsReq, &sv->tabFlag[slotIdx][0],   \
+                                          &sv->linkFlag[slotIdx][0], (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 36ull) : nullptr })
+        if (rdfirst(ctl[17]) != 0u) {
+            if (MULTI) {
+                LaunchArgs a2 = args;
+                const uint32_t pi = rdfirst(svc_profile_index((uint32_t)(q6 >> 24) & 0xFFu));
+                a2.prof = profs[pi < kSvcProfiles ? pi : 0u]; /* (uniform: the dispatcher only queues levels of the table) */
+                const bool chain = a2.prof.chainDepth != 0u, rpt = a2.prof.repWin != 0u, turns = a2.prof.subTileLog != 0u;
+                if (chain) count = rpt ? QZ_SVC_ITEM(a2, false, true, true, true) : QZ_SVC_ITEM(a2, false, false, true, true);
+                else if (turns) count = rpt ? QZ_SVC_ITEM(a2, false, true, false, true) : QZ_SVC_ITEM(a2, false, false, false, true);
+                else count = rpt ? QZ_SVC_ITEM(a2, false, true, false, false) : QZ_SVC_ITEM(a2, false, false, false, false);
+            } else {
+                count = QZ_SVC_ITEM(args, HAS_LONG, REP, CHAIN, TURNS);
+            }
+        } else if (tid == 0u) (void)__hip_atomic_fetch_add(&sv->spinFails, 1u, QZ_RLX_AGENT);
+#undef QZ_SVC_ITEM
         /* ---- completion: every wave's result stores are performed, then the count — the host's flag — with a system-scope release ---- */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1851,7 +1872,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
 }
 
 /* one wave: host ring -> device queue, and the service's life cycle */
-__global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcDev *sv, uint32_t level, uint32_t idleUs, uint32_t drainUs)
+__global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcDev *sv, uint32_t served, uint32_t idleUs, uint32_t drainUs)
 {
     const uint32_t lane = threadIdx.x;
     u64 head = __hip_atomic_load(&hs->consumed, QZ_RLX_SYSTEM); /* where the previous launch stopped */
@@ -1877,8 +1898,9 @@ __global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcD
             const uint32_t nItems = (uint32_t)(r4 >> 36) & 63u, slotIdx = (uint32_t)(r4 >> 42) & (kSvcSlots - 1u);
             const uint32_t cap = (uint32_t)r5 & 0xFFFFFFu, epoch = (uint32_t)r6 & 0xFFFFFFu, lv = (uint32_t)(r6 >> 24) & 0xFFu;
             const bool sane = nItems >= 1u && nItems <= kSvcMaxItems && itemBytes != 0u && srcLen != 0u && srcLen <= QZSTD_HIP_BLOCK_MAX &&
-                              (u64)(nItems - 1u) * itemBytes < srcLen && lv == level;
-            if (!sane) { /* another level (the workers serve one), or nonsense: handed back, the caller takes the launch path */
+                              (u64)(nItems - 1u) * itemBytes < srcLen && (lv & 0x7Fu) >= 1u && (lv & 0x7Fu) <= 12u &&
+                              ((served >> svc_profile_index(lv)) & 1u) != 0u; /* served: one bit per (level, repeat-aware) the resident workers take */
+            if (!sane) { /* a level the resident workers do not serve, or nonsense: handed back, the caller takes the launch path */
                 if (lane < umin(nItems, kSvcMaxItems)) __hip_atomic_store((uint32_t *)r3 + lane, kSvcRejected, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
                 /* room in the queue: items still running keep nothing in it (a worker copies its entry first), so the bound is
@@ -1896,7 +1918,7 @@ __global__ __launch_bounds__(64) void qzstd_service_dispatcher(SvcHost *hs, SvcD
                     __hip_atomic_store(e + 3, tg | (r3 + 4ull * lane), QZ_RLX_AGENT);
                     __hip_atomic_store(e + 4, tg | upTo | ((u64)from << 18) | ((u64)lane << 36) | ((u64)slotIdx << 42), QZ_RLX_AGENT);
                     __hip_atomic_store(e + 5, tg | cap | ((u64)nItems << 24), QZ_RLX_AGENT);
-                    __hip_atomic_store(e + 6, tg | epoch, QZ_RLX_AGENT);
+                    __hip_atomic_store(e + 6, tg | epoch | ((u64)lv << 24), QZ_RLX_AGENT);
                     __hip_atomic_store(e + 7, tg | r7, QZ_RLX_AGENT); /* the items of a request share its scratch (HistShare) */
                 }
                 tail += nItems;
@@ -2016,7 +2038,9 @@ struct Service {
     SvcDev *dv = nullptr;
     hipStream_t sWork = nullptr, sDisp = nullptr;
     hipEvent_t ev = nullptr;
-    int level = 0;   /* the level (profile) the resident workers serve */
+    int level = 0;   /* the level the resident workers were launched for */
+    uint32_t served = 0; /* one bit per (level, repeat-aware) they serve: svc_profile_index (the multi-level worker: levels 1-2 and 5-12) */
+    qzstd_hip_profile_t *dProfs = nullptr; /* device: the profiles of every level, for the multi-level worker */
     int workers = 0;
     int broken = 0;  /* a request timed out or a launch failed: the service is not used again */
     std::atomic<unsigned long long> reserve{0}; /* request numbers handed to submitters */
@@ -2502,7 +2526,7 @@ namespace {
 
 const void *svc_worker_variant(const qzstd_hip_profile_t &p)
 {
-#define QZ_W(L, R, C, T) reinterpret_cast<const void *>(qzstd_service_worker<L, R, C, T>)
+#define QZ_W(L, R, C, T) reinterpret_cast<const void *>(qzstd_service_worker<L, R, C, T, false>)
     if (p.chainDepth) return p.repWin ? QZ_W(false, true, true, true) : QZ_W(false, false, true, true);
     if (p.longSize) return p.repWin ? QZ_W(true, true, false, false) : QZ_W(true, false, false, false); /* levels 3-4: a worker fills its CU's LDS
                                                                                                          * (see Service::wide) */
@@ -2511,16 +2535,41 @@ const void *svc_worker_variant(const qzstd_hip_profile_t &p)
 #undef QZ_W
 }
 
+/* index of a level (optionally | QZSTD_HIP_LEVEL_REPCODES) in the table of profiles: the host side of svc_profile_index */
+int svc_level_index(int level)
+{
+    const int l = level & ~QZSTD_HIP_LEVEL_REPCODES;
+    return (l >= 1 && l <= 12) ? (l - 1) + ((level & QZSTD_HIP_LEVEL_REPCODES) ? 12 : 0) : -1;
+}
+
 int svc_launch_locked(int device, Service &s, int level)
 {
     const SvcConfig &cfg = svc_config();
     LaunchArgs a;
     memset(&a, 0, sizeof(a));
     if (qzstd_hip_profile_for_level(level, QZSTD_HIP_BLOCK_MAX, &a.prof)) return fail_msg("service: bad level");
-    const void *worker = svc_worker_variant(a.prof);
-    const size_t lds = qzstd_hip_lds_bytes(level, QZSTD_HIP_BLOCK_MAX);
+    /* levels 1-2 and 5-12 share the 65 KB layout: ONE worker serves them all (QZSTD_HIP_SERVICE_MULTI=0: a worker per level, as before
+     * round 4); levels 3-4 (136 KB) keep a worker of their own */
+    static const bool multiOn = [] { const char *v = getenv("QZSTD_HIP_SERVICE_MULTI"); return !(v && atoi(v) == 0); }();
+    const bool multi = multiOn && a.prof.longSize == 0u;
+    const void *worker = multi ? reinterpret_cast<const void *>(qzstd_service_worker<false, false, false, false, true>) : svc_worker_variant(a.prof);
+    size_t lds = qzstd_hip_lds_bytes(level, QZSTD_HIP_BLOCK_MAX);
+    uint32_t served = 0u;
+    qzstd_hip_profile_t profs[kSvcProfiles];
+    memset(profs, 0, sizeof(profs));
+    for (int l = 1; l <= 12; l++)
+        for (int r = 0; r < 2; r++) {
+            const int lv = l | (r ? QZSTD_HIP_LEVEL_REPCODES : 0), ix = svc_level_index(lv);
+            qzstd_hip_profile_t p;
+            if (ix < 0 || qzstd_hip_profile_for_level(lv, QZSTD_HIP_BLOCK_MAX, &p)) continue;
+            profs[ix] = p;
+            if (multi ? p.longSize == 0u : lv == level) {
+                served |= 1u << ix;
+                if (multi && qzstd_hip_lds_bytes(lv, QZSTD_HIP_BLOCK_MAX) > lds) lds = qzstd_hip_lds_bytes(lv, QZSTD_HIP_BLOCK_MAX);
+            }
+        }
     if (!worker || lds == 0) return fail_msg("service: level not served");
-    if (a.prof.chainDepth) a.orderedLds = (uint32_t)probe_lds_order(device, phys(device));
+    if (a.prof.chainDepth || multi) a.orderedLds = (uint32_t)probe_lds_order(device, phys(device));
     QZ_SET_DEVICE(device);
     for (int k = 0; k < Service::kBig; k++) {
         if (!s.bigUsed[k]) continue;
@@ -2596,16 +2645,19 @@ int svc_launch_locked(int device, Service &s, int level)
         clock_gettime(CLOCK_MONOTONIC, &t);
         __atomic_store_n(&s.launchNs, (long long)t.tv_sec * 1000000000ll + t.tv_nsec, __ATOMIC_RELAXED); /* (before `state` says "running") */
     }
+    if (!s.dProfs && hipMalloc(reinterpret_cast<void **>(&s.dProfs), sizeof(profs)) != hipSuccess) { (void)hipGetLastError(); s.dProfs = nullptr; return fail_msg("service: no memory for the profile table"); }
+    QZ_CHECK(hipMemcpyAsync(s.dProfs, profs, sizeof(profs), hipMemcpyHostToDevice, s.sWork), "hipMemcpyAsync(service profiles)");
+    QZ_CHECK(hipStreamSynchronize(s.sWork), "hipStreamSynchronize(service worker stream)");
     __atomic_store_n(&s.hs->state, 1u, __ATOMIC_RELEASE);
     s.level = level;
+    s.served = served;
     s.lds = lds;
     SvcHost *hsDev = nullptr;
     QZ_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&hsDev), s.hs, 0), "hipHostGetDevicePointer");
     uint32_t ctlOff = (uint32_t)(lds - 96u - kLdsBase), spin = (uint32_t)cfg.spinLimit;
-    void *wargs[4] = { &a, &s.dv, &ctlOff, &spin };
-    uint32_t lv = (uint32_t)level & 0xFFu, idle = (uint32_t)cfg.idleUs, drain = 1000000u;
-    if (level & QZSTD_HIP_LEVEL_REPCODES) lv |= 0x80u;
-    void *dargs[5] = { &hsDev, &s.dv, &lv, &idle, &drain };
+    void *wargs[5] = { &a, &s.dv, &ctlOff, &spin, &s.dProfs };
+    uint32_t idle = (uint32_t)cfg.idleUs, drain = 1000000u;
+    void *dargs[5] = { &hsDev, &s.dv, &served, &idle, &drain };
     /* the dispatcher first: workers without one would never be told to leave */
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(qzstd_service_dispatcher), dim3(1), dim3(64), dargs, 0, s.sDisp);
     if (e != hipSuccess) {
@@ -2650,7 +2702,10 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
             if (svc_launch_locked(device, s, level) != 0) return 1;
         }
     }
-    if (s.level != level) { s.refused++; return 1; } /* the resident workers serve another level: launch path */
+    {   /* a level the resident workers do not serve (levels 3-4 beside the multi-level worker, or the other way round): launch path */
+        const int ix = svc_level_index(level);
+        if (ix < 0 || !((s.served >> ix) & 1u)) { s.refused++; return 1; }
+    }
     void *dvSrc = nullptr, *dvSeqs = nullptr, *dvCount = nullptr;
     if (hipHostGetDevicePointer(&dvSrc, const_cast<void *>(r->hSrc), 0) != hipSuccess || hipHostGetDevicePointer(&dvSeqs, r->hSeqs, 0) != hipSuccess ||
         hipHostGetDevicePointer(&dvCount, r->hCount, 0) != hipSuccess) {

@@ -264,8 +264,14 @@ def test_service_under_load_every_item_against_the_oracle(gpu_plugin, tmp_path, 
 
 @pytest.mark.parametrize("levels,threads,reps,block", [("6,12", 16, 24, 131072), ("1,6", 16, 30, 131072), ("1,3", 12, 30, 131072), ("12,9,5", 12, 16, 32768)])
 def test_callers_of_several_levels_on_one_gpu_under_load(gpu_plugin, tmp_path, levels, threads, reps, block):
-    """the drop-in path with callers of SEVERAL levels on one GPU at once (thread t at levels[t % n]): one level's workers are resident,
-    the others take the batches, levels 3-4 and the rest take turns — every frame byte-identical to libzstd + oracle, no producer errors"""
+    """the drop-in path with callers of SEVERAL levels on one GPU at once (thread t at levels[t % n]): levels 1-2 and 5-12 are all served by
+    the one multi-level resident worker, levels 3-4 and the rest take turns — every frame byte-identical to libzstd + oracle, no producer errors"""
     exe, corpus, weblog = _stress_exe(tmp_path)
     out = _run_stress([exe, "frames", corpus if block > 32768 else weblog, levels, str(threads), str(reps), str(block)])
     assert "producer errors 0" in out, out
+    if not ({"3", "4"} & set(levels.split(","))):
+        # levels 1-2 and 5-12 share ONE resident worker (round 4: the multi-level worker): every block of every level is served without a
+        # launch — none goes through the batches (levels 3-4 fill a CU's LDS and keep taking turns with everything else)
+        import re
+        m = re.search(r"device 0: announced (\d+), batches (\d+), service (\d+)", out)
+        assert m and int(m.group(2)) == 0 and int(m.group(3)) == threads * reps, out
