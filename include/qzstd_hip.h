@@ -161,8 +161,9 @@ int qzstd_hip_occupancy(int device, int level);
  *
  * Resident kernels (one worker workgroup per CU + a one-wave dispatcher) are launched by the first request and leave
  * after QZSTD_HIP_SERVICE_IDLE_US (default 20000) without work, when memory is freed, or on qzstd_hip_service_stop().
- * Served: every level; the workers serve ONE level (profile) at a time — a request of another level is handed back while they are
- * resident — and leave when a launch needs the LDS they hold: a launch and a service whose workgroups do not fit a CU's 160 KB
+ * Served: every level.  ONE multi-level worker serves levels 1-2 and 5-12 (with and without the repeat-aware parse) at the same time —
+ * the request carries its level —, levels 3-4 (136 KB of LDS per workgroup) have a worker of their own: a request of a level the resident
+ * workers do not serve is handed back while they are resident.  The workers leave when a launch needs the LDS they hold: a launch and a service whose workgroups do not fit a CU's 160 KB
  * together take turns (batch launches of levels 3-4 against any service, any batch launch against a service of levels 3-4).
  *
  *   qzstd_hip_service_submit   0 = queued;  1 = not served (level, QZSTD_HIP_SERVICE=0, another level is resident, the
