@@ -834,7 +834,11 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     Src src;
     src.ring = (LdsWords)ring32;
     src.g = (HbmWords)reinterpret_cast<const uint32_t *>(gsrc);
+#ifdef QZ_EXP_ALLNEAR /* timing experiment only (wrong lengths for far candidates): what the device-memory side of the compares costs a kernel */
+    src.nearLimit = 0xFFFFFFFFu;
+#else
     src.nearLimit = NEAR ? 0xFFFFFFFFu : kNear;
+#endif
     const uint32_t nPad = (n + 15u) & ~15u; /* the caller keeps the buffer readable up to here */
 
     /* ---- clear the tables; segment mode below the chain levels: fast-forward over the tiles before the segment ---- */
