@@ -184,7 +184,12 @@ typedef struct {
                          * links the block before it, and leaves the chain entries of one item's range to the items after it);
                          * NULL at the other levels */
 } qzstd_hip_svc_req_t;
-#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * 36u + (size_t)QZSTD_HIP_SVC_MAX_ITEMS * 5888u * 4u) /* chain entries of the history and of the
+#ifndef QZSTD_HIP_CHAIN_ENTRY_LINKS
+#define QZSTD_HIP_CHAIN_ENTRY_LINKS 4u /* links per chain entry in device memory (levels >= 5), 4 or 8: 4 B each, one dependent gather per entry in the walk.
+                                        * Eight were measured in round 4 (bit-exact): level 5 61 -> 118, level 6 102 -> 194, level 12 269 -> 347 ms per GiB — the entries of
+                                        * positions whose predecessors lie in the same tile are hopped together link by link from LDS, seven dependent reads instead of three */
+#endif
+#define QZSTD_HIP_SVC_WORK_BYTES ((size_t)QZSTD_HIP_BLOCK_MAX * (8u * QZSTD_HIP_CHAIN_ENTRY_LINKS + 4u) + (size_t)QZSTD_HIP_SVC_MAX_ITEMS * 5888u * 4u) /* chain entries of the history and of the
                                        * items' own positions, first links, and one published head table per item */
 int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *req);
 int qzstd_hip_service_stop(int device);          /* asks the resident kernels to leave and waits for them; 0 = stopped */

@@ -87,6 +87,9 @@ constexpr uint32_t kLook = 4608u;  /* bytes staged ahead of the current tile (co
 constexpr uint32_t kNear = kRing - kLook - 3u * kTile - 1024u; /* kRing - kLook - 3 tiles of pipeline lag - slack */
 static_assert((kRing & kRingMask) == 0u && kRing >= 16384u, "the ring is a power of two of at least 16 KiB");
 constexpr size_t kLdsPerCu = 163840u; /* 160 KB */
+constexpr uint32_t kEL = QZSTD_HIP_CHAIN_ENTRY_LINKS; /* links per chain entry: the walk needs one dependent gather per kEL links */
+constexpr uint32_t kEQ = kEL / 4u;                    /* 16-byte words per entry */
+static_assert(kEL == 4u || kEL == 8u, "chain entries hold four or eight links");
 constexpr uint32_t kLdsBase = 16u; /* first LDS byte the kernel uses (csrc/qzstd_profile.c: QZ_LDS_CTRL covers it) */
 
 struct LaunchArgs {
@@ -97,7 +100,7 @@ struct LaunchArgs {
     qzstd_hip_profile_t prof; /* the level's search profile (block-size independent) */
     uint4 *chain;             /* levels >= 5: per-block chain entries (four links each), chainStride entries per block */
     uint32_t chainStride;     /* uint4 units between the scratch regions of consecutive work items */
-    uint32_t chainEntries;    /* entries per region; the region's dense array of first links (4 B per position) follows them */
+    uint32_t chainEntries;    /* 16-byte words of entries per region (positions x kEQ); the region's dense array of first links (4 B per position) follows them */
     uint32_t orderedLds;      /* this device's LDS returns from ds_max_rtn, to lanes of one instruction that hit the same address, the
                                * values in lane order (probed once per device, probe_lds_order) */
 #ifdef QZ_DEBUG_DUMP
@@ -998,23 +1001,22 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         if (tid == 0u) __hip_atomic_store(&hsh.linkFlags[k], hsh.epoch, QZ_RLX_AGENT);
         if (!wait_for(hsh.linkFlags)) return QZSTD_HIP_NSEQ_ERROR;
         /* 4: the entries of the range */
-        for (uint32_t p0 = a0 + tid; p0 < b0; p0 += 4u * (uint32_t)kThreads) {
-            uint32_t e0[4], e1[4], e2[4], e3[4];
+        constexpr uint32_t kCh = 16u / kEL; /* chases in flight per thread */
+        for (uint32_t p0 = a0 + tid; p0 < b0; p0 += kCh * (uint32_t)kThreads) {
+            uint32_t e[kEL][kCh];
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e0[i] = pp < b0 ? __hip_atomic_load(&p1B[pp], QZ_RLX_AGENT) : 0u; }
+            for (uint32_t i = 0; i < kCh; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e[0][i] = pp < b0 ? __hip_atomic_load(&p1B[pp], QZ_RLX_AGENT) : 0u; }
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) e1[i] = e0[i] ? __hip_atomic_load(&p1B[(e0[i] >> kTagBits) - 1u], QZ_RLX_AGENT) : 0u;
+            for (uint32_t d = 1; d < kEL; d++)
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) e2[i] = e1[i] ? __hip_atomic_load(&p1B[(e1[i] >> kTagBits) - 1u], QZ_RLX_AGENT) : 0u;
+                for (uint32_t i = 0; i < kCh; i++) e[d][i] = e[d - 1u][i] ? __hip_atomic_load(&p1B[(e[d - 1u][i] >> kTagBits) - 1u], QZ_RLX_AGENT) : 0u;
 #pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) e3[i] = e2[i] ? __hip_atomic_load(&p1B[(e2[i] >> kTagBits) - 1u], QZ_RLX_AGENT) : 0u;
-#pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) {
+            for (uint32_t i = 0; i < kCh; i++) {
                 const uint32_t pp = p0 + i * (uint32_t)kThreads;
                 if (pp < b0) {
-                    u64 *e = reinterpret_cast<u64 *>(chainB + pp);
-                    __hip_atomic_store(e, (u64)e0[i] | ((u64)e1[i] << 32), QZ_RLX_AGENT);
-                    __hip_atomic_store(e + 1, (u64)e2[i] | ((u64)e3[i] << 32), QZ_RLX_AGENT);
+                    u64 *w = reinterpret_cast<u64 *>(chainB + (size_t)pp * kEQ);
+#pragma unroll
+                    for (uint32_t d = 0; d < kEL; d += 2u) __hip_atomic_store(w + d / 2u, (u64)e[d][i] | ((u64)e[d + 1u][i] << 32), QZ_RLX_AGENT);
                 }
             }
         }
@@ -1112,29 +1114,28 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         /* pass 2: every history position's entry = its first link and the three behind it, chased through the dense array (L2:
          * about 1.8 us per dependent gather under load); eight independent chases per thread in flight (sixteen push the kernel past
          * 104 VGPRs: one workgroup per CU, level 6 26 -> 37 ms per 256 MiB) */
-        constexpr uint32_t kChase = 8u;
+        constexpr uint32_t kChase = 32u / kEL; /* chases in flight per thread: kEL words each */
         /* (shared scratch: only the range of the item before this one, the rest comes from the items before it) */
         const uint32_t chaseFrom = hsh.flags ? histEnd - histEnd / hsh.item : 0u; /* (a history implies item >= 1) */
         for (uint32_t p0 = chaseFrom + tid; p0 < histEnd && !QZ_ABLATED(512u); p0 += kChase * (uint32_t)kThreads) {
-            uint32_t e0[kChase], e1[kChase], e2[kChase], e3[kChase];
+            uint32_t e[kEL][kChase];
 #pragma unroll
-            for (uint32_t i = 0; i < kChase; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e0[i] = pp < histEnd ? p1B[pp] : 0u; }
+            for (uint32_t i = 0; i < kChase; i++) { const uint32_t pp = p0 + i * (uint32_t)kThreads; e[0][i] = pp < histEnd ? p1B[pp] : 0u; }
 #pragma unroll
-            for (uint32_t i = 0; i < kChase; i++) e1[i] = e0[i] ? p1B[(e0[i] >> kTagBits) - 1u] : 0u;
+            for (uint32_t d = 1; d < kEL; d++)
 #pragma unroll
-            for (uint32_t i = 0; i < kChase; i++) e2[i] = e1[i] ? p1B[(e1[i] >> kTagBits) - 1u] : 0u;
-#pragma unroll
-            for (uint32_t i = 0; i < kChase; i++) e3[i] = e2[i] ? p1B[(e2[i] >> kTagBits) - 1u] : 0u;
+                for (uint32_t i = 0; i < kChase; i++) e[d][i] = e[d - 1u][i] ? p1B[(e[d - 1u][i] >> kTagBits) - 1u] : 0u;
 #pragma unroll
             for (uint32_t i = 0; i < kChase; i++) {
                 const uint32_t pp = p0 + i * (uint32_t)kThreads;
                 if (pp < histEnd) {
                     if (hsh.flags) { /* written through: other items (other XCDs) read these */
-                        u64 *e = reinterpret_cast<u64 *>(chainB + pp);
-                        __hip_atomic_store(e, (u64)e0[i] | ((u64)e1[i] << 32), QZ_RLX_AGENT);
-                        __hip_atomic_store(e + 1, (u64)e2[i] | ((u64)e3[i] << 32), QZ_RLX_AGENT);
+                        u64 *w = reinterpret_cast<u64 *>(chainB + (size_t)pp * kEQ);
+#pragma unroll
+                        for (uint32_t d = 0; d < kEL; d += 2u) __hip_atomic_store(w + d / 2u, (u64)e[d][i] | ((u64)e[d + 1u][i] << 32), QZ_RLX_AGENT);
                     } else {
-                        chainB[pp] = make_uint4(e0[i], e1[i], e2[i], e3[i]);
+#pragma unroll
+                        for (uint32_t j = 0; j < kEQ; j++) chainB[(size_t)pp * kEQ + j] = make_uint4(e[4u * j][i], e[4u * j + 1u][i], e[4u * j + 2u][i], e[4u * j + 3u][i]);
                     }
                 }
             }
@@ -1278,9 +1279,13 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
      * on the launch paths, an array of its own where the items of a request share chainB (HistShare): there the entries of an
      * item's range are stored by the item AFTER it, written through, and nobody else may leave half-written lines of them in an
      * L2 that a reader on the same XCD would hit. */
-    uint4 *const ownB = (CHAIN && hsh.flags) ? chainB + QZSTD_HIP_BLOCK_MAX : chainB;
+    uint4 *const ownB = (CHAIN && hsh.flags) ? chainB + (size_t)QZSTD_HIP_BLOCK_MAX * kEQ : chainB;
     const uint32_t ownFrom = blk.parseFrom;
-    auto entryOf = [&](uint32_t q) -> uint4 { return (q >= ownFrom ? ownB : chainB)[q]; };
+    auto entryOf = [&](uint32_t q, uint32_t (&D)[kEL]) { /* the kEL links of position q's entry */
+        const uint4 *b = (q >= ownFrom ? ownB : chainB) + (size_t)q * kEQ;
+#pragma unroll
+        for (uint32_t j = 0; j < kEQ; j++) { const uint4 v = b[j]; D[4u * j] = v.x; D[4u * j + 1u] = v.y; D[4u * j + 2u] = v.z; D[4u * j + 3u] = v.w; }
+    };
     const uint32_t hiMask = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
     const uint32_t nearShift = 32u - kTileLog;
     const uint32_t stampShift = kTileLog + kTagBits;
@@ -1349,12 +1354,14 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 if (!TURNS) oldL = tblL[slotL];
             }
         }
-        uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t pre[kEL];
+#pragma unroll
+        for (uint32_t j = 0; j < kEL; j++) pre[j] = 0u;
         if (CHAIN && it != itBegin) {
             /* the chain entry of the predecessor (left by the parse wave during the previous tile), fetched now if that is a position of an
              * earlier tile: its entry was stored at least one barrier ago */
             old = valid ? ((it & 1u) ? P1odd : nearTab)[tid] : 0u;
-            if (old != 0u && (old >> kTagBits) - 1u < t0) pre = entryOf((old >> kTagBits) - 1u);
+            if (old != 0u && (old >> kTagBits) - 1u < t0) entryOf((old >> kTagBits) - 1u, pre);
         }
         QZ_LAP(dI1)
         __syncthreads(); /* B1 */
@@ -1406,21 +1413,25 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             tC = __builtin_amdgcn_s_memtime();
 #endif
             /* the entry of the own position */
-            uint32_t E[4] = { 0u, 0u, 0u, 0u };
+            uint32_t E[kEL];
+#pragma unroll
+            for (uint32_t j = 0; j < kEL; j++) E[j] = 0u;
             if (valid) {
                 E[0] = P1T[tid];
                 if (E[0] != 0u && (E[0] >> kTagBits) - 1u < t0) { /* predecessor in an earlier tile: its entry is here (the item's first tile: fetched now) */
-                    if (it == itBegin) pre = entryOf((E[0] >> kTagBits) - 1u);
-                    E[1] = pre.x; E[2] = pre.y; E[3] = pre.z;
+                    if (it == itBegin) entryOf((E[0] >> kTagBits) - 1u, pre);
+#pragma unroll
+                    for (uint32_t i = 1; i < kEL; i++) E[i] = pre[i - 1u];
                 } else {
 #pragma unroll
-                    for (int i = 1; i < 4; i++) { /* hop inside the tile */
-                        const uint32_t q = (E[i - 1] >> kTagBits) - 1u;
-                        if (E[i - 1] == 0u || q < t0) break;
+                    for (uint32_t i = 1; i < kEL; i++) { /* hop inside the tile */
+                        const uint32_t q = (E[i - 1u] >> kTagBits) - 1u;
+                        if (E[i - 1u] == 0u || q < t0) break;
                         E[i] = P1T[q - t0];
                     }
                 }
-                ownB[p] = make_uint4(E[0], E[1], E[2], E[3]);
+#pragma unroll
+                for (uint32_t j = 0; j < kEQ; j++) ownB[(size_t)p * kEQ + j] = make_uint4(E[4u * j], E[4u * j + 1u], E[4u * j + 2u], E[4u * j + 3u]);
             }
             /* the walk: chainDepth links, newest first; a link whose tag differs is a slot collision (skipped without
              * touching its bytes); the candidate with the highest gain stays, the nearer one on a tie */
@@ -1430,22 +1441,24 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             int bg = 0;
             QZ_CLAP(0)
             while (__ballot(E[0] != 0u)) {
-                uint32_t N[4] = { 0u, 0u, 0u, 0u };
+                uint32_t N[kEL];
+#pragma unroll
+                for (uint32_t j = 0; j < kEL; j++) N[j] = 0u;
                 if (E[0] != 0u) {
                     /* the entry behind the last link of this one: in flight during the compares */
-                    const uint32_t last = E[3] ? E[3] : (E[2] ? E[2] : (E[1] ? E[1] : E[0]));
+                    uint32_t last = E[0], cnt = 1u;
+#pragma unroll
+                    for (uint32_t j = 1; j < kEL; j++) { if (E[j] != 0u) { last = E[j]; cnt = j + 1u; } } /* (an entry's links are a prefix: zeros only behind the last) */
                     const uint32_t ql = (last >> kTagBits) - 1u;
-                    const uint32_t cnt = E[3] ? 4u : (E[2] ? 3u : (E[1] ? 2u : 1u));
                     if (walked + cnt < pf.chainDepth) {
                         if (ql < t0) {
-                            const uint4 v = entryOf(ql);
-                            N[0] = v.x; N[1] = v.y; N[2] = v.z; N[3] = v.w;
+                            entryOf(ql, N);
                         } else {
                             N[0] = P1T[ql - t0];
 #pragma unroll
-                            for (int i = 1; i < 4; i++) {
-                                const uint32_t q = (N[i - 1] >> kTagBits) - 1u;
-                                if (N[i - 1] == 0u || q < t0) break;
+                            for (uint32_t i = 1; i < kEL; i++) {
+                                const uint32_t q = (N[i - 1u] >> kTagBits) - 1u;
+                                if (N[i - 1u] == 0u || q < t0) break;
                                 N[i] = P1T[q - t0];
                             }
                         }
@@ -1462,7 +1475,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     constexpr int kG = QZ_LINKS_PER_STEP;
                     QZ_CLAP(1)
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk += kG) {
+                    for (int kk = 0; kk < (int)kEL; kk += kG) {
                         uint32_t q[kG], rq[kG];
                         bool far[kG], m[kG];
 #pragma unroll
@@ -1526,7 +1539,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 dC[5] += 1;
 #endif
 #pragma unroll
-                for (int k = 0; k < 4; k++) E[k] = N[k];
+                for (uint32_t j = 0; j < kEL; j++) E[j] = N[j];
                 QZ_CLAP(4)
             }
         } else {
@@ -1848,9 +1861,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
         /* the request's scratch: entries of the history [BLOCK_MAX], entries of the items' own positions [BLOCK_MAX], first links [BLOCK_MAX],
          * one head table per item [kSvcMaxItems][kSvcTabStride] */
 #define QZ_SVC_ITEM(A, L, R, C, T)                                                                                                            \
-    qz_item<L, R, C, T, false>(A, blk, dSrc, out, (C) ? (uint4 *)q7 : nullptr, (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 32ull) : nullptr, \
+    qz_item<L, R, C, T, false>(A, blk, dSrc, out, (C) ? (uint4 *)q7 : nullptr, (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * (8ull * kEL)) : nullptr, \
                                HistShare{ (C) ? &sv->histFlag[slotIdx][0] : nullptr, k, epoch, spinLimit, nItemsReq, &sv->tabFlag[slotIdx][0],   \
-                                          &sv->linkFlag[slotIdx][0], (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * 36ull) : nullptr })
+                                          &sv->linkFlag[slotIdx][0], (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * (8ull * kEL + 4ull)) : nullptr })
         if (rdfirst(ctl[17]) != 0u) {
             if (MULTI) {
                 LaunchArgs a2 = args;
@@ -2466,7 +2479,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         if (!d_work || workBytes < need) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
         a.chain = static_cast<uint4 *>(d_work);
         a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
-        a.chainEntries = (uint32_t)(need / nBlocks / 20u);
+        a.chainEntries = (uint32_t)(need / nBlocks / (4u * kEL + 4u)) * kEQ;
     }
     a.src = static_cast<const uint8_t *>(d_src);
     a.blocks = d_blocks;

@@ -87,7 +87,7 @@ size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockL
 {
     qzstd_hip_profile_t p;
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX || qzstd_hip_profile_for_level(level, maxBlockLen, &p) || !p.chainDepth) return 0;
-    return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * 20u; /* a chain entry of four links + the first link again, dense */
+    return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * (4u * QZSTD_HIP_CHAIN_ENTRY_LINKS + 4u); /* a chain entry of QZSTD_HIP_CHAIN_ENTRY_LINKS links + the first link again, dense */
 }
 
 #ifndef QZ_RING

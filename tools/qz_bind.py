@@ -415,7 +415,7 @@ class ServiceLane:
         work = None
         if self.L.qzstd_hip_workspace_bytes(level, 1, self.BLOCK_MAX):
             if not self.dwork:
-                self.dwork = self.L.qzstd_hip_malloc(self.device, self.BLOCK_MAX * 36 + 32 * 5888 * 4)  # QZSTD_HIP_SVC_WORK_BYTES: one scratch per request
+                self.dwork = self.L.qzstd_hip_malloc(self.device, self.BLOCK_MAX * (8 * 4 + 4) + 32 * 5888 * 4)  # QZSTD_HIP_SVC_WORK_BYTES: one scratch per request
                 assert self.dwork, self.plug.err()
             work = self.dwork
         rq = SvcReq(self.hsrc, self.dsrc, self.hseq, self.hcnt, n, item_bytes, nit, cap, self.slot, self.epoch, work)
