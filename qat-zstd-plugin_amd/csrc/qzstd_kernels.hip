@@ -87,8 +87,12 @@ constexpr uint32_t kLook = 4608u;  /* bytes staged ahead of the current tile (co
 constexpr uint32_t kNear = kRing - kLook - 3u * kTile - 1024u; /* kRing - kLook - 3 tiles of pipeline lag - slack */
 static_assert((kRing & kRingMask) == 0u && kRing >= 16384u, "the ring is a power of two of at least 16 KiB");
 constexpr size_t kLdsPerCu = 163840u; /* 160 KB */
+#ifdef QZ_EXP_LINKS4_SPACED /* experiment: four links per entry at the SPACING of eight (same gathers and hops as four, the lines of eight) */
+constexpr uint32_t kEL = 4u;
+#else
 constexpr uint32_t kEL = QZSTD_HIP_CHAIN_ENTRY_LINKS; /* links per chain entry: the walk needs one dependent gather per kEL links */
-constexpr uint32_t kEQ = kEL / 4u;                    /* 16-byte words per entry */
+#endif
+constexpr uint32_t kEQ = QZSTD_HIP_CHAIN_ENTRY_LINKS / 4u; /* 16-byte words between consecutive entries (= per entry, outside the experiment) */
 static_assert(kEL == 4u || kEL == 8u, "chain entries hold four or eight links");
 constexpr uint32_t kLdsBase = 16u; /* first LDS byte the kernel uses (csrc/qzstd_profile.c: QZ_LDS_CTRL covers it) */
 
@@ -1135,7 +1139,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         for (uint32_t d = 0; d < kEL; d += 2u) __hip_atomic_store(w + d / 2u, (u64)e[d][i] | ((u64)e[d + 1u][i] << 32), QZ_RLX_AGENT);
                     } else {
 #pragma unroll
-                        for (uint32_t j = 0; j < kEQ; j++) chainB[(size_t)pp * kEQ + j] = make_uint4(e[4u * j][i], e[4u * j + 1u][i], e[4u * j + 2u][i], e[4u * j + 3u][i]);
+                        for (uint32_t j = 0; j < kEL / 4u; j++) chainB[(size_t)pp * kEQ + j] = make_uint4(e[4u * j][i], e[4u * j + 1u][i], e[4u * j + 2u][i], e[4u * j + 3u][i]);
                     }
                 }
             }
@@ -1284,7 +1288,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     auto entryOf = [&](uint32_t q, uint32_t (&D)[kEL]) { /* the kEL links of position q's entry */
         const uint4 *b = (q >= ownFrom ? ownB : chainB) + (size_t)q * kEQ;
 #pragma unroll
-        for (uint32_t j = 0; j < kEQ; j++) { const uint4 v = b[j]; D[4u * j] = v.x; D[4u * j + 1u] = v.y; D[4u * j + 2u] = v.z; D[4u * j + 3u] = v.w; }
+        for (uint32_t j = 0; j < kEL / 4u; j++) { const uint4 v = b[j]; D[4u * j] = v.x; D[4u * j + 1u] = v.y; D[4u * j + 2u] = v.z; D[4u * j + 3u] = v.w; }
     };
     const uint32_t hiMask = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
     const uint32_t nearShift = 32u - kTileLog;
@@ -1431,7 +1435,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     }
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < kEQ; j++) ownB[(size_t)p * kEQ + j] = make_uint4(E[4u * j], E[4u * j + 1u], E[4u * j + 2u], E[4u * j + 3u]);
+                for (uint32_t j = 0; j < kEL / 4u; j++) ownB[(size_t)p * kEQ + j] = make_uint4(E[4u * j], E[4u * j + 1u], E[4u * j + 2u], E[4u * j + 3u]);
             }
             /* the walk: chainDepth links, newest first; a link whose tag differs is a slot collision (skipped without
              * touching its bytes); the candidate with the highest gain stays, the nearer one on a tie */
@@ -1861,9 +1865,9 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
         /* the request's scratch: entries of the history [BLOCK_MAX], entries of the items' own positions [BLOCK_MAX], first links [BLOCK_MAX],
          * one head table per item [kSvcMaxItems][kSvcTabStride] */
 #define QZ_SVC_ITEM(A, L, R, C, T)                                                                                                            \
-    qz_item<L, R, C, T, false>(A, blk, dSrc, out, (C) ? (uint4 *)q7 : nullptr, (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * (8ull * kEL)) : nullptr, \
+    qz_item<L, R, C, T, false>(A, blk, dSrc, out, (C) ? (uint4 *)q7 : nullptr, (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * (8ull * QZSTD_HIP_CHAIN_ENTRY_LINKS)) : nullptr, \
                                HistShare{ (C) ? &sv->histFlag[slotIdx][0] : nullptr, k, epoch, spinLimit, nItemsReq, &sv->tabFlag[slotIdx][0],   \
-                                          &sv->linkFlag[slotIdx][0], (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * (8ull * kEL + 4ull)) : nullptr })
+                                          &sv->linkFlag[slotIdx][0], (C) ? (uint32_t *)(q7 + (u64)QZSTD_HIP_BLOCK_MAX * (8ull * QZSTD_HIP_CHAIN_ENTRY_LINKS + 4ull)) : nullptr })
         if (rdfirst(ctl[17]) != 0u) {
             if (MULTI) {
                 LaunchArgs a2 = args;
@@ -2479,7 +2483,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         if (!d_work || workBytes < need) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
         a.chain = static_cast<uint4 *>(d_work);
         a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
-        a.chainEntries = (uint32_t)(need / nBlocks / (4u * kEL + 4u)) * kEQ;
+        a.chainEntries = (uint32_t)(need / nBlocks / (4u * QZSTD_HIP_CHAIN_ENTRY_LINKS + 4u)) * kEQ;
     }
     a.src = static_cast<const uint8_t *>(d_src);
     a.blocks = d_blocks;
