@@ -573,6 +573,7 @@ def main():
     kern_wall = time.perf_counter() - tk0
     kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(a.steps)]
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    kern_avg_ms_slowest = S.reduce_max_seconds(kern_avg_ms, dist if world > 1 else None, None)  # (a MAX over ranks, whatever the unit)
 
     cnt = d_cnt.cpu().numpy().astype("uint32")
     n_err = int((cnt == 0xFFFFFFFF).sum())
@@ -637,9 +638,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_input_MBps": round(size / (kern_avg_ms * 1e-3) / 1e6, 1),
                          "kernel_input_MBps_wall": round(size * a.steps / kern_wall / 1e6, 1),
+                         "kernel_input_MBps_all_gpus": round(world * size / (kern_avg_ms_slowest * 1e-3) / 1e6, 1),
                          "input_read_frac_of_peak": round(size / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "note": "the resident-input kernel rate (rounds 1-3: `value`); the metric above is bounded by host cores x libzstd's "
-                                 "entropy stage, this is what the GPU side delivers"},
+                                 "entropy stage (so is its scaling over GPUs: the ranks share the host's cores), this is what the GPU side delivers: "
+                                 "kernel_input_MBps_all_gpus = ranks x bytes per launch / the slowest rank's average launch"},
             "sequences_per_block": round(seq_total / max(nb - n_err, 1), 1), "error_blocks": n_err,
         }
         if not a.no_cpu and world == 1 and level == 1 and block == 131072:
