@@ -166,7 +166,7 @@ int qzstd_hip_occupancy(int device, int level);
  * workers do not serve is handed back while they are resident.  The workers leave when a launch needs the LDS they hold: a launch and a service whose workgroups do not fit a CU's 160 KB
  * together take turns (batch launches of levels 3-4 against any service, any batch launch against a service of levels 3-4).
  *
- *   qzstd_hip_service_submit   0 = queued;  1 = not served (level, QZSTD_HIP_SERVICE=0, another level is resident, the
+ *   qzstd_hip_service_submit   0 = queued;  1 = not served (QZSTD_HIP_SERVICE=0, a level the resident workers do not serve, the
  *                              service is down): the caller takes the launch path;  < 0 = error
  */
 #define QZSTD_HIP_NSEQ_REJECTED 0xFFFFFFFEu
@@ -199,7 +199,7 @@ int qzstd_hip_service_stop(int device);          /* asks the resident kernels to
  * has not answered will not be answered */
 int qzstd_hip_service_poke(int device, int level);
 void qzstd_hip_service_mark_broken(int device);  /* a request timed out: stop and do not use the service again */
-/* out[0] launches of the service, [1] requests queued, [2] requests refused (another level resident), [3] broken,
+/* out[0] launches of the service, [1] requests queued, [2] requests refused (a level the resident workers do not serve), [3] broken,
  * [4] state (0 stopped, 1 running), [5] items finished, [6] items that gave up waiting for a slice, [7] workers */
 int qzstd_hip_service_info(int device, unsigned long out[8]);
 /* diagnostics the dispatcher refreshes while it runs: [0] its polls of the ring, [1] requests taken, [2] items queued, [3] worker
