@@ -1494,6 +1494,16 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         bool any = false;
 #pragma unroll
                         for (int g = 0; g < kG; g++) any = any || m[g];
+#ifdef QZ_HEADS_WITH_TESTS /* A/B: the candidates' 16-byte heads requested TOGETHER with the four-byte tests (one LDS round trip instead of two per step;
+                            * the heads of candidates that fail the test are fetched for nothing) */
+                        uint32_t Q[kG][5];
+#pragma unroll
+                        for (int g = 0; g < kG; g++) {
+#pragma unroll
+                            for (int i = 0; i < 5; i++) Q[g][i] = 0u;
+                            if (m[g] && cl < cap) load_dw_r<5>(src, q[g], rq[g], far[g], Q[g]);
+                        }
+#endif
                         if (any && cl != 0u) {
                             /* links come nearest first, so a later one can only win with MORE matching bytes than the best so
                              * far (its offset costs at least as much): it has to match at byte cl, in particular.  Four bytes
@@ -1511,6 +1521,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                             for (int g = 0; g < kG; g++) m[g] = m[g] && v[g] == pw;
                         }
                         QZ_CLAP(2)
+#ifndef QZ_HEADS_WITH_TESTS
                         uint32_t Q[kG][5];
 #pragma unroll
                         for (int g = 0; g < kG; g++) {
@@ -1518,6 +1529,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                             for (int i = 0; i < 5; i++) Q[g][i] = 0u;
                             if (m[g]) load_dw_r<5>(src, q[g], rq[g], far[g], Q[g]);
                         }
+#endif
 #pragma unroll
                         for (int g = 0; g < kG; g++) {
                             if (m[g] && cl < cap) { /* (a best that fills the cap cannot be beaten: the sequential walk would not have looked) */
