@@ -57,6 +57,10 @@
 
 #include "qzstd_hip.h"
 
+#ifndef QZ_CHAIN_SHIFT
+#define QZ_CHAIN_SHIFT 1 /* chain levels: a tile's start flags are written in the next iteration's first interval (A/B: 0) */
+#endif
+
 namespace {
 
 constexpr int kMatchWaves = 8;
@@ -1230,7 +1234,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 if (work) {
                     st.tileSeq = st.nseq;
                     if (lane == 0u) srecT[0] = st.nseq; /* the records carry indices relative to this */
-                    parse_rep_span(pf, src, pvT, base, base + 64u * kSplit, n, nh, lane, st);
+                    if (!(CHAIN && QZ_CHAIN_SHIFT)) parse_rep_span(pf, src, pvT, base, base + 64u * kSplit, n, nh, lane, st);
                 }
                 if (CHAIN && it == itBegin && it < nTiles) chain_insert_tile(pf, src, tbl, (it & 1u) ? P1odd : nearTab, it << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI1)
@@ -1249,16 +1253,20 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u;
-                if (work)
+                if (work && !(CHAIN && QZ_CHAIN_SHIFT))
                     parse_tile<0, kSplit>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
                                           k << kTileLog, n, lane, st);
                 if (CHAIN && it == itBegin && it < nTiles) chain_insert_tile(pf, src, tbl, (it & 1u) ? P1odd : nearTab, it << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
                 QZ_PLAP(pW1)
-                if (work)
-                    parse_tile<kSplit, kWin>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
-                                             k << kTileLog, n, lane, st);
+                if (work) {
+                    if (CHAIN && QZ_CHAIN_SHIFT)
+                        parse_tile<0, kWin>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog, n, lane, st);
+                    else
+                        parse_tile<kSplit, kWin>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
+                                                 k << kTileLog, n, lane, st);
+                }
                 if (CHAIN && it + 1u < nTiles) chain_insert_tile(pf, src, tbl, ((it + 1u) & 1u) ? P1odd : nearTab, (it + 1u) << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI2)
                 __syncthreads(); /* B2 */
@@ -1309,6 +1317,52 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #define QZ_CLAP(k)
 #endif
 
+    /* Start flags and parse words of one tile from every position's candidate (cl = capped length, off = offset).  Below the chain levels this
+     * runs at the end of the tile's own interval 2.  At the chain levels (QZ_CHAIN_SHIFT, round 4) it runs in interval 1 of the NEXT iteration, and
+     * the parse wave — which has next to nothing to do there — parses the whole tile in that iteration's interval 2: the tile's last words no
+     * longer sit between the walk and the barrier. */
+    auto write_flags = [&](uint32_t tileIdx, uint32_t cl, uint32_t off) {
+            /* start flags: the lazy rules compare capped lengths and never look across the window edge */
+            const bool take = cl != 0u && cl >= min_len(pf, off);
+            bool defer1, defer2, defer3 = false;
+            if (pf.lazy >= 4u) {
+                /* chain levels: by gain (4 per matched byte minus the offset's bit length, biased to stay positive);
+                 * one position on must gain more than 4, two on more than 7 (oracle: qzo_is_start) */
+                const uint32_t G = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
+                const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x130, 0xF, 0xF, true);
+                const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G1, 0x130, 0xF, 0xF, true);
+                defer1 = lane < 63u && G1 > G + 4u;
+                defer2 = lane < 62u && G2 > G + 7u;
+            } else {
+                const uint32_t tl = take ? cl : 0u; /* length if this position could start a match, else 0 */
+                /* the next three positions' values: whole-wave DPP shifts (wave_shl:1 = lane i reads lane i+1), three
+                 * VALU moves instead of three LDS permutes; what lane 63/62/61 read is masked by the edge rule below */
+                const uint32_t tl1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x130, 0xF, 0xF, true);
+                const uint32_t tl2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl1, 0x130, 0xF, 0xF, true);
+                const uint32_t tl3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl2, 0x130, 0xF, 0xF, true);
+                defer1 = pf.lazy >= 1u && lane < 63u && tl1 > cl;      /* next position: strictly longer */
+                defer2 = pf.lazy >= 2u && lane < 62u && tl2 > cl;      /* two on: strictly longer */
+                defer3 = pf.lazy >= 3u && lane < 61u && tl3 > cl + 2u; /* three on: longer by more than two */
+            }
+            const bool start = take && !defer1 && !defer2 && !defer3;
+            const u64 startMask = __ballot(start);
+            /* what the parse wave needs, one word per position (see parse_tile) */
+            /* ns = the first start at/after this lane: the starts below the lane masked off word by word (a 64-bit shift by the
+             * lane is a quarter-rate instruction), v_ffbl's -1 for "none" drops out of the unsigned min */
+            const uint32_t smLo = (uint32_t)startMask, smHi = (uint32_t)(startMask >> 32);
+            const uint32_t keepLo = lane < 32u ? smLo & (0xFFFFFFFFu << (lane & 31u)) : 0u;
+            const uint32_t keepHi = lane < 32u ? smHi : smHi & (0xFFFFFFFFu << (lane & 31u));
+            const uint32_t ns = umin(umin(first_diff_bit(keepLo), first_diff_bit(keepHi) | 32u), 64u);
+            const bool capped = cl == pf.capLen;
+            const uint32_t endj = lane + cl;
+            /* the next start at/after the match end is that position's `ns`: one ds_bpermute instead of a second 64-bit shift + count */
+            const uint32_t nsEnd = (uint32_t)__shfl((int)ns, (int)(endj & 63u));
+            uint32_t nx = endj >= 64u ? endj : nsEnd;
+            nx = capped ? kNxCapped : nx;
+            /* REP: the hash gain (0 = no usable candidate; 4 len + 32 - bits(offset) < 1024) | offset << 10; bit 31 stays clear */
+            const uint32_t gRep = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
+            pv[(tileIdx & 1u) * kPvStride + tid] = REP ? (gRep | (off << 10)) : pack_pos(nx, ns, capped ? off : cl);
+    };
     for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
         const uint32_t t0 = it << kTileLog;
         const uint32_t p = t0 + tid; /* own position in tile it */
@@ -1367,6 +1421,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             old = valid ? ((it & 1u) ? P1odd : nearTab)[tid] : 0u;
             if (old != 0u && (old >> kTagBits) - 1u < t0) entryOf((old >> kTagBits) - 1u, pre);
         }
+        if (CHAIN && QZ_CHAIN_SHIFT && it > itBegin && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(4u)) write_flags(it - 1u, lenA, offA);
         QZ_LAP(dI1)
         __syncthreads(); /* B1 */
         QZ_LAP(dW1)
@@ -1638,48 +1693,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             }
         }
         }
-        if (it < nTiles && !history && !QZ_ABLATED(4u)) {
-            /* start flags: the lazy rules compare capped lengths and never look across the window edge */
-            const bool take = cl != 0u && cl >= min_len(pf, off);
-            bool defer1, defer2, defer3 = false;
-            if (pf.lazy >= 4u) {
-                /* chain levels: by gain (4 per matched byte minus the offset's bit length, biased to stay positive);
-                 * one position on must gain more than 4, two on more than 7 (oracle: qzo_is_start) */
-                const uint32_t G = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
-                const uint32_t G1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G, 0x130, 0xF, 0xF, true);
-                const uint32_t G2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)G1, 0x130, 0xF, 0xF, true);
-                defer1 = lane < 63u && G1 > G + 4u;
-                defer2 = lane < 62u && G2 > G + 7u;
-            } else {
-                const uint32_t tl = take ? cl : 0u; /* length if this position could start a match, else 0 */
-                /* the next three positions' values: whole-wave DPP shifts (wave_shl:1 = lane i reads lane i+1), three
-                 * VALU moves instead of three LDS permutes; what lane 63/62/61 read is masked by the edge rule below */
-                const uint32_t tl1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x130, 0xF, 0xF, true);
-                const uint32_t tl2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl1, 0x130, 0xF, 0xF, true);
-                const uint32_t tl3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl2, 0x130, 0xF, 0xF, true);
-                defer1 = pf.lazy >= 1u && lane < 63u && tl1 > cl;      /* next position: strictly longer */
-                defer2 = pf.lazy >= 2u && lane < 62u && tl2 > cl;      /* two on: strictly longer */
-                defer3 = pf.lazy >= 3u && lane < 61u && tl3 > cl + 2u; /* three on: longer by more than two */
-            }
-            const bool start = take && !defer1 && !defer2 && !defer3;
-            const u64 startMask = __ballot(start);
-            /* what the parse wave needs, one word per position (see parse_tile) */
-            /* ns = the first start at/after this lane: the starts below the lane masked off word by word (a 64-bit shift by the
-             * lane is a quarter-rate instruction), v_ffbl's -1 for "none" drops out of the unsigned min */
-            const uint32_t smLo = (uint32_t)startMask, smHi = (uint32_t)(startMask >> 32);
-            const uint32_t keepLo = lane < 32u ? smLo & (0xFFFFFFFFu << (lane & 31u)) : 0u;
-            const uint32_t keepHi = lane < 32u ? smHi : smHi & (0xFFFFFFFFu << (lane & 31u));
-            const uint32_t ns = umin(umin(first_diff_bit(keepLo), first_diff_bit(keepHi) | 32u), 64u);
-            const bool capped = cl == pf.capLen;
-            const uint32_t endj = lane + cl;
-            /* the next start at/after the match end is that position's `ns`: one ds_bpermute instead of a second 64-bit shift + count */
-            const uint32_t nsEnd = (uint32_t)__shfl((int)ns, (int)(endj & 63u));
-            uint32_t nx = endj >= 64u ? endj : nsEnd;
-            nx = capped ? kNxCapped : nx;
-            /* REP: the hash gain (0 = no usable candidate; 4 len + 32 - bits(offset) < 1024) | offset << 10; bit 31 stays clear */
-            const uint32_t gRep = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
-            pv[(it & 1u) * kPvStride + tid] = REP ? (gRep | (off << 10)) : pack_pos(nx, ns, capped ? off : cl);
-        }
+        if (!(CHAIN && QZ_CHAIN_SHIFT) && it < nTiles && !history && !QZ_ABLATED(4u)) write_flags(it, cl, off);
         offA = off;
         lenA = cl;
         rp = ring_fwd(rp, kTile);
