@@ -1423,7 +1423,12 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         }
         if (CHAIN && QZ_CHAIN_SHIFT && it > itBegin && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(4u)) write_flags(it - 1u, lenA, offA);
         QZ_LAP(dI1)
+#ifdef QZ_B1_LDS_ONLY /* A/B: the barrier between the intervals orders LDS traffic only — nothing in global memory crosses it (the chain entries of the
+                       * previous tile were drained at B2, the refill's load and the predecessor's entry are waited for where they are used) */
+        QZ_BARRIER_LDS(); /* B1 */
+#else
         __syncthreads(); /* B1 */
+#endif
         QZ_LAP(dW1)
 
         /* ================= interval 2 ================= */
