@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-seconds", type=float, default=5.5, help="continuous load per first-class end-to-end side leg")
     ap.add_argument("--e2e-blocks", type=int, default=4096, help="chunks per GPU per step of the timed ZSTD_compress2 leg (4096 x 128 KiB = 512 MiB)")
-    ap.add_argument("--e2e-threads", type=int, default=0, help="front-end worker threads per rank (0 = usable host cores / ranks)")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="front-end worker threads per rank (0 = the rank's share of the usable host cores + an eighth)")
     ap.add_argument("--kernel-only", action="store_true", help="only the roofline leg (K timed launches of the dominant kernel, resident input): what "
                     "tools/prof_stats.sh / prof_pmc.sh run under rocprofv3, so that the profile holds these launches and no others")
     ap.add_argument("--product-multi-gpu", type=int, default=0, help=argparse.SUPPRESS)  # internal: only that leg, in a process that sees every GPU
@@ -593,7 +593,11 @@ def main():
         return
     # ---- THE METRIC: input MB/s through ZSTD_compress2, plugin registered (module docstring); exactly a.steps timed passes
     ncpu, quota = host_cpu_budget()
-    e2e_threads = a.e2e_threads if a.e2e_threads > 0 else max(1, min(int(quota) // world, 128))
+    # threads per rank: the rank's share of the usable cores + an eighth — a worker that announces a segment sits in the HIP runtime's locks for a
+    # moment (copy + launch) and leaves its core idle; two more threads than cores fill those gaps (tools/fe_threads.sh on a 16-core box: 16 threads
+    # 3.87-3.93 GB/s, 18: 4.30-4.32, 20: 4.25-4.37 with a wider spread, 22 and more: the cgroup's CPU quota throttles, 3.5 and falling)
+    share = max(1.0, quota / world)
+    e2e_threads = a.e2e_threads if a.e2e_threads > 0 else max(1, min(int(share + share / 8.0), 128))
     e2e_nb = max(1, min(a.e2e_blocks, nb))
     e2e_buf = shard[:e2e_nb * block]
     B.Zstd()  # libzstd >= 1.5.4 first (RTLD_GLOBAL): the front-end links against it
@@ -622,7 +626,7 @@ def main():
             "data": "synthetic batch assembled from real files of the ROCm image (system corpus, tools/qz_corpus.py), repeated to size" if a.corpus == "system" else "synthetic",
             "config": {"workload": "through ZSTD_compress2: level-%d, one frame per %d KiB chunk, %d chunks (%d MiB) per GPU per step, qatSequenceProducer "
                                    "registered (no software match-finder: %d producer errors), batch front-end (include/qzstd_frontend.h) with %d CCtx "
-                                   "threads per rank (usable host cores %.0f / %d rank(s)), 2 MiB announcements; host buffers in, frames out"
+                                   "threads per rank (usable host cores %.0f / %d rank(s), plus an eighth), 2 MiB announcements; host buffers in, frames out"
                                    % (level & 0xFF, block >> 10, e2e_nb, len(e2e_buf) >> 20, e2e_info["producer_errors"]["total"], e2e_threads, quota, world),
                        "corpus": prov[:300], "level": level, "block_bytes": block, "chunks_per_gpu_per_step": e2e_nb,
                        "threads_per_rank": e2e_threads, "libzstd": B.Zstd().version(),
