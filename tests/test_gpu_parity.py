@@ -183,3 +183,24 @@ print("ballot path ok")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, QZSTD_HIP_ORDERED_LDS="0"))
     assert out.returncode == 0 and "ballot path ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("level", [1, 3, 6, 12, 0x106])
+def test_near_kernels_at_the_ring_boundary(gpu_plugin, oracle, level):
+    """round 4: a launch whose blocks all fit the LDS ring (maxBlockLen <= 32 KiB) runs the NEAR kernels — every source is compared from LDS, the
+    device-memory side of the compares is compiled out; one byte more and the launch takes the kernels with both sides.  Same sequences either
+    way: the same blocks alone (NEAR), next to a 32 769-byte block (not NEAR), and with sources as far back as a 32 KiB block allows"""
+    far = K.by_name("text", 3000, seed=5)
+    blocks = [K.by_name("weblog", 32768, seed=4), K.by_name("system", 32768, seed=9), K.by_name("mix", 32767, seed=2),
+              far + K.incompressible(3, 32768 - 6000) + far,          # the only matches lie ~29.7 KiB back: beyond kNear, inside the ring
+              K.by_name("text", 20000, seed=1)]
+    check_blocks(gpu_plugin, oracle, blocks, level)                                       # maxBlockLen 32768: NEAR
+    check_blocks(gpu_plugin, oracle, blocks + [K.by_name("text", 32769, seed=8)], level)  # maxBlockLen 32769: not NEAR
+
+
+def test_two_workgroups_per_cu_where_the_design_says_so(gpu_plugin):
+    """the LDS budget is sized for two workgroups per CU at levels 1-2 and 5-12 and one at levels 3-4 (qzstd_hip_lds_bytes); the runtime's
+    occupancy query has to agree — a register or LDS regression that halves the residency shows here, not only in the timings"""
+    L = gpu_plugin.lib
+    for level, want in ((1, 2), (2, 2), (3, 1), (4, 1), (5, 2), (6, 2), (9, 2), (12, 2), (0x101, 2), (0x106, 2)):
+        assert L.qzstd_hip_occupancy(0, level) == want, (level, L.qzstd_hip_occupancy(0, level), gpu_plugin.err())
