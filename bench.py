@@ -629,7 +629,7 @@ def main():
                                    "threads per rank (usable host cores %.0f / %d rank(s), plus an eighth), 2 MiB announcements; host buffers in, frames out"
                                    % (level & 0xFF, block >> 10, e2e_nb, len(e2e_buf) >> 20, e2e_info["producer_errors"]["total"], e2e_threads, quota, world),
                        "corpus": prov[:300], "level": level, "block_bytes": block, "chunks_per_gpu_per_step": e2e_nb,
-                       "threads_per_rank": e2e_threads, "libzstd": B.Zstd().version(),
+                       "threads_per_rank": e2e_threads, "libzstd": B.Zstd().version(), "libzstd_build": B.libzstd_build(B.find_libzstd()),
                        "parallelism": "block-sharded x%d (one process per GPU, each rank's plugin sees its own GPU only), no collective" % world},
             "e2e": dict(e2e_info, served_by_gpu=served_by_gpu, pass_s_median=round(srt[len(srt) // 2], 4), pass_s_min=round(srt[0], 4),
                         pass_s_max=round(srt[-1], 4),

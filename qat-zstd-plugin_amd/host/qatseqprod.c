@@ -193,9 +193,10 @@ typedef struct {
     int numaThreadNode;            /* QZSTD_HIP_NUMA_NODE: treat every calling thread as running on this node (-1: ask the kernel) */
     int devNode[QZ_MAX_DEVICES];   /* -1 = unknown */
     unsigned int nodeNext[QZ_NUMA_NODES_MAX], anyNext; /* round-robin counters: per node, and the fallback over all GPUs */
+    int hintDirect;                /* QZSTD_HIP_HINT_DIRECT: the kernel of an announcement reads the pinned staging copy itself (no H2D copy) */
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER, 1, -1, { 0 }, { 0 }, 0 };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER, 1, -1, { 0 }, { 0 }, 0, 0 };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
  * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
@@ -227,6 +228,9 @@ typedef struct {
     unsigned int *hCount;     /* pinned */
     qzstd_hip_block_t *hDesc; /* pinned */
     void *dvSeqs, *dvCount, *dvDesc; /* device-side addresses of the three: the kernels use them directly */
+    void *dvSrc;                     /* ... and of hSrc (QZSTD_HIP_HINT_DIRECT: the kernel reads the staging copy itself) */
+    const void *dvOf[4];             /* the host buffers the four were asked for: asked again only when a buffer was replaced (the
+                                      * runtime's look-up takes its global lock: ~0.5 ms per call with 16 announcing threads) */
     size_t hSrcCap, hSeqsCap, hCountCap, hDescCap; /* bytes */
     int nStuck, stuckSlot[QZ_HINT_PARTS]; /* slots whose wait timed out: a kernel may still read and write the buffers above */
 } QZSTD_Hint_T;
@@ -261,7 +265,7 @@ typedef struct {
     unsigned long servedFromBatch, servedSync, servedService;
     unsigned long fail[QZ_CAUSE_N]; /* callbacks that returned the error code, by cause ([0] = all of them) */
     unsigned long redoneAlone;      /* blocks too dense for a batch's result area, redone on a slot of their own (not errors) */
-    unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs; /* event log only */
+    unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs, hintCopyCallNs, hintLaunchCallNs, hintPrepNs, hintDropNs; /* event log only */
 } QZSTD_Session_T;
 
 #define QZ_AUTO_DEPTH_MIN 2u  /* transparent look-ahead: blocks guessed ahead, doubling while guesses are consumed */
@@ -808,6 +812,7 @@ int QZSTD_startQatDevice(void)
         gProc.service = qzEnvInt("QZSTD_HIP_SERVICE", 1, 0, 1);
         gProc.svcItemBytes = qzEnvInt("QZSTD_HIP_SERVICE_ITEM", 4096, 4096, (int)QZSTD_HIP_BLOCK_MAX) & ~4095;
         gProc.svcSpinUs = qzEnvInt("QZSTD_HIP_SERVICE_SPIN_US", 400, 0, 1000000);
+        gProc.hintDirect = qzEnvInt("QZSTD_HIP_HINT_DIRECT", 0, 0, 1);
         {
             /* The transparent look-ahead READS memory behind the block a callback names, so it is strictly opt-in:
              * QZSTD_HIP_LOOKAHEAD = 0 / unset: off; 1: on; 2: on and always through a pipe.  It needs a fault-safe read:
@@ -906,7 +911,7 @@ static void qzOrphanHint(QZSTD_Hint_T *h)
         pthread_mutex_unlock(&qzOrphanMu);
     }
     h->hSrc = NULL; h->hSeqs = NULL; h->hCount = NULL; h->hDesc = NULL;
-    h->dvSeqs = h->dvCount = h->dvDesc = NULL;
+    h->dvSeqs = h->dvCount = h->dvDesc = h->dvSrc = NULL;
     h->hSrcCap = h->hSeqsCap = h->hCountCap = h->hDescCap = 0;
     h->nStuck = 0;
     QZ_LOG(1, "an announcement's buffers are parked until a timed-out stream drains\n");
@@ -955,9 +960,9 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
     int k;
     if (!s) return;
     QZ_LOG(2, "state %p: %lu block(s) served from a look-ahead batch (%lu of them speculative, %lu speculation(s)), %lu per "
-              "block; %lu hint(s): staging %.2f ms, queueing %.2f ms, waited %.2f ms for the GPU\n", (void *)s,
-           s->servedFromBatch, s->autoServed, s->autoLaunched, s->servedSync, s->hintCalls, s->hintStageNs / 1e6,
-           s->hintQueueNs / 1e6, s->hintWaitNs / 1e6);
+              "block; %lu hint(s), timers from the 9th on: drop %.2f ms, buffers %.2f ms, staging %.2f ms, queueing %.2f ms (%.2f ms of it in the copy call, %.2f in the launch call), waited %.2f ms for the GPU\n", (void *)s,
+           s->servedFromBatch, s->autoServed, s->autoLaunched, s->servedSync, s->hintCalls, s->hintDropNs / 1e6, s->hintPrepNs / 1e6, s->hintStageNs / 1e6,
+           s->hintQueueNs / 1e6, s->hintCopyCallNs / 1e6, s->hintLaunchCallNs / 1e6, s->hintWaitNs / 1e6);
     for (k = 0; k < 4; k++) {
         qzHintDrop(&s->hint[k]);
         /* the staged copies are the caller's data (for a guess: bytes it never handed over): scrubbed before the
@@ -1636,8 +1641,10 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
     }
     if (dev < 0) s->slotHint = i;
     if (qzSetupSlot(sl, 0) != QZSTD_OK) goto fail;
-    sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, bytes);
-    if (!sl->dBatchSrc) goto fail;
+    if (!gProc.hintDirect) {
+        sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, bytes);
+        if (!sl->dBatchSrc) goto fail;
+    }
     {
         const size_t work = qzstd_hip_workspace_bytes(level, (unsigned int)(b1 - b0), (unsigned int)h->block);
         if (work) sl->dBatchWork = qzGrowDev(sl->device, sl->dBatchWork, &sl->dBatchWorkCap, work);
@@ -1645,12 +1652,25 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
     }
     for (b = b0; b < b1; b++) h->hDesc[b].srcOff = b * h->block - o0; /* relative to this part's device buffer */
     /* everything below is queued on the slot's stream and returns immediately */
-    if (qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc + o0, bytes) ||
-        qzstd_hip_find_sequences(sl->device, sl->stream, level, sl->dBatchSrc, (const qzstd_hip_block_t *)h->dvDesc + b0,
-                                 (unsigned int)(b1 - b0), (unsigned int)h->block, h->dvSeqs, (unsigned int *)h->dvCount + b0,
-                                 sl->dBatchWork, sl->dBatchWorkCap)) {
-        if (qzWait(sl->device, sl->stream) == 1) sl->stuck = 1;
-        goto fail;
+    if (!gProc.hintDirect) {
+        const unsigned long t0 = qzNowNs();
+        const int rc = qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc + o0, bytes);
+        s->hintCopyCallNs += qzNowNs() - t0;
+        if (rc) { if (qzWait(sl->device, sl->stream) == 1) sl->stuck = 1; goto fail; }
+    }
+    {
+        const unsigned char *dsrc = gProc.hintDirect ? (const unsigned char *)h->dvSrc : sl->dBatchSrc;
+        const unsigned long t0 = qzNowNs();
+        int rc = dsrc == NULL;
+        if (!rc)
+            rc = qzstd_hip_find_sequences(sl->device, sl->stream, level, gProc.hintDirect ? dsrc + o0 : dsrc, (const qzstd_hip_block_t *)h->dvDesc + b0,
+                                          (unsigned int)(b1 - b0), (unsigned int)h->block, h->dvSeqs, (unsigned int *)h->dvCount + b0,
+                                          sl->dBatchWork, sl->dBatchWorkCap);
+        s->hintLaunchCallNs += qzNowNs() - t0;
+        if (rc) {
+            if (qzWait(sl->device, sl->stream) == 1) sl->stuck = 1;
+            goto fail;
+        }
     }
     __atomic_fetch_add(&gProc.devBlocks[sl->device][0], (unsigned long)(b1 - b0), __ATOMIC_RELAXED);
     pt->st = 1; /* in flight; the slot stays ours until qzPartFinish() */
@@ -1673,10 +1693,12 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
                          int compressionLevel, int speculative)
 {
     size_t nb, blocksBytes, srcBytes;
-    unsigned long tq;
+    unsigned long tq, tp;
     int parts, k, firstDev;
 
+    tp = qzNowNs();
     qzHintDrop(h); /* an old announcement that was never consumed */
+    s->hintDropNs += qzNowNs() - tp;
     if (qzOrphans) qzReapOrphans(0);
     nb = (srcSize + blockSize - 1) / blockSize;
     /* a fine grid means many blocks: the result area is sized by what a block of that size can produce at most */
@@ -1686,14 +1708,18 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
 
     if (s->slotHint < 0) s->slotHint = qzPickHint(); /* the state's own GPU: sticky from its first use */
     firstDev = s->slotHint % gProc.numDevices;
+    tp = qzNowNs();
     h->hSrc = (unsigned char *)qzGrowHost(h->hSrc, &h->hSrcCap, srcBytes, firstDev);
     h->hDesc = (qzstd_hip_block_t *)qzGrowHost(h->hDesc, &h->hDescCap, blocksBytes, firstDev);
     h->hCount = (unsigned int *)qzGrowHost(h->hCount, &h->hCountCap, nb * sizeof(unsigned int), firstDev);
     h->hSeqs = (ZSTD_Sequence *)qzGrowHost(h->hSeqs, &h->hSeqsCap, nb * h->pitch * sizeof(ZSTD_Sequence), firstDev);
-    h->dvDesc = qzstd_hip_host_device_ptr(h->hDesc);
-    h->dvCount = qzstd_hip_host_device_ptr(h->hCount);
-    h->dvSeqs = qzstd_hip_host_device_ptr(h->hSeqs);
-    if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs || !h->dvDesc || !h->dvCount || !h->dvSeqs) return 0;
+    if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs) return 0;
+    if (h->dvOf[0] != h->hDesc || !h->dvDesc) { h->dvDesc = qzstd_hip_host_device_ptr(h->hDesc); h->dvOf[0] = h->hDesc; }
+    if (h->dvOf[1] != h->hCount || !h->dvCount) { h->dvCount = qzstd_hip_host_device_ptr(h->hCount); h->dvOf[1] = h->hCount; }
+    if (h->dvOf[2] != h->hSeqs || !h->dvSeqs) { h->dvSeqs = qzstd_hip_host_device_ptr(h->hSeqs); h->dvOf[2] = h->hSeqs; }
+    if (gProc.hintDirect && (h->dvOf[3] != h->hSrc || !h->dvSrc)) { h->dvSrc = qzstd_hip_host_device_ptr(h->hSrc); h->dvOf[3] = h->hSrc; }
+    if (!h->dvDesc || !h->dvCount || !h->dvSeqs || (gProc.hintDirect && !h->dvSrc)) return 0;
+    s->hintPrepNs += qzNowNs() - tp;
 
     tq = qzNowNs();
     if (speculative) {
@@ -1781,6 +1807,8 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
         return -1;
     }
     s->hintCalls++;
+    if (s->hintCalls == 8) /* the event log's timers: steady state only (the first announcements allocate pinned buffers and create streams) */
+        s->hintStageNs = s->hintQueueNs = s->hintWaitNs = s->hintCopyCallNs = s->hintLaunchCallNs = s->hintPrepNs = s->hintDropNs = 0;
     return 0;
 }
 

@@ -1,9 +1,10 @@
 """ctypes bindings shared by tests/, tools/ and bench.py.
 
 * ``Zstd``     — libzstd >= 1.5.4 (the caller of the sequence producer and the judge of
-                 its output).  Discovery order: $ZSTDLIB, system
+                 its output).  Discovery order: $ZSTDLIB, the normally-built
+                 1.5.7 inside pyarrow's libarrow.so through tools/zstdshim (round 4), a system
                  libzstd that exports ZSTD_registerSequenceProducer, the copy bundled in
-                 pillow.libs (1.5.7 on the ROCm image).
+                 pillow.libs (1.5.7 on the ROCm image, a ~4x slower build).
 * ``Oracle``   — oracle/libqzstd_oracle.so (TEST INFRASTRUCTURE: only tests, smoke() and
                  bench.py's cpu_baseline leg may use it).
 * ``Plugin``   — the product: libqatseqprod.so (drop-in C surface + qzstd_hip_* C-ABI).
@@ -47,7 +48,35 @@ ps_auto, ps_enable, ps_disable = 0, 1, 2
 e_continue, e_flush, e_end = 0, 1, 2
 
 
-def find_libzstd() -> str:
+SHIM_DIR = os.path.join(ROOT, "tools", "zstdshim")
+SHIM_SO = os.path.join(SHIM_DIR, "libzstd-arrow.so")
+_libzstd_path = None
+
+
+def fast_libzstd() -> str | None:
+    """tools/zstdshim: the normally-built zstd 1.5.7 inside pyarrow's libarrow.so behind the public ZSTD_* names (zstdshim.c says why: the
+    only exported libzstd >= 1.5.4 on the image, Pillow's, is a 4x slower build).  Builds the shim when it is missing or older than its
+    sources; returns its path when it resolved every name (zstdshim_ok), else None.  $QZ_ZSTD_NO_SHIM=1 turns it off."""
+    if os.environ.get("QZ_ZSTD_NO_SHIM", "0") not in ("", "0"):
+        return None
+    srcs = [os.path.join(SHIM_DIR, "zstdshim.c"), os.path.join(SHIM_DIR, "zstd_names.h")]
+    try:
+        if not all(os.path.isfile(x) for x in srcs):
+            return None
+        if not os.path.isfile(SHIM_SO) or os.path.getmtime(SHIM_SO) < max(os.path.getmtime(x) for x in srcs):
+            import subprocess
+            tmp = "%s.%d.tmp" % (SHIM_SO, os.getpid())  # (several pytest workers may get here together: build aside, rename)
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", tmp, srcs[0], "-ldl", "-Wl,-soname,libzstd-arrow.so"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            os.replace(tmp, SHIM_SO)
+        lib = C.CDLL(SHIM_SO)
+        return SHIM_SO if lib.zstdshim_ok() == 1 and hasattr(lib, "ZSTD_registerSequenceProducer") else None
+    except Exception:  # noqa: BLE001 - no gcc, no libarrow.so, an image without pyarrow: the Pillow copy it is
+        return None
+
+
+def slow_libzstd() -> str:
+    """an EXPORTED libzstd >= 1.5.4: $ZSTDLIB, the system's, the copy bundled in pillow.libs (a slow build: see fast_libzstd)"""
     cands = []
     env = os.environ.get("ZSTDLIB")
     if env:
@@ -66,6 +95,23 @@ def find_libzstd() -> str:
         except OSError:
             continue
     raise OSError("no libzstd >= 1.5.4 (ZSTD_registerSequenceProducer) found; set $ZSTDLIB")
+
+
+def find_libzstd() -> str:
+    """the libzstd every test, tool and bench leg runs: $ZSTDLIB when set, else the shim over libarrow.so's copy when it works, else slow_libzstd()"""
+    global _libzstd_path
+    if _libzstd_path is None:
+        _libzstd_path = (None if os.environ.get("ZSTDLIB") else fast_libzstd()) or slow_libzstd()
+    return _libzstd_path
+
+
+def libzstd_build(path: str) -> str:
+    """what a bench line says about the libzstd it ran"""
+    if os.path.abspath(path) == os.path.abspath(SHIM_SO):
+        lib = C.CDLL(path)
+        lib.zstdshim_source.restype = C.c_char_p
+        return "the copy inside %s through tools/zstdshim (a normal build)" % lib.zstdshim_source().decode()
+    return path + (" (the image's Pillow copy: a ~4x slower build)" if "pillow.libs" in path else "")
 
 
 class ZBounds(C.Structure):
@@ -495,3 +541,9 @@ class Front:
             return [dst.raw[c * stride:c * stride + sizes[c]] for c in range(n)], list(st), list(fs)
         finally:
             F.QZSTD_freeFront(f)
+
+
+if __name__ == "__main__":  # `python tools/qz_bind.py --libzstd`: the Makefiles' default ZSTDLIB
+    import sys
+    if "--libzstd" in sys.argv:
+        print(find_libzstd())
