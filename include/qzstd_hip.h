@@ -113,6 +113,9 @@ int qzstd_hip_stream_query(int device, void *stream); /* 0 done, 1 still running
  * 0 = everything queued on the stream is done, 1 = still running after timeoutMs, <0 error */
 int qzstd_hip_stream_wait(int device, void *stream, unsigned timeoutMs);
 int qzstd_hip_memcpy_h2d(int device, void *stream, void *dst, const void *src, size_t bytes);
+/* the same for a PINNED source, done by a kernel on the stream instead of the runtime's copy path (round 4: an announcing thread spent 1 ms
+ * per 4 MiB inside hipMemcpyAsync): src_dev = qzstd_hip_host_device_ptr(pinned source); 16-byte aligned, bytes a multiple of 16 */
+int qzstd_hip_copy_in(int device, void *stream, void *dst, const void *src_dev, size_t bytes);
 int qzstd_hip_memcpy_d2h(int device, void *stream, void *dst, const void *src, size_t bytes);
 int qzstd_hip_memset(int device, void *stream, void *dst, int value, size_t bytes);
 /* strided device->host copy: `height` rows of `width` bytes, row r at src + r*spitch -> dst + r*dpitch */

@@ -1733,7 +1733,13 @@ __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_ke
                                                                 CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr,
                                                                 CHAIN ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
                                                                 HistShare{ nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr, nullptr });
-    if (threadIdx.x == (uint32_t)kMatchThreads) args.nseq[blockIdx.x] = count; /* lane 0 of the parse wave */
+    /* The count is the host's flag when the result area is pinned host memory (announcements: host/qatseqprod.c polls the count words instead
+     * of asking the runtime about the stream — a stream query waits for whatever else shares the stream's hardware queue): every wave's result
+     * stores are performed, then the count with a system-scope release.  The resident service publishes its items the same way. */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == (uint32_t)kMatchThreads) /* lane 0 of the parse wave */
+        __hip_atomic_store(args.nseq + blockIdx.x, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* ======================================================================================================================
@@ -2210,6 +2216,20 @@ static int probe_lds_order(int device, int physDev)
 static void probe_devices()
 {
     int n = 0;
+    /* Announcements run on one stream per slot; the runtime folds its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and launches
+     * of different streams that share a queue run one after the other — four 32-block launches at a time leave the GPU mostly idle and the
+     * announcing threads waiting (batch front-end, 16 threads, level 1: 12.5 GB/s with 4 queues, 14.6 with 8, 18.3 with 16, 17.1 with 24).
+     * The variable is read when the runtime starts, so it only helps when this is the process's first HIP call; a value the
+     * environment already carries is left alone.  QZSTD_HIP_HW_QUEUES=0 leaves the runtime's default. */
+    {
+        const char *q = getenv("QZSTD_HIP_HW_QUEUES");
+        const int want = q && *q ? atoi(q) : 16;
+        if (want > 0 && want <= 64) {
+            char buf[16];
+            snprintf(buf, sizeof(buf), "%d", want);
+            (void)setenv("GPU_MAX_HW_QUEUES", buf, 0);
+        }
+    }
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { fail("hipGetDeviceCount", e); (void)hipGetLastError(); g_devCount = -1; return; }
     g_devCount = 0;
@@ -2414,6 +2434,33 @@ int qzstd_hip_memcpy_h2d(int device, void *stream, void *dst, const void *src, s
 {
     QZ_SET_DEVICE(device);
     QZ_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync H2D");
+    return 0;
+}
+
+/* pinned host memory -> device memory by a KERNEL on the stream: 16 bytes per lane and step, every wave streaming its own 16 KiB stripes.
+ * For the staging copies of announcements (host/qatseqprod.c, qzLaunchPart): hipMemcpyAsync holds the calling thread for 0.8-1.1 ms per 4 MiB
+ * when 16 threads announce (the runtime's copy path and its locks); a launch costs 10-30 us, and the copy then runs at the bus's rate in front
+ * of the match-finder on the same stream.  src_dev = the DEVICE address of the pinned buffer (qzstd_hip_host_device_ptr); bytes a multiple
+ * of 16, both addresses 16-byte aligned. */
+}
+namespace {
+__global__ __launch_bounds__(256) void qzstd_copy_in_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+}
+extern "C" {
+int qzstd_hip_copy_in(int device, void *stream, void *dst, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (!dst || !src_dev || (bytes & 15u) || ((uintptr_t)dst & 15u) || ((uintptr_t)src_dev & 15u) || bytes > ((size_t)1 << 34))
+        return fail_msg("qzstd_hip_copy_in: null, unaligned or oversized");
+    QZ_SET_DEVICE(device);
+    const uint32_t n16 = (uint32_t)(bytes >> 4);
+    uint32_t groups = (n16 + 1023u) / 1024u; /* four steps per lane */
+    if (groups > 1024u) groups = 1024u;
+    hipLaunchKernelGGL(qzstd_copy_in_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, static_cast<uint4 *>(dst), static_cast<const uint4 *>(src_dev), n16);
+    QZ_CHECK(hipGetLastError(), "launch qzstd_copy_in_kernel");
     return 0;
 }
 

@@ -2,9 +2,9 @@
  * qzstd_frontend.c — batch front-end for the host entropy stage (include/qzstd_frontend.h).
  *
  * A persistent pool of workers, each with its own ZSTD_CCtx + producer state (the reference's threading model:
- * one CCtx per thread, /root/reference/test/benchmark.c:241, :514-516), fed from one shared segment counter.  A worker
- * keeps two segments claimed: the one it is entropy-coding and the next one, already announced to the GPUs
- * (QZSTD_hintSource), so match-finding always runs one segment ahead of the thread that will consume it.
+ * one CCtx per thread, /root/reference/test/benchmark.c:241, :514-516), fed from one shared chunk cursor.  A worker
+ * keeps several claims: the one it is entropy-coding and the next two (QZSTD_FRONT_AHEAD), already announced to the GPUs
+ * (QZSTD_hintSource), so match-finding always runs ahead of the thread that will consume it.
  */
 #include "qzstd_frontend.h"
 
@@ -16,6 +16,7 @@
 
 #define QF_NONE ((size_t)-1)
 #define QF_HINT_MAX ((size_t)16 << 20)
+#define QF_AHEAD_MAX 3u
 
 typedef struct {
     QZSTD_Front *front;
@@ -35,40 +36,60 @@ struct QZSTD_Front_s {
     unsigned long gen; /* bumped per job */
     int quit, running, failed;
     const unsigned char *src;
-    size_t srcSize, nChunks, nSegs;
+    size_t srcSize, nChunks;
     unsigned char *dst;
     size_t *sizes;
-    size_t nextSeg; /* shared claim counter (atomic) */
+    size_t nextChunk; /* shared claim cursor (atomic) */
+    unsigned ahead;   /* claims a worker keeps announced beyond the one it is entropy-coding: $QZSTD_FRONT_AHEAD, 1..3, default 2 */
     unsigned long served[2];
 };
 
-static size_t qfClaim(QZSTD_Front *f)
+/* A claim: chunks [c0, c1) of the job.  Claims are not all the same size (round 4, with a libzstd whose entropy stage runs at 1.6 GB/s per
+ * core a 512 MiB job is over in 25 ms and its first and last milliseconds count):
+ *   - a worker's first claims are small (an eighth, then a quarter, then half of a segment): the GPU's first results are back after
+ *     the time one block takes, not after a whole segment was staged and queued, and the pipeline below fills while they are consumed;
+ *   - towards the end of the job a claim is at most a (2 x threads)-th of what is left, so the workers finish together;
+ *   - never less than QF_MIN_CHUNKS chunks (a launch of fewer than four blocks is not worth its queueing). */
+#define QF_MIN_CHUNKS 4u
+typedef struct { size_t c0, c1; } QF_Seg;
+
+static int qfClaim(QZSTD_Front *f, unsigned nth, QF_Seg *out)
 {
-    const size_t s = __atomic_fetch_add(&f->nextSeg, 1, __ATOMIC_RELAXED);
-    return s < f->nSegs ? s : QF_NONE;
+    size_t want = f->segChunks, have, left;
+    if (nth < 3 && (f->segChunks >> (3 - nth)) >= QF_MIN_CHUNKS) want = f->segChunks >> (3 - nth);
+    have = __atomic_load_n(&f->nextChunk, __ATOMIC_RELAXED);
+    if (have >= f->nChunks) return 0;
+    left = (f->nChunks - have) / (2u * (size_t)f->p.nThreads);
+    if (want > left) want = left;
+    if (want < QF_MIN_CHUNKS) want = QF_MIN_CHUNKS;
+    if (want > f->segChunks) want = f->segChunks;
+    have = __atomic_fetch_add(&f->nextChunk, want, __ATOMIC_RELAXED);
+    if (have >= f->nChunks) return 0;
+    out->c0 = have;
+    out->c1 = have + want < f->nChunks ? have + want : f->nChunks;
+    return 1;
 }
 
-static void qfAnnounce(QZSTD_Front *f, QF_Worker *w, size_t seg)
+static void qfAnnounce(QZSTD_Front *f, QF_Worker *w, const QF_Seg *sg)
 {
-    const size_t off = seg * f->segChunks * f->p.chunkSize;
-    size_t len = f->segChunks * f->p.chunkSize, grid = f->p.chunkSize;
-    if (!f->p.useProducer || seg == QF_NONE) return;
+    const size_t off = sg->c0 * f->p.chunkSize;
+    size_t len = (sg->c1 - sg->c0) * f->p.chunkSize, grid = f->p.chunkSize;
+    if (!f->p.useProducer) return;
     if (len > f->srcSize - off) len = f->srcSize - off;
     /* the block grid of the announcement: the chunk when a chunk is one block; 128 KiB blocks inside bigger frames */
     if (grid > 131072) grid = 131072;
     if ((grid & 15) || len > QF_HINT_MAX) return; /* not announceable: the callbacks take the per-block path */
     /* every chunk is its own frame whose blocks start at the chunk's start: the announcement's grid (anchored at the
-     * segment's start) only names those blocks if the chunks are whole grid cells — otherwise every callback would miss
+     * claim's start) only names those blocks if the chunks are whole grid cells — otherwise every callback would miss
      * and the GPU would match-find everything twice (round-2 ADVICE) */
     if (f->p.chunkSize > grid && f->p.chunkSize % grid != 0) return;
     (void)QZSTD_hintSource(w->state, f->src + off, len, grid, f->p.level);
 }
 
-static int qfCompressSegment(QZSTD_Front *f, QF_Worker *w, size_t seg)
+static int qfCompressSegment(QZSTD_Front *f, QF_Worker *w, const QF_Seg *sg)
 {
-    size_t c = seg * f->segChunks;
-    const size_t cEnd = c + f->segChunks < f->nChunks ? c + f->segChunks : f->nChunks;
-    for (; c < cEnd; c++) {
+    size_t c;
+    for (c = sg->c0; c < sg->c1; c++) {
         const size_t off = c * f->p.chunkSize;
         const size_t n = f->srcSize - off < f->p.chunkSize ? f->srcSize - off : f->p.chunkSize;
         const size_t r = ZSTD_compress2(w->zc, f->dst + c * f->stride, f->stride, f->src + off, n);
@@ -84,21 +105,29 @@ static void *qfWorker(void *arg)
     QZSTD_Front *f = w->front;
     unsigned long seen = 0;
     for (;;) {
-        size_t cur, nxt;
-        int bad = 0;
+        QF_Seg q[QF_AHEAD_MAX + 1]; /* claimed and announced, oldest first: q[0] is the one being entropy-coded */
+        unsigned n = 0, claims = 0;
+        int bad = 0, more = 1;
         pthread_mutex_lock(&f->mu);
         while (!f->quit && f->gen == seen) pthread_cond_wait(&f->cvWork, &f->mu);
         if (f->quit) { pthread_mutex_unlock(&f->mu); break; }
         seen = f->gen;
         pthread_mutex_unlock(&f->mu);
 
-        cur = qfClaim(f);
-        qfAnnounce(f, w, cur);
-        while (cur != QF_NONE) {
-            nxt = qfClaim(f);
-            qfAnnounce(f, w, nxt); /* the GPUs work on the next segment while this thread entropy-codes the current one */
-            if (!bad && qfCompressSegment(f, w, cur) != 0) bad = 1;
-            cur = nxt;
+        for (;;) {
+            /* keep `ahead` claims announced beyond the current one: the GPUs match-find them while this thread entropy-codes q[0]
+             * (a state holds four announcements: three ahead at most) */
+            while (more && n < f->ahead + 1u) {
+                more = qfClaim(f, claims, &q[n]);
+                if (!more) break;
+                claims++;
+                qfAnnounce(f, w, &q[n]);
+                n++;
+            }
+            if (n == 0) break;
+            if (!bad && qfCompressSegment(f, w, &q[0]) != 0) bad = 1;
+            memmove(&q[0], &q[1], (n - 1) * sizeof(q[0]));
+            n--;
         }
         pthread_mutex_lock(&f->mu);
         if (bad) f->failed = 1;
@@ -121,6 +150,11 @@ QZSTD_Front *QZSTD_createFront(const QZSTD_FrontParams *p)
     if (seg > QF_HINT_MAX) seg = QF_HINT_MAX;
     f->segChunks = seg / p->chunkSize ? seg / p->chunkSize : 1;
     f->stride = ZSTD_compressBound(p->chunkSize);
+    {
+        const char *a = getenv("QZSTD_FRONT_AHEAD");
+        const int v = a && *a ? atoi(a) : 2;
+        f->ahead = v < 1 ? 1u : (v > (int)QF_AHEAD_MAX ? QF_AHEAD_MAX : (unsigned)v);
+    }
     f->w = (QF_Worker *)calloc((size_t)p->nThreads, sizeof(QF_Worker));
     pthread_mutex_init(&f->mu, NULL);
     pthread_cond_init(&f->cvWork, NULL);
@@ -167,8 +201,7 @@ size_t QZSTD_frontCompress(QZSTD_Front *f, const void *src, size_t srcSize, void
     f->dst = (unsigned char *)dst;
     f->sizes = frameSizes;
     f->nChunks = nChunks;
-    f->nSegs = (nChunks + f->segChunks - 1) / f->segChunks;
-    f->nextSeg = 0;
+    f->nextChunk = 0;
     f->failed = 0;
     f->running = f->p.nThreads;
     f->gen++;

@@ -193,10 +193,16 @@ typedef struct {
     int numaThreadNode;            /* QZSTD_HIP_NUMA_NODE: treat every calling thread as running on this node (-1: ask the kernel) */
     int devNode[QZ_MAX_DEVICES];   /* -1 = unknown */
     unsigned int nodeNext[QZ_NUMA_NODES_MAX], anyNext; /* round-robin counters: per node, and the fallback over all GPUs */
-    int hintDirect;                /* QZSTD_HIP_HINT_DIRECT: the kernel of an announcement reads the pinned staging copy itself (no H2D copy) */
+    int hintFlags;                 /* QZSTD_HIP_HINT_FLAGS (default 1): an announcement's launch is complete when its blocks' count words are in (0: when
+                                    * the runtime says its stream is idle) */
+    int hintDirect;                /* QZSTD_HIP_HINT_DIRECT: 0 (default) an announcement's staging copy goes to device memory by a copy kernel on the
+                                    * launch's stream; 1 the match-finder reads the pinned staging copy itself; 2 that at the levels without
+                                    * chains only; 3 the copy by hipMemcpyAsync (rounds 1-3).  Batch front-end, 16 threads, 2 MiB claims, GB/s:
+                                    * level 1 21.4 / 18.5 / 18.5 / 12-14, level 3 18.6 / 15.7 (the kernel takes 0.72 ms per launch out of device
+                                    * memory, 0.96 ms over the bus; hipMemcpyAsync holds the caller 0.8-1.1 ms per 4 MiB) */
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER, 1, -1, { 0 }, { 0 }, 0, 0 };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER, 1, -1, { 0 }, { 0 }, 0, 1, 0 };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
  * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
@@ -204,11 +210,18 @@ static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DE
 #define QZ_HINT_MAX_BYTES ((size_t)16 << 20)
 #define QZ_HINT_PITCH ((size_t)16384) /* blocks with more sequences take the per-block path */
 #define QZ_HINT_PARTS 8
+#define QZ_COUNT_PENDING 0xFFFFFFFDu /* an announced block's count word until its workgroup publishes it (gProc.hintFlags) */
+#define QZ_HINTS 6
+#define QZ_IS_GUESS(k) ((k) == 2 || (k) == 3)
+#define QZ_ANNOUNCED 4
+static const int kAnnounced[QZ_ANNOUNCED] = { 0, 1, 4, 5 };
 #define QZ_CONTENT_LOOKUP_BLOCKS 256u /* announcements with more grid blocks are matched by address only */
 typedef struct {
     int st;   /* 0 none, 1 in flight on the GPU (slot held), 2 ready, 3 failed */
     int slot; /* index of the slot held while in flight */
     size_t b0, b1; /* block range [b0, b1) of the announcement */
+    size_t seen;   /* flags: every block below this one has published its count */
+    int flags;     /* completion by the blocks' count words (gProc.hintFlags), not by the stream */
 } QZSTD_Part_T;
 
 typedef struct {
@@ -254,7 +267,8 @@ typedef struct {
     unsigned int failOffloadCnt;
     /* look-ahead batches served to later callbacks (QZSTD_hintSource): two, so that the GPU can
      * work on the next buffer while libzstd entropy-codes the current one on this thread */
-    QZSTD_Hint_T hint[4]; /* [0..1] announced by the caller, [2..3] speculative (transparent look-ahead, opt-in) */
+    QZSTD_Hint_T hint[QZ_HINTS]; /* [0..1] and [4..5] announced by the caller (a ring of four: kAnnounced), [2..3] speculative (transparent
+                                  * look-ahead, opt-in) */
     int hintNext, autoNext;
     unsigned autoDepth, autoBackoff, autoFails; /* blocks to speculate on, callbacks to sit out, misses in a row */
     int autoOutstanding;                        /* a guess was launched and nothing has been served from it yet */
@@ -812,7 +826,8 @@ int QZSTD_startQatDevice(void)
         gProc.service = qzEnvInt("QZSTD_HIP_SERVICE", 1, 0, 1);
         gProc.svcItemBytes = qzEnvInt("QZSTD_HIP_SERVICE_ITEM", 4096, 4096, (int)QZSTD_HIP_BLOCK_MAX) & ~4095;
         gProc.svcSpinUs = qzEnvInt("QZSTD_HIP_SERVICE_SPIN_US", 400, 0, 1000000);
-        gProc.hintDirect = qzEnvInt("QZSTD_HIP_HINT_DIRECT", 0, 0, 1);
+        gProc.hintFlags = qzEnvInt("QZSTD_HIP_HINT_FLAGS", 1, 0, 1);
+        gProc.hintDirect = qzEnvInt("QZSTD_HIP_HINT_DIRECT", 0, 0, 3);
         {
             /* The transparent look-ahead READS memory behind the block a callback names, so it is strictly opt-in:
              * QZSTD_HIP_LOOKAHEAD = 0 / unset: off; 1: on; 2: on and always through a pipe.  It needs a fault-safe read:
@@ -925,13 +940,41 @@ void qzstd_test_set_service_epochs(unsigned int e) /* every slot's next service 
 }
 #endif
 
+/* Completion of an announcement's launch WITHOUT the runtime (round 4): every workgroup publishes its block's count word — in the
+ * announcement's pinned, coherent result area — with a system-scope release after all of its result stores (csrc/qzstd_kernels.hip,
+ * qzstd_find_sequences_kernel), and the words start out as QZ_COUNT_PENDING.  A callback waits for ITS blocks only, by reading memory.
+ * (hipStreamQuery on one of 48 streams folded onto 16 hardware queues waits for whatever was queued behind the launch it asks about:
+ * with the stream waits a worker of the batch front-end spent 30 % of its time waiting for launches that had long finished.)
+ * Blocks [b0, b1): 0 = all published, 1 = not within the time-out. */
+static int qzBlocksWait(const QZSTD_Hint_T *h, size_t b0, size_t b1)
+{
+    const unsigned long t0 = qzNowNs(), limit = (unsigned long)gProc.timeoutMs * 1000000ul;
+    size_t b = b0;
+    for (;;) {
+        unsigned long el;
+        while (b < b1 && __atomic_load_n(&h->hCount[b], __ATOMIC_ACQUIRE) != QZ_COUNT_PENDING) b++;
+        if (b >= b1) return 0;
+        el = qzNowNs() - t0;
+        if (el > limit) {
+            qzCause = QZ_CAUSE_TIMEOUT;
+            QZ_LOG(1, "announcement: block %zu still not published after %d ms\n", b, gProc.timeoutMs);
+            return 1;
+        }
+        if (el > 50000ul) { /* 50 us of polling, then naps: a waiting caller does not burn a core others could entropy-code on */
+            const struct timespec nap = { 0, el < 20000000ul ? 20000l : 200000l };
+            nanosleep(&nap, NULL);
+        }
+    }
+}
+
 /* wait for one part of an announcement and give its slot back; the part becomes ready (2) or failed (3) */
 static void qzPartFinish(QZSTD_Hint_T *h, QZSTD_Part_T *pt)
 {
     if (pt->st != 1) return;
     if (gProc.slots && pt->slot >= 0 && pt->slot < gProc.numSlots) {
         QZSTD_Slot_T *sl = &gProc.slots[pt->slot];
-        const int w = qzWait(sl->device, sl->stream);
+        const int w = pt->flags ? qzBlocksWait(h, pt->seen > pt->b0 ? pt->seen : pt->b0, pt->b1) : qzWait(sl->device, sl->stream);
+        if (w == 0) pt->seen = pt->b1;
         if (w == 1) sl->stuck = 1; /* the slot is given back, but nobody uses it before its stream has drained */
         if (w != 0 && h->nStuck < QZ_HINT_PARTS) h->stuckSlot[h->nStuck++] = pt->slot; /* ... and the kernel may still use h's buffers */
         qzReleaseSlot(pt->slot);
@@ -963,7 +1006,7 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
               "block; %lu hint(s), timers from the 9th on: drop %.2f ms, buffers %.2f ms, staging %.2f ms, queueing %.2f ms (%.2f ms of it in the copy call, %.2f in the launch call), waited %.2f ms for the GPU\n", (void *)s,
            s->servedFromBatch, s->autoServed, s->autoLaunched, s->servedSync, s->hintCalls, s->hintDropNs / 1e6, s->hintPrepNs / 1e6, s->hintStageNs / 1e6,
            s->hintQueueNs / 1e6, s->hintCopyCallNs / 1e6, s->hintLaunchCallNs / 1e6, s->hintWaitNs / 1e6);
-    for (k = 0; k < 4; k++) {
+    for (k = 0; k < QZ_HINTS; k++) {
         qzHintDrop(&s->hint[k]);
         /* the staged copies are the caller's data (for a guess: bytes it never handed over): scrubbed before the
          * pinned pages go back to the allocator */
@@ -1325,13 +1368,13 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
      * since the announcement): one memcmp per callback, a mismatch drops the announcement. */
     {
         int k, guessMissed = 0, announced = 0;
-        for (k = 0; k < 4; k++) {
+        for (k = 0; k < QZ_HINTS; k++) {
             QZSTD_Hint_T *h = &s->hint[k];
             const unsigned char *p = (const unsigned char *)src;
             size_t rel, b, e, covered = 0;
             int pi, ok = 1;
             if (h->st == 0) continue;
-            if (k < 2) announced = 1;
+            if (!QZ_IS_GUESS(k)) announced = 1;
             if (h->level != compressionLevel) continue;
             if (p >= h->base && p + srcSize <= h->base + h->size) { /* by address: the callback names announced memory */
                 rel = (size_t)(p - h->base);
@@ -1340,13 +1383,13 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 for (e = b; e < h->nb && covered < srcSize; e++) covered += h->hDesc[e].srcLen;
                 /* a GUESS must not change what the caller gets: it serves a callback only block for block (joining
                  * independently parsed grid blocks costs ratio; for announcements that is the announcer's choice) */
-                if (covered != srcSize || e - b > 8 || (k >= 2 && e - b != 1)) {
+                if (covered != srcSize || e - b > 8 || (QZ_IS_GUESS(k) && e - b != 1)) {
                     QZ_LOG(3, "look-ahead %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
                     continue;
                 }
                 if (memcmp(h->hSrc + rel, src, srcSize) != 0) {
                     /* a guess that was read before these bytes were final, or an announced buffer that was rewritten */
-                    if (k >= 2) guessMissed = 1;
+                    if (QZ_IS_GUESS(k)) guessMissed = 1;
                     else {
                         QZ_LOG(2, "announcement %d: the buffer changed after it was announced; dropped\n", k);
                         qzHintDrop(h);
@@ -1359,7 +1402,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                  * the same size, the same first and last 8 bytes and — verified — the same bytes serves such a callback
                  * just as well (the sequences depend on nothing but the block's bytes). */
                 unsigned long long key;
-                if (k >= 2 || srcSize < 16 || h->nb > QZ_CONTENT_LOOKUP_BLOCKS || !h->keys) continue;
+                if (QZ_IS_GUESS(k) || srcSize < 16 || h->nb > QZ_CONTENT_LOOKUP_BLOCKS || !h->keys) continue;
                 key = qzBlockKey((const unsigned char *)src, srcSize);
                 for (b = 0; b < h->nb; b++)
                     if (h->keys[b] == key && h->hDesc[b].srcLen == srcSize && memcmp(h->hSrc + b * h->block, src, srcSize) == 0) break;
@@ -1371,6 +1414,21 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
             for (pi = 0; pi < h->nParts; pi++) {
                 QZSTD_Part_T *pt = &h->part[pi];
                 if (pt->b1 <= b || pt->b0 >= e) continue;
+                if (pt->st == 1 && pt->flags) {
+                    /* this callback's blocks only; the slot goes back once the part's last block is in */
+                    const size_t w0b = b > pt->b0 ? b : pt->b0, w1b = e < pt->b1 ? e : pt->b1;
+                    const unsigned long w0 = qzNowNs();
+                    if (qzBlocksWait(h, w0b, w1b) != 0) {
+                        qzPartFinish(h, pt); /* (times out again at once: the same block is still pending) -> failed, slot quarantined */
+                    } else {
+                        if (pt->seen < pt->b0) pt->seen = pt->b0;
+                        while (pt->seen < pt->b1 && __atomic_load_n(&h->hCount[pt->seen], __ATOMIC_ACQUIRE) != QZ_COUNT_PENDING) pt->seen++;
+                        if (pt->seen >= pt->b1) qzPartFinish(h, pt);
+                    }
+                    s->hintWaitNs += qzNowNs() - w0;
+                    if (pt->st == 3) ok = 0;
+                    continue;
+                }
                 if (pt->st == 1) {
                     const unsigned long w0 = qzNowNs();
                     qzPartFinish(h, pt);
@@ -1407,7 +1465,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                     s->servedFromBatch++;
                     h->touched = 1;
                     h->misses = 0;
-                    if (k >= 2) {
+                    if (QZ_IS_GUESS(k)) {
                         s->autoServed++;
                         s->autoFails = 0;
                         s->autoOutstanding = 0;
@@ -1431,14 +1489,16 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
         }
         /* nothing to serve from.  Announcements the caller has walked away from (used, then missed again and again)
          * are dropped, so that they neither serve stale positions nor keep the state from guessing */
-        for (k = 0; k < 2; k++) {
+        announced = 0;
+        for (k = 0; k < QZ_HINTS; k++) {
             QZSTD_Hint_T *h = &s->hint[k];
+            if (QZ_IS_GUESS(k)) continue;
             if (h->st != 0 && h->touched && ++h->misses > QZ_HINT_STALE_MISSES) {
                 QZ_LOG(2, "announcement %d: abandoned by the caller; dropped\n", k);
                 qzHintDrop(h);
             }
         }
-        announced = s->hint[0].st != 0 || s->hint[1].st != 0;
+        for (k = 0; k < QZ_ANNOUNCED; k++) announced = announced || s->hint[kAnnounced[k]].st != 0;
         QZ_LOG(3, "miss: %p + %zu (guesses: %d %p+%zu, %d %p+%zu) outstanding %d backoff %u depth %u\n", src, srcSize, s->hint[2].st,
                (const void *)s->hint[2].base, s->hint[2].size, s->hint[3].st, (const void *)s->hint[3].base, s->hint[3].size,
                s->autoOutstanding, s->autoBackoff, s->autoDepth);
@@ -1476,16 +1536,18 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
 /* ---------------------------------------------------------------- look-ahead ----- */
 
 /* grow-only buffers: returns the (possibly new) pointer, NULL on failure */
-static void *qzGrowHost(void *old, size_t *cap, size_t need, int dev)
+static void *qzGrowHostC(void *old, size_t *cap, size_t need, int dev, int coherent)
 {
     void *p;
     if (old && *cap >= need) return old;
     if (old) memset(old, 0, *cap); /* staged caller data: scrubbed before the pages go back */
     qzstd_hip_host_free(old);
-    p = qzHostAlloc(need, dev, 0); /* next to the state's own GPU (the first of the GPUs an announcement is split across) */
+    p = qzHostAlloc(need, dev, coherent); /* next to the state's own GPU (the first of the GPUs an announcement is split across) */
     *cap = p ? need : 0;
     return p;
 }
+
+static void *qzGrowHost(void *old, size_t *cap, size_t need, int dev) { return qzGrowHostC(old, cap, need, dev, 0); }
 
 static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need)
 {
@@ -1621,14 +1683,14 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
     const size_t o0 = b0 * h->block;
     const size_t bytes = ((b1 * h->block < h->size ? b1 * h->block : h->size) - o0 + 63) & ~(size_t)63;
     size_t b;
-    int i, tries;
+    int i, tries, direct = 0;
     pt->st = 0;
     for (tries = 0; ; tries++) {
         i = qzTryGrabSlot(s->slotHint + tries * gProc.numDevices, dev);
         if (i < 0 && mayWait) {
             /* every slot is busy: give back what this state still holds, then wait for one */
             int k, j;
-            for (k = 0; k < 4; k++)
+            for (k = 0; k < QZ_HINTS; k++)
                 for (j = 0; j < s->hint[k].nParts; j++)
                     if (&s->hint[k] != h) qzPartFinish(&s->hint[k], &s->hint[k].part[j]);
             i = qzGrabSlot(s->slotHint, dev);
@@ -1641,31 +1703,33 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
     }
     if (dev < 0) s->slotHint = i;
     if (qzSetupSlot(sl, 0) != QZSTD_OK) goto fail;
-    if (!gProc.hintDirect) {
-        sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, bytes);
-        if (!sl->dBatchSrc) goto fail;
-    }
     {
         const size_t work = qzstd_hip_workspace_bytes(level, (unsigned int)(b1 - b0), (unsigned int)h->block);
         if (work) sl->dBatchWork = qzGrowDev(sl->device, sl->dBatchWork, &sl->dBatchWorkCap, work);
         if (work && !sl->dBatchWork) goto fail;
+        /* (A/B switch, see hintDirect) */
+        direct = h->dvSrc != NULL && (gProc.hintDirect == 1 || (gProc.hintDirect == 2 && work == 0));
     }
-    for (b = b0; b < b1; b++) h->hDesc[b].srcOff = b * h->block - o0; /* relative to this part's device buffer */
-    /* everything below is queued on the slot's stream and returns immediately */
-    if (!gProc.hintDirect) {
+    if (!direct) {
+        sl->dBatchSrc = (unsigned char *)qzGrowDev(sl->device, sl->dBatchSrc, &sl->dBatchSrcCap, bytes);
+        if (!sl->dBatchSrc) goto fail;
+    }
+    for (b = b0; b < b1; b++) h->hDesc[b].srcOff = b * h->block - o0; /* relative to this part's first byte */
+    /* everything below is queued on the slot's stream */
+    if (!direct) {
         const unsigned long t0 = qzNowNs();
-        const int rc = qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc + o0, bytes);
+        /* the staging copy goes to device memory by a copy kernel on the stream (qzstd_hip_copy_in says why not by the runtime's copy) */
+        const int rc = h->dvSrc && gProc.hintDirect != 3 ? qzstd_hip_copy_in(sl->device, sl->stream, sl->dBatchSrc, (const unsigned char *)h->dvSrc + o0, bytes)
+                                                         : qzstd_hip_memcpy_h2d(sl->device, sl->stream, sl->dBatchSrc, h->hSrc + o0, bytes);
         s->hintCopyCallNs += qzNowNs() - t0;
         if (rc) { if (qzWait(sl->device, sl->stream) == 1) sl->stuck = 1; goto fail; }
     }
     {
-        const unsigned char *dsrc = gProc.hintDirect ? (const unsigned char *)h->dvSrc : sl->dBatchSrc;
+        const unsigned char *dsrc = direct ? (const unsigned char *)h->dvSrc + o0 : sl->dBatchSrc;
         const unsigned long t0 = qzNowNs();
-        int rc = dsrc == NULL;
-        if (!rc)
-            rc = qzstd_hip_find_sequences(sl->device, sl->stream, level, gProc.hintDirect ? dsrc + o0 : dsrc, (const qzstd_hip_block_t *)h->dvDesc + b0,
-                                          (unsigned int)(b1 - b0), (unsigned int)h->block, h->dvSeqs, (unsigned int *)h->dvCount + b0,
-                                          sl->dBatchWork, sl->dBatchWorkCap);
+        const int rc = qzstd_hip_find_sequences(sl->device, sl->stream, level, dsrc, (const qzstd_hip_block_t *)h->dvDesc + b0,
+                                                (unsigned int)(b1 - b0), (unsigned int)h->block, h->dvSeqs, (unsigned int *)h->dvCount + b0,
+                                                sl->dBatchWork, sl->dBatchWorkCap);
         s->hintLaunchCallNs += qzNowNs() - t0;
         if (rc) {
             if (qzWait(sl->device, sl->stream) == 1) sl->stuck = 1;
@@ -1677,8 +1741,11 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
     pt->slot = i;
     pt->b0 = b0;
     pt->b1 = b1;
+    pt->seen = b0;
+    pt->flags = gProc.hintFlags;
     return 0;
 fail:
+    for (b = b0; b < b1; b++) h->hCount[b] = QZSTD_HIP_NSEQ_ERROR; /* never launched: nothing will publish these */
     QZ_LOG(1, "look-ahead not taken: %s\n", qzstd_hip_last_error());
     qzReleaseSlot(i);
     return -1;
@@ -1711,14 +1778,14 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     tp = qzNowNs();
     h->hSrc = (unsigned char *)qzGrowHost(h->hSrc, &h->hSrcCap, srcBytes, firstDev);
     h->hDesc = (qzstd_hip_block_t *)qzGrowHost(h->hDesc, &h->hDescCap, blocksBytes, firstDev);
-    h->hCount = (unsigned int *)qzGrowHost(h->hCount, &h->hCountCap, nb * sizeof(unsigned int), firstDev);
-    h->hSeqs = (ZSTD_Sequence *)qzGrowHost(h->hSeqs, &h->hSeqsCap, nb * h->pitch * sizeof(ZSTD_Sequence), firstDev);
+    h->hCount = (unsigned int *)qzGrowHostC(h->hCount, &h->hCountCap, nb * sizeof(unsigned int), firstDev, gProc.hintFlags);
+    h->hSeqs = (ZSTD_Sequence *)qzGrowHostC(h->hSeqs, &h->hSeqsCap, nb * h->pitch * sizeof(ZSTD_Sequence), firstDev, gProc.hintFlags);
     if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs) return 0;
     if (h->dvOf[0] != h->hDesc || !h->dvDesc) { h->dvDesc = qzstd_hip_host_device_ptr(h->hDesc); h->dvOf[0] = h->hDesc; }
     if (h->dvOf[1] != h->hCount || !h->dvCount) { h->dvCount = qzstd_hip_host_device_ptr(h->hCount); h->dvOf[1] = h->hCount; }
     if (h->dvOf[2] != h->hSeqs || !h->dvSeqs) { h->dvSeqs = qzstd_hip_host_device_ptr(h->hSeqs); h->dvOf[2] = h->hSeqs; }
-    if (gProc.hintDirect && (h->dvOf[3] != h->hSrc || !h->dvSrc)) { h->dvSrc = qzstd_hip_host_device_ptr(h->hSrc); h->dvOf[3] = h->hSrc; }
-    if (!h->dvDesc || !h->dvCount || !h->dvSeqs || (gProc.hintDirect && !h->dvSrc)) return 0;
+    if (h->dvOf[3] != h->hSrc || !h->dvSrc) { h->dvSrc = qzstd_hip_host_device_ptr(h->hSrc); h->dvOf[3] = h->hSrc; }
+    if (!h->dvDesc || !h->dvCount || !h->dvSeqs) return 0;
     s->hintPrepNs += qzNowNs() - tp;
 
     tq = qzNowNs();
@@ -1757,7 +1824,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
             h->hDesc[b].seqCap = (unsigned int)h->pitch;
             h->hDesc[b].parseFrom = 0;
             h->hDesc[b].mark = 0;
-            h->hCount[b] = QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
+            h->hCount[b] = gProc.hintFlags ? QZ_COUNT_PENDING : QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
             if (!speculative && h->keys && nb <= h->keysCap && nb <= QZ_CONTENT_LOOKUP_BLOCKS)
                 h->keys[b] = h->hDesc[b].srcLen >= 16 ? qzBlockKey(h->hSrc + o, h->hDesc[b].srcLen) : 0ull;
         }
@@ -1798,8 +1865,8 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
         return -1;
     if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) return -1;
     if (!qzDeviceUsable(s)) return -1;
-    h = &s->hint[s->hintNext];
-    s->hintNext ^= 1;
+    h = &s->hint[kAnnounced[s->hintNext]]; /* the oldest of the four */
+    s->hintNext = (s->hintNext + 1) % QZ_ANNOUNCED;
     if (qzAnnounce(s, h, src, srcSize, blockSize, compressionLevel, 0) == 0) return -1;
     for (k = 0; k < h->nParts; k++) inflight += h->part[k].st == 1;
     if (!inflight) { /* nothing could be queued */

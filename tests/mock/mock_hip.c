@@ -87,6 +87,7 @@ int qzstd_hip_stream_wait(int device, void *s, unsigned timeoutMs)
     return 0;
 }
 int qzstd_hip_memcpy_h2d(int device, void *s, void *dst, const void *src, size_t n) { (void)device; (void)s; memcpy(dst, src, n); return 0; }
+int qzstd_hip_copy_in(int device, void *s, void *dst, const void *src, size_t n) { (void)device; (void)s; if (n & 15) return -1; memcpy(dst, src, n); return 0; }
 int qzstd_hip_memcpy_d2h(int device, void *s, void *dst, const void *src, size_t n) { (void)device; (void)s; memcpy(dst, src, n); return 0; }
 int qzstd_hip_memset(int device, void *s, void *dst, int v, size_t n) { (void)device; (void)s; memset(dst, v, n); return 0; }
 int qzstd_hip_memcpy2d_d2h(int device, void *s, void *dst, size_t dp, const void *src, size_t sp, size_t w, size_t h)
@@ -198,7 +199,9 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         const qzstd_hip_block_t *k = &d_blocks[b];
         const size_t n = qzo_find_sequences_from(&pf, (const uint8_t *)d_src + k->srcOff, k->srcLen, k->parseFrom,
                                                  (qzo_seq_t *)d_seqs + k->seqOff, k->seqCap);
-        d_nseq[b] = n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n;
+        /* a stalled "GPU" (qzstd_mock_stall_ms) never publishes: the count words keep what the host put there (announcements poll them) */
+        if (nowNs() < gStallUntilNs) continue;
+        __atomic_store_n(&d_nseq[b], n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n, __ATOMIC_RELEASE);
     }
     return 0;
 }

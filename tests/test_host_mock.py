@@ -708,13 +708,13 @@ def test_timed_out_announcement_parks_its_buffers(mock, zstd, oracle):
     with restarted(mock, QZSTD_HIP_TIMEOUT_MS="30"):
         before = L.qzstd_test_orphans()
         st = L.QZSTD_createSeqProdState()
+        L.qzstd_mock_stall_ms(300)  # (before the announcement: a stalled launch never publishes its blocks' count words)
         assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) == 0
-        L.qzstd_mock_stall_ms(300)
         seqs = (B.Sequence * B.sequence_bound(chunk))()
         assert L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 3, 1 << 17) == B.SEQ_ERROR  # the part times out, the launch path too
-        # a state holds two announcements: the second call from here reuses — drops — the one whose part timed out
-        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) in (0, -1)
-        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) in (0, -1)
+        # a state holds four announcements (round 4; two before): the fourth call from here reuses - drops - the one whose part timed out
+        for _ in range(4):
+            assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) in (0, -1)
         assert L.qzstd_test_orphans() == before + 1  # its buffers are parked, not reused
         L.qzstd_mock_stall_ms(0)
         time.sleep(0.35)
@@ -748,7 +748,9 @@ def test_multi_gpu_product_leg_over_four_mock_devices(mock, zstd, tmp_path):
         counts = [int(x.split()[1].split("/")[0]) for x in per.split(",")]
         assert len(counts) == 4 and sum(counts) == 2 * 64, per  # two passes (one warms up) of 64 blocks, all announced
         if split == 4:
-            assert all(c == 32 for c in counts), per  # every announcement of 16 blocks: four blocks per GPU
+            # every announcement of 8 blocks or more is cut into block ranges over the GPUs (claims differ in size since round 4: small first,
+            # small last), the few 4-block ones stay on their state's GPU: every GPU gets about a quarter
+            assert all(20 <= c <= 44 for c in counts), per
         else:
             assert all(c > 0 for c in counts), per    # whole announcements per GPU, four states round-robin
 

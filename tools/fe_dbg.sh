@@ -7,17 +7,20 @@ open("/tmp/fe.bin","wb").write(d); open("/tmp/fe2.bin","wb").write(d + d)
 PY
 make -s -C qat-zstd-plugin_amd >/dev/null 2>&1; make -s -C qat-zstd-plugin_amd/test frontbench >/dev/null 2>&1
 FB=qat-zstd-plugin_amd/test/frontbench
-run() { echo "== seg ${SEG:-4} ${BUF:-} $*"; env "$@" QZSTD_HIP_DEBUG=2 $FB -t${T:-16} -l10 -c131072 -L1 -s${SEG:-4} -m1 ${BUF:-/tmp/fe.bin} 2>&1 | grep -o "median [0-9.]* min [0-9.]* max [0-9.]*\|[0-9]* hint(s): .*\|PASS\|FAIL" | sort | uniq -c | sort -rn | head -${ROWS:-4}; }
-run A=0
-run QZSTD_HIP_HINT_DIRECT=1
+run() { echo "== seg ${SEG:-4} threads ${T:-16} L${LV:-1} ${BUF:-} $*"; env "$@" QZSTD_HIP_DEBUG=2 $FB -t${T:-16} -l${LOOPS:-10} -c131072 -L${LV:-1} -s${SEG:-4} -m1 ${BUF:-/tmp/fe.bin} 2>&1 | grep -o "median [0-9.]* min [0-9.]* max [0-9.]*\|[0-9]* hint(s), .*\|PASS\|FAIL\|[0-9]* block(s) from announcements, [0-9]* per block\|roducer errors: [0-9]*" | sort | uniq -c | sort -rn | head -${ROWS:-5}; }
+if [ $# -gt 0 ]; then for CFG in "$@"; do eval "$CFG"; done; exit 0; fi
+SEG=2 run QZSTD_FRONT_AHEAD=2
+SEG=2 run QZSTD_FRONT_AHEAD=2 QZSTD_HIP_HINT_DIRECT=0
+SEG=2 run QZSTD_FRONT_AHEAD=2 QZSTD_HIP_HINT_FLAGS=0
+SEG=2 run QZSTD_FRONT_AHEAD=2 QZSTD_HIP_HINT_FLAGS=0 QZSTD_HIP_HINT_DIRECT=0
 ROWS=3
-run GPU_MAX_HW_QUEUES=16
-run GPU_MAX_HW_QUEUES=16 QZSTD_HIP_HINT_DIRECT=1
-SEG=2 run GPU_MAX_HW_QUEUES=16 QZSTD_HIP_HINT_DIRECT=1
-SEG=1 run GPU_MAX_HW_QUEUES=16 QZSTD_HIP_HINT_DIRECT=1
-ROWS=2
-SEG=8 run GPU_MAX_HW_QUEUES=16 QZSTD_HIP_HINT_DIRECT=1
-T=18 run GPU_MAX_HW_QUEUES=16 QZSTD_HIP_HINT_DIRECT=1
-BUF=/tmp/fe2.bin SEG=2 run GPU_MAX_HW_QUEUES=16 QZSTD_HIP_HINT_DIRECT=1
-BUF=/tmp/fe2.bin SEG=4 run GPU_MAX_HW_QUEUES=16 QZSTD_HIP_HINT_DIRECT=1
-BUF=/tmp/fe2.bin SEG=4 run GPU_MAX_HW_QUEUES=16
+SEG=4 run QZSTD_FRONT_AHEAD=1
+SEG=4 run QZSTD_FRONT_AHEAD=2
+SEG=4 run QZSTD_FRONT_AHEAD=2 QZSTD_HIP_HINT_DIRECT=0
+SEG=1 run QZSTD_FRONT_AHEAD=3
+SEG=1 run QZSTD_FRONT_AHEAD=3 QZSTD_HIP_HINT_DIRECT=0
+SEG=2 T=18 run QZSTD_FRONT_AHEAD=2
+BUF=/tmp/fe2.bin SEG=2 run QZSTD_FRONT_AHEAD=2
+LV=3 SEG=2 run QZSTD_FRONT_AHEAD=2
+LV=3 SEG=2 run QZSTD_FRONT_AHEAD=2 QZSTD_HIP_HINT_DIRECT=0
+LV=6 SEG=2 LOOPS=3 run QZSTD_FRONT_AHEAD=2
