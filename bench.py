@@ -4,7 +4,7 @@
 `value` (since round 4; rounds 1-3 reported the resident-input kernel rate here, which the judge rejected as "not the metric")
 = what BASELINE.json's metric literally names: INPUT MB/s THROUGH ZSTD_compress2 with qatSequenceProducer registered, level 1,
 one frame per 128 KiB chunk (the framing of /root/reference/test/benchmark.c:300-321, timing shape :305-319,:374-382).  A "step"
-is one pass of ONE buffer of --e2e-blocks chunks (default 4096 x 128 KiB = 512 MiB per GPU) through the batch front-end
+is one pass of ONE buffer of --e2e-blocks chunks (default 8192 x 128 KiB = 1 GiB per GPU: BASELINE configs[1]) through the batch front-end
 (include/qzstd_frontend.h: a pool of CCtx threads, one per usable host core, every 2 MiB segment announced one claim ahead, the
 GPU match-finds while the threads entropy-code), called IN THIS PROCESS through its C ABI.  W untimed warm-up passes, then exactly
 K passes between barrier + synchronize brackets, MAX over ranks; `value` = chunks' bytes of all ranks x K / that time.  One
@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / end-to-end legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-seconds", type=float, default=5.5, help="continuous load per first-class end-to-end side leg")
-    ap.add_argument("--e2e-blocks", type=int, default=4096, help="chunks per GPU per step of the timed ZSTD_compress2 leg (4096 x 128 KiB = 512 MiB)")
+    ap.add_argument("--e2e-blocks", type=int, default=8192, help="chunks per GPU per step of the timed ZSTD_compress2 leg (8192 x 128 KiB = 1 GiB: BASELINE configs[1])")
     ap.add_argument("--e2e-threads", type=int, default=0, help="front-end worker threads per rank (0 = the rank's share of the usable host cores + an eighth)")
     ap.add_argument("--kernel-only", action="store_true", help="only the roofline leg (K timed launches of the dominant kernel, resident input): what "
                     "tools/prof_stats.sh / prof_pmc.sh run under rocprofv3, so that the profile holds these launches and no others")
@@ -506,6 +506,9 @@ def main():
         print(json.dumps(product_multi_gpu_leg(plug, data, a.block, a.level, a.product_multi_gpu)))
         return
     visible_before = narrow_to_own_gpu(world, local)
+    # the plugin asks for 16 hardware queues when it makes the process's first HIP call (csrc/qzstd_kernels.hip, probe_devices: launches of
+    # different streams that share a queue run one after the other); here torch starts HIP first, so the variable is set for it
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("QZSTD_HIP_HW_QUEUES") or "16")
     import torch
     import torch.distributed as dist
 
@@ -593,9 +596,9 @@ def main():
         return
     # ---- THE METRIC: input MB/s through ZSTD_compress2, plugin registered (module docstring); exactly a.steps timed passes
     ncpu, quota = host_cpu_budget()
-    # threads per rank: the rank's share of the usable cores + an eighth — a worker that announces a segment sits in the HIP runtime's locks for a
-    # moment (copy + launch) and leaves its core idle; two more threads than cores fill those gaps (tools/fe_threads.sh on a 16-core box: 16 threads
-    # 3.87-3.93 GB/s, 18: 4.30-4.32, 20: 4.25-4.37 with a wider spread, 22 and more: the cgroup's CPU quota throttles, 3.5 and falling)
+    # threads per rank: the rank's share of the usable cores + an eighth — a worker that waits for the GPU's first results of a pass or naps in a
+    # poll leaves its core idle; two more threads than cores fill those gaps (tools/fe_dbg.sh on a 16-core box, 2 MiB claims, two announced ahead:
+    # 14 threads 14.9 GB/s, 16: 20.7, 18: 22.3, 20: 22.1, 24: 22.5)
     share = max(1.0, quota / world)
     e2e_threads = a.e2e_threads if a.e2e_threads > 0 else max(1, min(int(share + share / 8.0), 128))
     e2e_nb = max(1, min(a.e2e_blocks, nb))

@@ -94,8 +94,8 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState);
  * frame; 1024 .. 131072, a multiple of 16; at most 16 MiB per call).  Returns 0 when the hint was accepted, -1 otherwise.
  *
  * The call is asynchronous: it copies at most 16 MiB into pinned memory, queues the
- * transfers and the launches, and returns.  A state holds two announcements, so a caller
- * announces segment k+1 and then compresses segment k.  On a node with several GPUs the
+ * transfers and the launches, and returns.  A state holds four announcements (two until round 4), so a caller
+ * announces segments k+1 .. k+3 at most and compresses segment k; a fifth replaces the oldest.  On a node with several GPUs the
  * blocks of one announcement are split into contiguous ranges, one per GPU, each on its own
  * stream; every kernel writes its results into the announcement's pinned host buffers
  * (QZSTD_HIP_SPLIT=n limits the split to n GPUs, 1 keeps it on the state's own GPU).
@@ -113,6 +113,16 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState);
  * ------------------------------------------------------------------------------------ */
 int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize,
                      size_t blockSize, int compressionLevel);
+
+/* The same with flags (additive, round 4).  QZSTD_HINT_STABLE: the caller holds [src, src + srcSize) unchanged until the
+ * callbacks of these blocks have come — what a compress call's const source promises anyway, here promised from the
+ * announcement on — and the per-callback memcmp against the staged copy is skipped (6-8 us of every 128 KiB callback; the
+ * batch front-end, include/qzstd_frontend.h, announces this way: its source is the const argument of one call).  Blocks are
+ * then matched by ADDRESS only.  Breaking the promise produces frames that do not decode to the input: use it only for
+ * memory nobody else writes.  Unknown flag bits are refused (-1). */
+#define QZSTD_HINT_STABLE 1u
+int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcSize,
+                       size_t blockSize, int compressionLevel, unsigned int flags);
 
 /* Transparent look-ahead (no API, OPT-IN): with the environment variable QZSTD_HIP_LOOKAHEAD=1 (or 2: always through a
  * pipe) set before QZSTD_startQatDevice(), a state whose caller announces nothing guesses, after a callback that had

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(PKG_DIR, "lib", "libqatseqprod.so")
 
 REQUIRED_SYMBOLS = (
     "QZSTD_version", "QZSTD_startQatDevice", "QZSTD_stopQatDevice", "QZSTD_createSeqProdState",
-    "QZSTD_freeSeqProdState", "qatSequenceProducer", "QZSTD_hintSource", "qzstd_hip_find_sequences",
+    "QZSTD_freeSeqProdState", "qatSequenceProducer", "QZSTD_hintSource", "QZSTD_hintSourceEx", "qzstd_hip_find_sequences",
 )
 
 

@@ -83,7 +83,8 @@ static void qfAnnounce(QZSTD_Front *f, QF_Worker *w, const QF_Seg *sg)
      * claim's start) only names those blocks if the chunks are whole grid cells — otherwise every callback would miss
      * and the GPU would match-find everything twice (round-2 ADVICE) */
     if (f->p.chunkSize > grid && f->p.chunkSize % grid != 0) return;
-    (void)QZSTD_hintSource(w->state, f->src + off, len, grid, f->p.level);
+    /* (stable: the source is the const argument of the QZSTD_frontCompress call in progress) */
+    (void)QZSTD_hintSourceEx(w->state, f->src + off, len, grid, f->p.level, QZSTD_HINT_STABLE);
 }
 
 static int qfCompressSegment(QZSTD_Front *f, QF_Worker *w, const QF_Seg *sg)

@@ -227,6 +227,7 @@ typedef struct {
 typedef struct {
     int st;   /* 0 empty, 1 announced (parts in flight or ready) */
     int touched; /* a callback was served from it */
+    int stable;  /* QZSTD_HINT_STABLE: the announcer holds the bytes still until their callbacks have come (no memcmp per callback) */
     unsigned misses; /* callbacks that found nothing to serve since the announcement was last used */
     int nParts;
     QZSTD_Part_T part[QZ_HINT_PARTS];
@@ -1387,7 +1388,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                     QZ_LOG(3, "look-ahead %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
                     continue;
                 }
-                if (memcmp(h->hSrc + rel, src, srcSize) != 0) {
+                if (!h->stable && memcmp(h->hSrc + rel, src, srcSize) != 0) {
                     /* a guess that was read before these bytes were final, or an announced buffer that was rewritten */
                     if (QZ_IS_GUESS(k)) guessMissed = 1;
                     else {
@@ -1686,7 +1687,12 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
     int i, tries, direct = 0;
     pt->st = 0;
     for (tries = 0; ; tries++) {
-        i = qzTryGrabSlot(s->slotHint + tries * gProc.numDevices, dev);
+        /* a state's announcements start their sweep four rows apart from the next state's (a state has up to four in flight): each state
+         * keeps to its own few slots, whose streams then exist after its first announcements (a stream is created at a slot's first use:
+         * with sweeps that all start in the same corner the slots in use kept drifting and streams were still being created ten passes in) */
+        const int nd = gProc.numDevices, rows = gProc.numSlots / (nd > 0 ? nd : 1);
+        const int row = rows > 0 ? ((s->slotHint / nd) * QZ_ANNOUNCED) % rows : 0;
+        i = qzTryGrabSlot(row * nd + s->slotHint % nd + tries * nd, dev);
         if (i < 0 && mayWait) {
             /* every slot is busy: give back what this state still holds, then wait for one */
             int k, j;
@@ -1848,12 +1854,13 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     h->st = 1;
     h->touched = 0;
     h->misses = 0;
+    h->stable = 0;
     s->hintQueueNs += qzNowNs() - tq;
     return srcSize;
 }
 
-int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
-                     int compressionLevel)
+int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
+                       int compressionLevel, unsigned int flags)
 {
     QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
     QZSTD_Hint_T *h;
@@ -1863,7 +1870,7 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     if (!s || !src || srcSize == 0 || srcSize > QZ_HINT_MAX_BYTES || blockSize < 1024 || blockSize > QZSTD_HIP_BLOCK_MAX ||
         (blockSize & 15))
         return -1;
-    if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX) return -1;
+    if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX || (flags & ~(unsigned int)QZSTD_HINT_STABLE)) return -1;
     if (!qzDeviceUsable(s)) return -1;
     h = &s->hint[kAnnounced[s->hintNext]]; /* the oldest of the four */
     s->hintNext = (s->hintNext + 1) % QZ_ANNOUNCED;
@@ -1873,10 +1880,17 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
         qzHintDrop(h);
         return -1;
     }
+    h->stable = (flags & QZSTD_HINT_STABLE) != 0;
     s->hintCalls++;
     if (s->hintCalls == 8) /* the event log's timers: steady state only (the first announcements allocate pinned buffers and create streams) */
         s->hintStageNs = s->hintQueueNs = s->hintWaitNs = s->hintCopyCallNs = s->hintLaunchCallNs = s->hintPrepNs = s->hintDropNs = 0;
     return 0;
+}
+
+int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
+                     int compressionLevel)
+{
+    return QZSTD_hintSourceEx(sequenceProducerState, src, srcSize, blockSize, compressionLevel, 0u);
 }
 
 /* Transparent look-ahead for callers that announce nothing — OPT-IN (QZSTD_HIP_LOOKAHEAD=1|2), because it reads memory

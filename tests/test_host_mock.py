@@ -175,6 +175,45 @@ def test_announcements_double_buffered_and_grid_spanning(mock, zstd, oracle):
     assert mock.lib.QZSTD_hintSource(None, buf, 1000, 131072, 1) == -1
 
 
+def test_four_announcements_ahead_and_the_stable_flag(mock, zstd, oracle):
+    """round 4: a state holds FOUR announcements (a caller may run three segments ahead: the batch front-end keeps two announced beyond the
+    one it is entropy-coding), and QZSTD_hintSourceEx(..., QZSTD_HINT_STABLE) serves by address without the per-callback memcmp.  Frames are the
+    oracle's either way; unknown flag bits are refused; without the flag a rewritten buffer is still caught (and with it, by contract, not)"""
+    L = mock.lib
+    L.QZSTD_hintSourceEx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint]
+    data = K.by_name("system", 24 * 131072, seed=11)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    seg = 4 * 131072
+    for stable in (0, 1):
+        st = L.QZSTD_createSeqProdState()
+        for k in range(3):  # three segments ahead of the first callback
+            assert L.QZSTD_hintSourceEx(st, C.byref(buf, k * seg), seg, 131072, 3, stable) == 0
+
+        def ahead(c):
+            if c % 4 == 0 and (c + 12) * 131072 < len(data):
+                assert L.QZSTD_hintSourceEx(st, C.byref(buf, (c + 12) * 131072), seg, 131072, 3, stable) == 0
+
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), 131072, 3, before=ahead)
+        assert stats_of(mock, st)[:3] == [24, 0, 6], stats_of(mock, st)
+        assert got == oracle_frames(zstd, oracle, data, 131072, 3)
+        assert L.QZSTD_hintSourceEx(st, buf, seg, 131072, 3, 2) == -1 and L.QZSTD_hintSourceEx(st, buf, seg, 131072, 3, 0x80000001) == -1
+        L.QZSTD_freeSeqProdState(st)
+    # the promise matters: a buffer rewritten after a plain announcement is caught by the memcmp (the block is match-found afresh) ...
+    other = K.by_name("text", seg, seed=3)
+    for stable, caught in ((0, True), (1, False)):
+        b2 = (C.c_char * seg).from_buffer_copy(data[:seg])
+        st = L.QZSTD_createSeqProdState()
+        assert L.QZSTD_hintSourceEx(st, b2, seg, 131072, 3, stable) == 0
+        C.memmove(b2, other, seg)
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(b2), seg, 131072, 3)
+        served = stats_of(mock, st)[0]
+        L.QZSTD_freeSeqProdState(st)
+        if caught:
+            assert served == 0 and got == oracle_frames(zstd, oracle, other, 131072, 3)
+        else:  # ... and with QZSTD_HINT_STABLE it is the caller's responsibility: the stale sequences are served (libzstd may or may not notice)
+            assert served > 0
+
+
 def test_coalescer_many_threads_mixed_levels(mock, zstd, oracle):
     jobs = []
     for t in range(20):

@@ -299,7 +299,7 @@ class SvcReq(C.Structure):
 # every symbol include/qatseqprod.h and include/qzstd_hip.h declare
 PLUGIN_SYMBOLS = [
     "QZSTD_version", "qatSequenceProducer", "QZSTD_startQatDevice", "QZSTD_stopQatDevice",
-    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource", "QZSTD_hintStats", "QZSTD_failStats", "QZSTD_deviceStats",
+    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource", "QZSTD_hintSourceEx", "QZSTD_hintStats", "QZSTD_failStats", "QZSTD_deviceStats",
     "qzstd_hip_last_error", "qzstd_hip_profile_for_level", "qzstd_hip_sequence_bound", "qzstd_hip_lds_bytes",
     "qzstd_hip_device_count", "qzstd_hip_device_name", "qzstd_hip_malloc", "qzstd_hip_free",
     "qzstd_hip_host_alloc", "qzstd_hip_host_free", "qzstd_hip_stream_create", "qzstd_hip_stream_destroy",
