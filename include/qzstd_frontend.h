@@ -8,10 +8,13 @@
  * entropy stage and by whether the GPU works AHEAD of them.  This front-end packages exactly that:
  *
  *   - a persistent pool of worker threads, each with its own ZSTD_CCtx and its own QZSTD_createSeqProdState();
- *   - the input is cut into chunks (each chunk its own frame — the reference benchmark's framing, :300-321) and the
- *     chunks into segments; workers claim segments from a shared counter, announce every segment one claim ahead with
- *     QZSTD_hintSource() (two announcements per state: the GPUs match-find segment k+1 while the worker entropy-codes
- *     segment k; on a multi-GPU node an announcement is split across the GPUs), then call ZSTD_compress2 per chunk;
+ *   - the input is cut into chunks (each chunk its own frame — the reference benchmark's framing, :300-321); workers claim
+ *     runs of chunks from a shared cursor and keep two claims (three at the chain levels; QZSTD_FRONT_AHEAD=1..3) announced beyond
+ *     the one they are entropy-coding, with QZSTD_hintSourceEx(..., QZSTD_HINT_STABLE) — the source is the const argument of the
+ *     call in progress — so the GPUs match-find ahead of every worker (a state holds four announcements; on a multi-GPU node an
+ *     announcement is split across the GPUs); then ZSTD_compress2 per chunk.  Claims are at most segmentBytes; where the entropy
+ *     stage sets the pace (levels 1-4) a worker's first claims and the job's last ones are smaller, so that the first results
+ *     come back early and the workers finish together (QZSTD_FRONT_UNIFORM=0|1 overrides the choice by level);
  *   - frames land at fixed strides in the destination (frame c at dst + c * QZSTD_frontFrameStride()), sizes in
  *     frameSizes[c]; QZSTD_frontCompact() packs them back to back.
  *
@@ -32,7 +35,7 @@ typedef struct {
     int nThreads;        /* worker threads (>= 1) */
     int level;           /* 1..12 */
     size_t chunkSize;    /* bytes per frame, > 0 */
-    size_t segmentBytes; /* bytes announced at a time, rounded to whole chunks, <= 16 MiB (0 = 2 MiB) */
+    size_t segmentBytes; /* bytes announced at a time at most, rounded to whole chunks, <= 16 MiB (0 = 2 MiB at levels 1-4, 4 MiB at levels 5-12) */
     int extRepcodes;     /* ZSTD_c_searchForExternalRepcodes: 0 auto, 1 enable, 2 disable (the reference's -E) */
     int useProducer;     /* 1 = register the GPU sequence producer (with software fallback), 0 = software zstd (baseline) */
 } QZSTD_FrontParams;

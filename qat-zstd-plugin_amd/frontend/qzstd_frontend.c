@@ -40,27 +40,34 @@ struct QZSTD_Front_s {
     unsigned char *dst;
     size_t *sizes;
     size_t nextChunk; /* shared claim cursor (atomic) */
+    int uniform;      /* every claim a whole segment: the levels whose match-finding, not the entropy stage, sets the pace (see qfClaim) */
     unsigned ahead;   /* claims a worker keeps announced beyond the one it is entropy-coding: $QZSTD_FRONT_AHEAD, 1..3, default 2 */
     unsigned long served[2];
 };
 
-/* A claim: chunks [c0, c1) of the job.  Claims are not all the same size (round 4, with a libzstd whose entropy stage runs at 1.6 GB/s per
- * core a 512 MiB job is over in 25 ms and its first and last milliseconds count):
+/* A claim: chunks [c0, c1) of the job.  Where the entropy stage sets the pace (levels 1-4: with a libzstd that entropy-codes 1.6 GB/s per core
+ * a 512 MiB job is over in 25 ms and its first and last milliseconds count) claims are not all the same size:
  *   - a worker's first claims are small (an eighth, then a quarter, then half of a segment): the GPU's first results are back after
  *     the time one block takes, not after a whole segment was staged and queued, and the pipeline below fills while they are consumed;
  *   - towards the end of the job a claim is at most a (2 x threads)-th of what is left, so the workers finish together;
- *   - never less than QF_MIN_CHUNKS chunks (a launch of fewer than four blocks is not worth its queueing). */
+ *   - never less than QF_MIN_CHUNKS chunks (a launch of fewer than four blocks is not worth its queueing).
+ * Where the match-finder sets the pace (the chain levels, 5-12: a 128 KiB block takes a workgroup 4-5 ms at level 6) every claim is a whole
+ * segment and three are kept announced: what counts there is how many blocks are on the GPU at any time, and a launch of four blocks
+ * takes as long as one of thirty-two (level 6, 18 threads, 4 MiB: 5.8 GB/s with the varying claims, 8.3 with uniform ones; the kernel
+ * alone, input resident: 10.5). */
 #define QF_MIN_CHUNKS 4u
 typedef struct { size_t c0, c1; } QF_Seg;
 
 static int qfClaim(QZSTD_Front *f, unsigned nth, QF_Seg *out)
 {
     size_t want = f->segChunks, have, left;
-    if (nth < 3 && (f->segChunks >> (3 - nth)) >= QF_MIN_CHUNKS) want = f->segChunks >> (3 - nth);
     have = __atomic_load_n(&f->nextChunk, __ATOMIC_RELAXED);
     if (have >= f->nChunks) return 0;
-    left = (f->nChunks - have) / (2u * (size_t)f->p.nThreads);
-    if (want > left) want = left;
+    if (!f->uniform) {
+        if (nth < 3 && (f->segChunks >> (3 - nth)) >= QF_MIN_CHUNKS) want = f->segChunks >> (3 - nth);
+        left = (f->nChunks - have) / (2u * (size_t)f->p.nThreads);
+        if (want > left) want = left;
+    }
     if (want < QF_MIN_CHUNKS) want = QF_MIN_CHUNKS;
     if (want > f->segChunks) want = f->segChunks;
     have = __atomic_fetch_add(&f->nextChunk, want, __ATOMIC_RELAXED);
@@ -147,7 +154,8 @@ QZSTD_Front *QZSTD_createFront(const QZSTD_FrontParams *p)
     f = (QZSTD_Front *)calloc(1, sizeof(*f));
     if (!f) return NULL;
     f->p = *p;
-    seg = p->segmentBytes ? p->segmentBytes : ((size_t)2 << 20); /* measured best on MI355X + 16 cores: 2 MiB */
+    /* measured on MI355X + 16 cores: 2 MiB where the entropy stage sets the pace (levels 1-4), 4 MiB claims of one size where the match-finder does */
+    seg = p->segmentBytes ? p->segmentBytes : ((size_t)(p->level >= 5 ? 4 : 2) << 20);
     if (seg > QF_HINT_MAX) seg = QF_HINT_MAX;
     f->segChunks = seg / p->chunkSize ? seg / p->chunkSize : 1;
     f->stride = ZSTD_compressBound(p->chunkSize);
@@ -155,6 +163,9 @@ QZSTD_Front *QZSTD_createFront(const QZSTD_FrontParams *p)
         const char *a = getenv("QZSTD_FRONT_AHEAD");
         const int v = a && *a ? atoi(a) : 2;
         f->ahead = v < 1 ? 1u : (v > (int)QF_AHEAD_MAX ? QF_AHEAD_MAX : (unsigned)v);
+        a = getenv("QZSTD_FRONT_UNIFORM");
+        f->uniform = a && *a ? atoi(a) != 0 : p->level >= 5;
+        if (f->uniform && !(getenv("QZSTD_FRONT_AHEAD") && *getenv("QZSTD_FRONT_AHEAD"))) f->ahead = QF_AHEAD_MAX;
     }
     f->w = (QF_Worker *)calloc((size_t)p->nThreads, sizeof(QF_Worker));
     pthread_mutex_init(&f->mu, NULL);

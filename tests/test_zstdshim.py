@@ -1,0 +1,82 @@
+"""CPU: tools/zstdshim — the normally-built zstd 1.5.7 inside pyarrow's libarrow.so behind the public ZSTD_* names (zstdshim.c says why).
+It is the libzstd of every test, tool and bench leg when it works (tools/qz_bind.py: find_libzstd); these tests pin what "works" means:
+every public name resolved, the same version as the image's exported copy (Pillow's, a ~4x slower build), BYTE-IDENTICAL frames from both
+— software levels and through the sequence-producer API with the oracle as producer — and a faster entropy stage."""
+import ctypes as C
+import os
+import time
+
+import pytest
+
+import qz_bind as B
+import qz_corpus as K
+
+
+@pytest.fixture(scope="module")
+def shim():
+    path = B.fast_libzstd()
+    if not path:
+        pytest.skip("tools/zstdshim unusable here (no gcc, no pyarrow, or QZ_ZSTD_NO_SHIM=1): the suite runs on the exported libzstd")
+    return path
+
+
+def test_every_public_name_resolved_from_libarrow(shim):
+    L = C.CDLL(shim)
+    L.zstdshim_source.restype = C.c_char_p
+    assert L.zstdshim_ok() == 1
+    assert L.zstdshim_resolved() == L.zstdshim_wanted() >= 170
+    assert b"libarrow.so" in L.zstdshim_source()
+    names = [ln[2:-1] for ln in open(os.path.join(B.SHIM_DIR, "zstd_names.h")).read().split("\n") if ln.startswith("X(")]
+    assert len(names) == L.zstdshim_wanted() and "ZSTD_registerSequenceProducer" in names and "ZSTD_compress2" in names
+    for n in names:
+        assert hasattr(L, n), n
+    L.ZSTD_versionNumber.restype = C.c_uint
+    assert L.ZSTD_versionNumber() >= 10504
+    assert B.find_libzstd() == shim or os.environ.get("ZSTDLIB")
+
+
+def test_same_frames_as_the_exported_copy(shim, oracle):
+    """same version, same decisions: software frames at levels 1/3/6, and frames through the producer API (oracle as the producer)"""
+    slow_path = B.slow_libzstd()
+    if os.path.abspath(slow_path) == os.path.abspath(shim):
+        pytest.skip("no second libzstd >= 1.5.4 to compare with")
+    fast, slow = B.Zstd(shim), B.Zstd(slow_path)
+    if fast.version() != slow.version():
+        pytest.skip("the exported copy is %s, the one inside libarrow.so %s" % (slow.version(), fast.version()))
+    data = K.by_name("system", 6 * 131072 + 999, seed=21) + K.by_name("weblog", 2 * 131072, seed=2)
+    for level in (1, 3, 6):
+        a, b = fast.cctx(level), slow.cctx(level)
+        fa, fb = fast.compress_chunks(a, data, 131072)[1], slow.compress_chunks(b, data, 131072)[1]
+        fast.free(a)
+        slow.free(b)
+        assert fa == fb, "software frames differ at level %d" % level
+    for level, chunk in ((1, 131072), (6, 131072), (12, 32768)):
+        a = fast.cctx(level, producer=oracle.producer_addr, state=None, fallback=False, validate=True)
+        b = slow.cctx(level, producer=oracle.producer_addr, state=None, fallback=False, validate=True)
+        fa, fb = fast.compress_chunks(a, data, chunk)[1], slow.compress_chunks(b, data, chunk)[1]
+        fast.free(a)
+        slow.free(b)
+        assert fa == fb, "frames through the producer API differ at level %d" % level
+        assert b"".join(slow.decompress(f, chunk) for f in fa) == data
+
+
+def test_the_point_of_it_a_faster_library(shim):
+    """level 1 on 128 KiB chunks, one thread: the copy inside libarrow.so is several times faster than Pillow's (measured 684 vs 169 MB/s);
+    asserted loosely (>= 1.5x) — other tests share the cores"""
+    slow_path = B.slow_libzstd()
+    if "pillow.libs" not in slow_path:
+        pytest.skip("the exported libzstd here is not Pillow's slow build")
+    data = K.by_name("system", 64 * 131072, seed=5)
+    rate = {}
+    for name, path in (("fast", shim), ("slow", slow_path)):
+        z = B.Zstd(path)
+        c = z.cctx(1)
+        z.compress_chunks(c, data[:8 * 131072], 131072)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            z.compress_chunks(c, data, 131072)
+            best = min(best, time.perf_counter() - t0)
+        z.free(c)
+        rate[name] = len(data) / best / 1e6
+    assert rate["fast"] >= 1.5 * rate["slow"], rate
