@@ -18,12 +18,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MOCK_SO = os.path.join(ROOT, "tests", "mock", "libqatseqprod_mock.so")
 
 
+def build_shared(cmd, out):
+    """gcc ... -o <out>: built aside and renamed, so that pytest-xdist workers running the same fixture never load a half-written file"""
+    tmp = "%s.%d.tmp" % (out, os.getpid())
+    subprocess.check_call([tmp if x == out else x for x in cmd])
+    os.replace(tmp, out)
+
+
 @pytest.fixture(scope="module")
 def mock(oracle):
     srcs = [os.path.join(B.PKG_DIR, "host", "qatseqprod.c"), os.path.join(B.PKG_DIR, "csrc", "qzstd_profile.c"),
             os.path.join(ROOT, "tests", "mock", "mock_hip.c"), os.path.join(ROOT, "oracle", "qzstd_oracle.c")]
-    subprocess.check_call(["gcc", "-O2", "-g", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
-                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"), "-o", MOCK_SO] + srcs)
+    build_shared(["gcc", "-O2", "-g", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
+                  "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"), "-o", MOCK_SO] + srcs, MOCK_SO)
     plug = B.Plugin(MOCK_SO)
     assert plug.lib.QZSTD_startQatDevice() == 0
     yield plug
@@ -469,10 +476,10 @@ def test_batch_front_end_over_the_mock(mock, zstd, oracle):
     """include/qzstd_frontend.h: a pool of CCtx threads fed from one segment counter, every segment
     announced one claim ahead; frames are the oracle's, every block comes from an announcement"""
     front_so = os.path.join(ROOT, "tests", "mock", "libqzstdfront_mock.so")
-    subprocess.check_call(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
-                           "-I" + os.path.join(ROOT, "include"), "-o", front_so,
+    build_shared(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
+                  "-I" + os.path.join(ROOT, "include"), "-o", front_so,
                            os.path.join(B.PKG_DIR, "frontend", "qzstd_frontend.c"), MOCK_SO, zstd.path,
-                           "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)])
+                           "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)], front_so)
     F = C.CDLL(front_so)
 
     class Params(C.Structure):
@@ -769,9 +776,9 @@ def test_multi_gpu_product_leg_over_four_mock_devices(mock, zstd, tmp_path):
     states are spread round-robin); blocks per GPU from QZSTD_deviceStats, frames round-trip, no producer errors"""
     import re
     front_so = os.path.join(ROOT, "tests", "mock", "libqzstdfront_mock.so")
-    subprocess.check_call(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
-                           "-I" + os.path.join(ROOT, "include"), "-o", front_so, os.path.join(B.PKG_DIR, "frontend", "qzstd_frontend.c"),
-                           MOCK_SO, zstd.path, "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)])
+    build_shared(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
+                  "-I" + os.path.join(ROOT, "include"), "-o", front_so, os.path.join(B.PKG_DIR, "frontend", "qzstd_frontend.c"),
+                           MOCK_SO, zstd.path, "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)], front_so)
     exe = str(tmp_path / "frontbench")
     subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-I" + os.path.join(ROOT, "include"), "-o", exe,
                            os.path.join(B.PKG_DIR, "test", "frontbench.c"), front_so, MOCK_SO, zstd.path,

@@ -3,8 +3,10 @@ It is the libzstd of every test, tool and bench leg when it works (tools/qz_bind
 every public name resolved, the same version as the image's exported copy (Pillow's, a ~4x slower build), BYTE-IDENTICAL frames from both
 — software levels and through the sequence-producer API with the oracle as producer — and a faster entropy stage."""
 import ctypes as C
+import json
 import os
-import time
+import subprocess
+import sys
 
 import pytest
 
@@ -35,29 +37,54 @@ def test_every_public_name_resolved_from_libarrow(shim):
     assert B.find_libzstd() == shim or os.environ.get("ZSTDLIB")
 
 
+CHILD = r"""
+import hashlib, json, sys, time
+sys.path.insert(0, %r)
+import qz_bind as B, qz_corpus as K
+path, what = sys.argv[1], sys.argv[2]
+z = B.Zstd(path)   # ONE libzstd per process: two in one process interpose each other's symbols (both are loaded RTLD_GLOBAL)
+out = {"version": z.version()}
+if what == "frames":
+    orc = B.Oracle()
+    data = K.by_name("system", 6 * 131072 + 999, seed=21) + K.by_name("weblog", 2 * 131072, seed=2)
+    for level in (1, 3, 6):
+        c = z.cctx(level)
+        out["sw%%d" %% level] = hashlib.sha256(b"".join(z.compress_chunks(c, data, 131072)[1])).hexdigest()
+        z.free(c)
+    for level, chunk in ((1, 131072), (6, 131072), (12, 32768)):
+        c = z.cctx(level, producer=orc.producer_addr, state=None, fallback=False, validate=True)
+        frames = z.compress_chunks(c, data, chunk)[1]
+        z.free(c)
+        assert b"".join(z.decompress(f, chunk) for f in frames) == data
+        out["producer%%d" %% level] = hashlib.sha256(b"".join(frames)).hexdigest()
+else:
+    data = K.by_name("system", 64 * 131072, seed=5)
+    c = z.cctx(1)
+    z.compress_chunks(c, data[:8 * 131072], 131072)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); z.compress_chunks(c, data, 131072); best = min(best, time.perf_counter() - t0)
+    out["MBps"] = len(data) / best / 1e6
+print(json.dumps(out))
+""" % os.path.join(B.ROOT, "tools")
+
+
+def child(path, what):
+    r = subprocess.run([sys.executable, "-c", CHILD, path, what], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def test_same_frames_as_the_exported_copy(shim, oracle):
-    """same version, same decisions: software frames at levels 1/3/6, and frames through the producer API (oracle as the producer)"""
+    """same version, same decisions: software frames at levels 1/3/6, and frames through the producer API (the oracle as the producer) —
+    each library in its own process (two libzstd in one process interpose each other's symbols)"""
     slow_path = B.slow_libzstd()
     if os.path.abspath(slow_path) == os.path.abspath(shim):
         pytest.skip("no second libzstd >= 1.5.4 to compare with")
-    fast, slow = B.Zstd(shim), B.Zstd(slow_path)
-    if fast.version() != slow.version():
-        pytest.skip("the exported copy is %s, the one inside libarrow.so %s" % (slow.version(), fast.version()))
-    data = K.by_name("system", 6 * 131072 + 999, seed=21) + K.by_name("weblog", 2 * 131072, seed=2)
-    for level in (1, 3, 6):
-        a, b = fast.cctx(level), slow.cctx(level)
-        fa, fb = fast.compress_chunks(a, data, 131072)[1], slow.compress_chunks(b, data, 131072)[1]
-        fast.free(a)
-        slow.free(b)
-        assert fa == fb, "software frames differ at level %d" % level
-    for level, chunk in ((1, 131072), (6, 131072), (12, 32768)):
-        a = fast.cctx(level, producer=oracle.producer_addr, state=None, fallback=False, validate=True)
-        b = slow.cctx(level, producer=oracle.producer_addr, state=None, fallback=False, validate=True)
-        fa, fb = fast.compress_chunks(a, data, chunk)[1], slow.compress_chunks(b, data, chunk)[1]
-        fast.free(a)
-        slow.free(b)
-        assert fa == fb, "frames through the producer API differ at level %d" % level
-        assert b"".join(slow.decompress(f, chunk) for f in fa) == data
+    a, b = child(shim, "frames"), child(slow_path, "frames")
+    if a["version"] != b["version"]:
+        pytest.skip("the exported copy is %s, the one inside libarrow.so %s" % (b["version"], a["version"]))
+    assert a == b
 
 
 def test_the_point_of_it_a_faster_library(shim):
@@ -66,17 +93,5 @@ def test_the_point_of_it_a_faster_library(shim):
     slow_path = B.slow_libzstd()
     if "pillow.libs" not in slow_path:
         pytest.skip("the exported libzstd here is not Pillow's slow build")
-    data = K.by_name("system", 64 * 131072, seed=5)
-    rate = {}
-    for name, path in (("fast", shim), ("slow", slow_path)):
-        z = B.Zstd(path)
-        c = z.cctx(1)
-        z.compress_chunks(c, data[:8 * 131072], 131072)
-        best = 1e9
-        for _ in range(3):
-            t0 = time.perf_counter()
-            z.compress_chunks(c, data, 131072)
-            best = min(best, time.perf_counter() - t0)
-        z.free(c)
-        rate[name] = len(data) / best / 1e6
-    assert rate["fast"] >= 1.5 * rate["slow"], rate
+    fast, slow = child(shim, "rate")["MBps"], child(slow_path, "rate")["MBps"]
+    assert fast >= 1.5 * slow, (fast, slow)
