@@ -820,22 +820,37 @@ def main():
                     f.write(sample[:len(sample) // 4])
                     f6 = f.name
                 for key, lv, blk in (("level3", 3, block), ("level6", 6, block), ("level12_32k", 12, 32768)):  # level 3 = libzstd's default
-                    swl = c_benchmark(f6, blk, lv, base_t, mode=0, loops=1)
-                    sw14l = c_benchmark(f6, blk, lv, base_t, mode=0, loops=2, tool="benchmark_sw")
-                    pl = c_benchmark(f6, blk, lv, base_t, mode=1, hint=8, loops=10)  # (about a second each: the device layer's start-up is inside the wall clock)
-                    pp = c_benchmark(f6, blk, lv, base_t, mode=1, loops=10)
+                    # (each leg: one calibration run, then about 1.5 s of passes with a barrier between them, the value = the median pass — with a
+                    # libzstd of normal speed a pass over these samples takes milliseconds and the device layer's start-up would otherwise be the result)
+                    swl = measured(lambda l: c_benchmark(f6, blk, lv, base_t, mode=0, loops=l, passes=True), 1.5, min_passes=3)
+                    sw14l = measured(lambda l: c_benchmark(f6, blk, lv, base_t, mode=0, loops=l, tool="benchmark_sw", passes=True), 1.5, min_passes=3)
+                    pl = measured(lambda l: c_benchmark(f6, blk, lv, base_t, mode=1, hint=8, loops=l, passes=True), 1.5)
+                    pp = measured(lambda l: c_benchmark(f6, blk, lv, base_t, mode=1, loops=l, passes=True), 1.5)
+                    for r_ in (swl, sw14l, pl, pp):
+                        if "value" in r_:
+                            r_["MBps_wall"] = r_["value"]  # (the comparisons below read MBps_wall: the median pass from here on)
                     if "csize" in pl and "csize" in swl:
                         pl["csize_vs_sw"] = round(pl["csize"] / swl["csize"], 4)
                         pl["ratio_within_2pct"] = pl["csize"] <= swl["csize"] * 1.02
                         pl["speedup_vs_libzstd_1_5"] = round(pl["MBps_wall"] / max(swl["MBps_wall"], 1e-9), 2)
                         if "MBps_wall" in sw14l:
                             pl["speedup_vs_libzstd_1_4"] = round(pl["MBps_wall"] / max(sw14l["MBps_wall"], 1e-9), 2)
+                    # the batch front-end at that level (its defaults: 2 MiB claims at levels 1-4, uniform 4 MiB claims at the chain levels), one
+                    # 128 MiB buffer (level 12: the web-log corpus in 32 KiB chunks, BASELINE config 4's shape), median pass of about 1.5 s
+                    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+                        f.write(K.weblog(4, 64 * K.MiB) * 2 if lv == 12 else shard[:1024 * block])
+                        fl = f.name
+                    fe = measured(lambda l: frontbench(fl, blk, lv, base_t, 1, loops=l, seg_mib=0), 1.5)
+                    os.unlink(fl)
                     out[key] = {"cpu_libzstd_1_5": slim(swl), "cpu_libzstd_1_4": slim(sw14l), "e2e_announced": slim(pl) | {k: pl.get(k) for k in ("csize_vs_sw", "ratio_within_2pct", "speedup_vs_libzstd_1_5", "speedup_vs_libzstd_1_4")},
-                                "unchanged_callers": slim(pp)}
+                                "unchanged_callers": slim(pp), "frontend": slim(fe)}
                 # BASELINE config 5's shape: 4 MiB frames (32 producer calls per frame), level 3, ZSTD_c_blockSplitterLevel = 1 so that
                 # libzstd keeps the blocks of a frame at 128 KiB (its 1.5.7 pre-splitter otherwise cuts them at arbitrary offsets)
-                sw5 = c_benchmark(fname, 4 << 20, 3, base_t, mode=0, loops=2, split=1)
-                p5 = c_benchmark(fname, 4 << 20, 3, base_t, mode=1, hint=4, loops=3, split=1)
+                sw5 = measured(lambda l: c_benchmark(fname, 4 << 20, 3, base_t, mode=0, loops=l, split=1, passes=True), 1.5, min_passes=3)
+                p5 = measured(lambda l: c_benchmark(fname, 4 << 20, 3, base_t, mode=1, hint=4, loops=l, split=1, passes=True), 1.5)
+                for r_ in (sw5, p5):
+                    if "value" in r_:
+                        r_["MBps_wall"] = r_["value"]
                 x5 = {}
                 if "csize" in p5 and "csize" in sw5:
                     x5 = {"csize_vs_sw": round(p5["csize"] / sw5["csize"], 4), "speedup_vs_libzstd_1_5": round(p5["MBps_wall"] / max(sw5["MBps_wall"], 1e-9), 2),
