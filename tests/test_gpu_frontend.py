@@ -46,3 +46,24 @@ def test_front_end_one_thread_and_default_segment(gpu_plugin, zstd, oracle):
     frames, st, fs = front.frames(data, 131072, 1, 1)
     assert frames == oracle_frames(zstd, oracle, data, 131072, 1)
     assert st[1] == 0 and fs[0] == 0, (st, fs)
+
+
+@pytest.mark.parametrize("level,chunk,blocks", [(1, 131072, 1024), (3, 131072, 512), (6, 131072, 192), (12, 32768, 768)])
+def test_front_end_under_load_every_frame_is_the_oracles(gpu_plugin, zstd, oracle, level, chunk, blocks):
+    """round 4: the announcements' completion is the blocks' count words in pinned memory (no stream query), their staging copy a copy kernel,
+    a state keeps up to four announcements and the front-end two or three claims announced ahead — all of it under the load the bench runs it
+    at: 18 workers on every core, hundreds of launches in flight over 16 hardware queues, three jobs back to back over the same buffers (result
+    areas reused while later launches write theirs).  Every frame of every job has to be libzstd's frame from the ORACLE's sequences: a count
+    word that overtook its entries, or entries of the previous job, would show here and nowhere else"""
+    front = B.Front()
+    data = K.by_name("system", blocks * chunk - 12345, seed=level + 90)
+    n = (len(data) + chunk - 1) // chunk
+    want = oracle_frames(zstd, oracle, data, chunk, level)
+    for threads, seg in ((18, 0), (7, 4 * chunk)):
+        def check(job, frames):
+            bad = [c for c in range(n) if frames[c] != want[c]]
+            assert not bad, "job %d: frames %s differ from libzstd + oracle (level %d, %d threads)" % (job, bad[:8], level, threads)
+
+        frames, st, fs = front.frames(data, chunk, level, threads, segment=seg, jobs=3, each=check)
+        assert st[0] == 3 * n and st[1] == 0, "not every block came from an announcement: %s" % (st,)
+        assert fs[0] == 0, "producer callbacks failed: %s" % (fs,)

@@ -519,8 +519,9 @@ class Front:
         F.QZSTD_frontFailStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong)]
         F.QZSTD_freeFront.argtypes = [C.c_void_p]
 
-    def frames(self, data: bytes, chunk: int, level: int, threads: int, segment: int = 0, jobs: int = 1, ext_rep: int = 0):
-        """-> (frames, [announced, per block] blocks, fail stats[8]) of `jobs` passes of `data` through one front"""
+    def frames(self, data: bytes, chunk: int, level: int, threads: int, segment: int = 0, jobs: int = 1, ext_rep: int = 0, each=None):
+        """-> (frames of the last pass, [announced, per block] blocks, fail stats[8]) of `jobs` passes of `data` through one front;
+        each(job, frames) is called after every pass"""
         F = self.lib
         prm = FrontParams(threads, level, chunk, segment, ext_rep, 1)
         f = F.QZSTD_createFront(C.byref(prm))
@@ -531,10 +532,13 @@ class Front:
             n = (len(data) + chunk - 1) // chunk
             dst = C.create_string_buffer(n * stride)
             sizes = (C.c_size_t * n)()
-            for _ in range(jobs):
+            for j in range(jobs):
                 got = F.QZSTD_frontCompress(f, data, len(data), dst, len(dst), sizes)
                 if got != n:
                     raise RuntimeError("QZSTD_frontCompress returned %d, expected %d frames" % (got, n))
+                if each is not None:
+                    raw = dst.raw
+                    each(j, [raw[c * stride:c * stride + sizes[c]] for c in range(n)])
             st, fs = (C.c_ulong * 2)(), (C.c_ulong * 8)()
             F.QZSTD_frontStats(f, st)
             F.QZSTD_frontFailStats(f, fs)
