@@ -183,7 +183,7 @@ typedef struct {
     int splitBlocks;         /* QZSTD_HIP_SPLIT_BLOCKS (default 1): per-block requests of segmentable levels go as segments */
     int service;             /* QZSTD_HIP_SERVICE (default 1): per-block requests go to the resident service where it serves the level */
     int svcItemBytes;        /* QZSTD_HIP_SERVICE_ITEM (default 4096): bytes per work item of a service request (whole segments) */
-    int svcSpinUs;           /* QZSTD_HIP_SERVICE_SPIN_US (default 400): busy polling of the count words before napping */
+    int svcSpinUs;           /* QZSTD_HIP_SERVICE_SPIN_US (default 400; 10 when there are more states than usable cores): busy polling of the count words before napping */
     unsigned long devBlocks[QZ_MAX_DEVICES][3]; /* per GPU: blocks queued from announcements, blocks through batches, blocks through the service */
     pthread_mutex_t mutex;
     /* NUMA (reference: qaeMemAllocNUMA(size, node, 64) for every DMA buffer, src/qatseqprod.c:216-246): the host node every GPU hangs
@@ -193,6 +193,9 @@ typedef struct {
     int numaThreadNode;            /* QZSTD_HIP_NUMA_NODE: treat every calling thread as running on this node (-1: ask the kernel) */
     int devNode[QZ_MAX_DEVICES];   /* -1 = unknown */
     unsigned int nodeNext[QZ_NUMA_NODES_MAX], anyNext; /* round-robin counters: per node, and the fallback over all GPUs */
+    int svcSpinSet;                /* QZSTD_HIP_SERVICE_SPIN_US was given: no adapting */
+    int liveStates;                /* producer states alive (one per CCtx, i.e. per calling thread): more of them than usable cores = the callers
+                                    * oversubscribe the cores, and a caller that waits for the GPU should give its core away at once */
     int hintFlags;                 /* QZSTD_HIP_HINT_FLAGS (default 1): an announcement's launch is complete when its blocks' count words are in (0: when
                                     * the runtime says its stream is idle) */
     int hintDirect;                /* QZSTD_HIP_HINT_DIRECT: 0 (default) an announcement's staging copy goes to device memory by a copy kernel on the
@@ -202,7 +205,7 @@ typedef struct {
                                     * memory, 0.96 ms over the bus; hipMemcpyAsync holds the caller 0.8-1.1 ms per 4 MiB) */
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER, 1, -1, { 0 }, { 0 }, 0, 1, 0 };
+static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER, 1, -1, { 0 }, { 0 }, 0, 0, 0, 1, 0 };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
  * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
@@ -227,6 +230,7 @@ typedef struct {
 typedef struct {
     int st;   /* 0 empty, 1 announced (parts in flight or ready) */
     int touched; /* a callback was served from it */
+    unsigned int epoch; /* count-word completion: the mark (24 bits, never 0) every entry of THIS announcement carries in its fourth word */
     int stable;  /* QZSTD_HINT_STABLE: the announcer holds the bytes still until their callbacks have come (no memcmp per callback) */
     unsigned misses; /* callbacks that found nothing to serve since the announcement was last used */
     int nParts;
@@ -827,6 +831,7 @@ int QZSTD_startQatDevice(void)
         gProc.service = qzEnvInt("QZSTD_HIP_SERVICE", 1, 0, 1);
         gProc.svcItemBytes = qzEnvInt("QZSTD_HIP_SERVICE_ITEM", 4096, 4096, (int)QZSTD_HIP_BLOCK_MAX) & ~4095;
         gProc.svcSpinUs = qzEnvInt("QZSTD_HIP_SERVICE_SPIN_US", 400, 0, 1000000);
+        gProc.svcSpinSet = getenv("QZSTD_HIP_SERVICE_SPIN_US") != NULL;
         gProc.hintFlags = qzEnvInt("QZSTD_HIP_HINT_FLAGS", 1, 0, 1);
         gProc.hintDirect = qzEnvInt("QZSTD_HIP_HINT_DIRECT", 0, 0, 3);
         {
@@ -878,12 +883,37 @@ void QZSTD_stopQatDevice(void)
     pthread_mutex_unlock(&gProc.mutex);
 }
 
+/* the cores this process may use: its affinity mask, capped by a cgroup CPU quota (cpu.max) */
+static int qzUsableCores(void)
+{
+    static int cached;
+    int n = 0;
+    cpu_set_t set;
+    FILE *f;
+    if (cached) return cached;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    f = fopen("/sys/fs/cgroup/cpu.max", "re");
+    if (f) {
+        char q[32] = "";
+        long per = 0;
+        if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+            const long quota = (atol(q) + per - 1) / per;
+            if (quota > 0 && quota < n) n = (int)quota;
+        }
+        fclose(f);
+    }
+    cached = n > 0 ? n : 1;
+    return cached;
+}
+
 void *QZSTD_createSeqProdState(void)
 {
     QZSTD_Session_T *s = (QZSTD_Session_T *)calloc(1, sizeof(QZSTD_Session_T));
     if (!s) return NULL;
     s->slotHint = -1;
     s->pipeFd[0] = s->pipeFd[1] = -1;
+    __atomic_fetch_add(&gProc.liveStates, 1, __ATOMIC_RELAXED);
     return s;
 }
 
@@ -934,12 +964,45 @@ static void qzOrphanHint(QZSTD_Hint_T *h)
 }
 #ifdef QZ_TEST_HOOKS /* the mock build of tests/test_host_mock.py only: never in the release library */
 unsigned long qzstd_test_orphans(void) { return qzOrphanCount; }
+void qzstd_test_set_hint_epochs(void *state, unsigned int e) /* the state's next announcements get epoch e + 1 (the 24-bit wrap) */
+{
+    QZSTD_Session_T *s = (QZSTD_Session_T *)state;
+    int k;
+    for (k = 0; s && k < QZ_HINTS; k++) s->hint[k].epoch = e & 0xFFFFFFu;
+}
 void qzstd_test_set_service_epochs(unsigned int e) /* every slot's next service request gets epoch e + 1 (the 24-bit wrap) */
 {
     int i;
     for (i = 0; gProc.slots && i < gProc.numSlots; i++) gProc.slots[i].vEpoch = e & 0xFFFFFFu;
 }
 #endif
+
+/* Takes n entries of a result area that is completed by count words: the count says how many entries there are, not that they have all
+ * arrived — they are stored by other waves than the count and nothing orders them on their ways to host memory (measured in round 3 on
+ * the resident service: under load an item's last entries land up to microseconds after its count).  Every entry is ONE 16-byte store
+ * that carries the announcement's epoch in its fourth word (qzstd_hip_block_t.mark): an entry is taken when it shows it; the mark is
+ * masked out of the copy.  dst may be NULL (the entries are only waited for).  0 = taken, 1 = not within the time-out. */
+static int qzTakeMarked(ZSTD_Sequence *dst, const ZSTD_Sequence *q, size_t n, unsigned int epoch)
+{
+    const __m128i keep = _mm_set_epi32(0, -1, -1, -1);
+    unsigned long t0 = 0;
+    size_t j;
+    for (j = 0; j < n; j++) {
+        __m128i v = _mm_load_si128((const __m128i *)(const void *)(q + j));
+        if ((unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(v, 12)) != epoch) { /* not there yet: rare */
+            unsigned spins = 0;
+            if (!t0) t0 = qzNowNs();
+            do {
+                __builtin_ia32_pause();
+                __asm__ volatile("" ::: "memory"); /* (a fresh load every time round) */
+                if ((++spins & 1023u) == 0u && qzNowNs() - t0 > (unsigned long)gProc.timeoutMs * 1000000ul) return 1;
+                v = _mm_load_si128((const __m128i *)(const void *)(q + j));
+            } while ((unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(v, 12)) != epoch);
+        }
+        if (dst) _mm_storeu_si128((__m128i *)(void *)(dst + j), _mm_and_si128(v, keep));
+    }
+    return 0;
+}
 
 /* Completion of an announcement's launch WITHOUT the runtime (round 4): every workgroup publishes its block's count word — in the
  * announcement's pinned, coherent result area — with a system-scope release after all of its result stores (csrc/qzstd_kernels.hip,
@@ -1003,6 +1066,7 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
     QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
     int k;
     if (!s) return;
+    __atomic_fetch_sub(&gProc.liveStates, 1, __ATOMIC_RELAXED);
     QZ_LOG(2, "state %p: %lu block(s) served from a look-ahead batch (%lu of them speculative, %lu speculation(s)), %lu per "
               "block; %lu hint(s), timers from the 9th on: drop %.2f ms, buffers %.2f ms, staging %.2f ms, queueing %.2f ms (%.2f ms of it in the copy call, %.2f in the launch call), waited %.2f ms for the GPU\n", (void *)s,
            s->servedFromBatch, s->autoServed, s->autoLaunched, s->servedSync, s->hintCalls, s->hintDropNs / 1e6, s->hintPrepNs / 1e6, s->hintStageNs / 1e6,
@@ -1192,7 +1256,11 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
      * JOIN every item's list as it arrives (the trailing literals of one flow into the first sequence of the next): by the time the
      * last item is in, the rest of the block's list stands.  Busy for svcSpinUs, then naps. */
     t0 = qzNowNs();
+    /* how long a waiting caller polls before it naps: with a core per caller polling is free and a nap costs its wake-up (level 1, 16 threads on
+     * 16 cores: 12.7 GB/s polling 400 us, 10.5 napping at once); with more callers than cores a poller keeps another caller's entropy stage
+     * off the core (32 threads: 9.5 GB/s polling 400 us, 14.2-14.6 polling 10 us or not at all; 48 threads: 5.6 against 15.1-15.5) */
     spinNs = (unsigned long)gProc.svcSpinUs * 1000ul;
+    if (!gProc.svcSpinSet && __atomic_load_n(&gProc.liveStates, __ATOMIC_RELAXED) > qzUsableCores()) spinNs = 10000ul;
     limitNs = (unsigned long)gProc.timeoutMs * 1000000ul;
     for (k = 0; k < nItems; k++) {
         unsigned polls = 0;
@@ -1450,14 +1518,23 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                     for (bi = b; bi < e; bi++) {
                         const ZSTD_Sequence *q = h->hSeqs + bi * h->pitch;
                         const size_t count = h->hCount[bi];
+                        /* completed by its count word: the entries certify themselves one by one (the last one, the delimiter, too) */
+                        if (h->hDesc[bi].mark != 0u && (qzTakeMarked(count > 1 ? outSeqs + out : NULL, q, count - 1, h->hDesc[bi].mark) != 0 ||
+                                                        qzTakeMarked(NULL, q + count - 1, 1, h->hDesc[bi].mark) != 0)) {
+                            QZ_LOG(1, "announcement: entries of block %zu did not arrive within %d ms of their count\n", bi, gProc.timeoutMs);
+                            usable = 0;
+                            break;
+                        }
                         if (count > 1) {
-                            memcpy(outSeqs + out, q, (count - 1) * sizeof(ZSTD_Sequence));
+                            if (h->hDesc[bi].mark == 0u) memcpy(outSeqs + out, q, (count - 1) * sizeof(ZSTD_Sequence));
                             outSeqs[out].litLength += (unsigned int)carry;
                             out += count - 1;
                             carry = 0;
                         }
                         carry += q[count - 1].litLength; /* the block's delimiter: its trailing literals */
                     }
+                }
+                if (usable && total < outSeqsCapacity - 1) {
                     outSeqs[out].offset = 0;
                     outSeqs[out].litLength = (unsigned int)carry;
                     outSeqs[out].matchLength = 0;
@@ -1810,6 +1887,13 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     h->block = blockSize;
     h->level = compressionLevel;
     h->nb = nb;
+    h->epoch = (h->epoch + 1u) & 0xFFFFFFu;
+    if (h->epoch == 0u) {
+        /* the 24-bit epoch starts over: an entry that no announcement of the last 2^24 overwrote would show a mark that is valid again.
+         * Nothing of this announcement's buffers is in flight here (qzHintDrop above): wipe the result area once per lap */
+        memset(h->hSeqs, 0, h->hSeqsCap);
+        h->epoch = 1u;
+    }
     if (!speculative && nb <= QZ_CONTENT_LOOKUP_BLOCKS) {
         if (h->keysCap < nb) {
             free(h->keys);
@@ -1829,7 +1913,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
             h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
             h->hDesc[b].seqCap = (unsigned int)h->pitch;
             h->hDesc[b].parseFrom = 0;
-            h->hDesc[b].mark = 0;
+            h->hDesc[b].mark = gProc.hintFlags ? h->epoch : 0u; /* (count-word completion: every entry certifies itself, see qzTakeMarked) */
             h->hCount[b] = gProc.hintFlags ? QZ_COUNT_PENDING : QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
             if (!speculative && h->keys && nb <= h->keysCap && nb <= QZ_CONTENT_LOOKUP_BLOCKS)
                 h->keys[b] = h->hDesc[b].srcLen >= 16 ? qzBlockKey(h->hSrc + o, h->hDesc[b].srcLen) : 0ull;

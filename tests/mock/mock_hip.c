@@ -201,6 +201,22 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
                                                  (qzo_seq_t *)d_seqs + k->seqOff, k->seqCap);
         /* a stalled "GPU" (qzstd_mock_stall_ms) never publishes: the count words keep what the host put there (announcements poll them) */
         if (nowNs() < gStallUntilNs) continue;
+        if (n != QZO_ERROR) { /* every entry carries the block's mark in its fourth word, as the kernel's do (qzstd_hip_block_t.mark) */
+            uint32_t *w = (uint32_t *)d_seqs + (size_t)k->seqOff * 4u;
+            size_t j;
+            if (gLateMarks && k->mark) { /* test hook: the count first, the entries a while later, last entries first */
+                late_t *lt = (late_t *)malloc(sizeof *lt);
+                pthread_t th;
+                lt->w = w; lt->n = n; lt->epoch = k->mark; lt->us = 300 + 20 * (int)(b & 15u);
+                lt->real = (uint32_t *)malloc(n * 16u);
+                memcpy(lt->real, w, n * 16u);
+                memset(w, 0xEE, n * 16u);
+                if (pthread_create(&th, NULL, late_marks, lt) == 0) pthread_detach(th);
+                else late_marks(lt);
+            } else {
+                for (j = 0; j < n; j++) w[j * 4u + 3u] = k->mark;
+            }
+        }
         __atomic_store_n(&d_nseq[b], n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n, __ATOMIC_RELEASE);
     }
     return 0;

@@ -639,6 +639,64 @@ def test_service_entries_that_arrive_after_their_count(mock, zstd, oracle):
     assert fs[7] == 4 and fs[0] == 0, fs
 
 
+def test_announced_entries_that_arrive_after_their_count(mock, zstd, oracle):
+    """round 4: an announcement's launch is complete when its blocks' COUNT WORDS are in (no stream query) — and a count says how many entries a
+    block has, not that they have arrived: the mock publishes the counts at once and the entries up to half a millisecond later, last entry
+    first, garbage in their place until then.  Every entry carries the announcement's epoch in its fourth word and is taken when it shows it:
+    frames are the oracle's, every block came from the announcement, nothing failed — for plain, stable and four-deep announcements, over
+    buffers that are reused (the epoch of the previous announcement in the same place does not count)"""
+    chunk = 65536
+    data = K.by_name("system", 24 * chunk + 333, seed=12)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_late_marks.argtypes = [C.c_int]
+    L.QZSTD_hintSourceEx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint]
+    seg = 4 * chunk
+    want = oracle_frames(zstd, oracle, data, chunk, 3)
+    L.qzstd_mock_late_marks(1)
+    try:
+        for stable in (0, 1):
+            st = L.QZSTD_createSeqProdState()
+            for rnd in range(2):  # the second round reuses the four announcements' result areas
+                for k in range(3):
+                    assert L.QZSTD_hintSourceEx(st, C.byref(buf, k * seg), seg, chunk, 3, stable) == 0
+
+                def ahead(c):
+                    o = (c + 12) * chunk
+                    if c % 4 == 0 and o < len(data):
+                        assert L.QZSTD_hintSourceEx(st, C.byref(buf, o), min(seg, len(data) - o), chunk, 3, stable) == 0
+
+                got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 3, before=ahead)
+                assert got == want, "round %d, stable %d" % (rnd, stable)
+            served = stats_of(mock, st)
+            fs = fail_stats(mock, st)
+            L.QZSTD_freeSeqProdState(st)
+            assert served[0] == 2 * 25 and served[1] == 0 and fs[0] == 0, (served, fs)
+    finally:
+        L.qzstd_mock_late_marks(0)
+
+
+def test_announcement_epoch_wrap_wipes_stale_marks(mock, zstd, oracle):
+    """the mark of an announcement's entries is a 24-bit epoch per announcement buffer: when it starts over the result area is wiped once (an
+    entry nothing overwrote for a lap would show a valid mark again); announcements across the wrap serve the oracle's frames"""
+    chunk = 65536
+    data = K.by_name("mix", 16 * chunk, seed=14)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_test_set_hint_epochs.argtypes = [C.c_void_p, C.c_uint]
+    want = oracle_frames(zstd, oracle, data, chunk, 1)
+    st = L.QZSTD_createSeqProdState()
+    assert L.QZSTD_hintSource(st, buf, len(data), chunk, 1) == 0  # (buffers exist before the epochs are moved)
+    assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1) == want
+    L.qzstd_test_set_hint_epochs(st, 0xFFFFFE)
+    for _ in range(6):  # epochs 0xFFFFFF, then the wrap to 1, on each of the four buffers in turn
+        assert L.QZSTD_hintSource(st, buf, len(data), chunk, 1) == 0
+        assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1) == want
+    served, fs = stats_of(mock, st), fail_stats(mock, st)
+    L.QZSTD_freeSeqProdState(st)
+    assert served[0] == 7 * 16 and served[1] == 0 and fs[0] == 0, (served, fs)
+
+
 def test_service_epoch_wrap_wipes_stale_marks(mock, zstd, oracle):
     """the request epoch is 24 bits per slot: when it starts over, entries no request of the last lap overwrote would carry a mark
     that is valid again — the slot's result area is wiped once per lap (round-3 verdict, weak 3).  Every slot is put just before the
