@@ -448,6 +448,34 @@ def narrow_to_own_gpu(world: int, local: int):
     return before
 
 
+def bind_rank_to_its_gpus_node(plug, world: int, rank: int, dist):
+    """N > 1: the rank's threads (front-end workers, the HIP runtime's helpers) onto the CPUs of the NUMA node its GPU hangs off, shared out
+    between the ranks of that node (tools/qz_shard.py: plan_rank_cpus) — the pinned staging buffers already sit there.  Returns
+    what was done, for the bench line; any doubt (unknown node, no sysfs, too few CPUs) leaves the affinity alone."""
+    try:
+        node = int(plug.lib.qzstd_hip_device_numa_node(0))
+        nodes = [None] * world
+        dist.all_gather_object(nodes, node)
+        allowed = sorted(os.sched_getaffinity(0))
+        cpus_of_node = {}
+        for n in set(x for x in nodes if x is not None and x >= 0):
+            cpus = S.parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % n).read())
+
+            def first_sibling(c):
+                try:
+                    return min(S.parse_cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read()) or [c])
+                except OSError:
+                    return c
+            cpus_of_node[n] = sorted(cpus, key=lambda c: (first_sibling(c), c))  # hyperthread siblings next to each other
+        mine = S.plan_rank_cpus(rank, nodes, cpus_of_node, allowed)
+        if not mine:
+            return {"bound": False, "gpu_numa_node": node, "why": "unknown node, no CPU list, or fewer than two CPUs per rank on the node"}
+        os.sched_setaffinity(0, mine)
+        return {"bound": True, "gpu_numa_node": node, "cpus": len(mine), "ranks_on_this_node": sum(1 for x in nodes if x == node)}
+    except Exception as e:  # noqa: BLE001 - never at the price of the bench line
+        return {"bound": False, "why": repr(e)[:200]}
+
+
 def e2e_steps(front, params, buf: bytes, chunk: int, steps: int, warmup: int, sync, barrier):
     """The timed region of the metric: `steps` passes of `buf` through QZSTD_frontCompress (ZSTD_compress2 per chunk on a pool of
     CCtx threads, qatSequenceProducer registered, segments announced one ahead), after `warmup` untimed ones; barrier + device
@@ -528,6 +556,8 @@ def main():
     plug = B.Plugin()
     L = plug.lib
     assert L.qzstd_hip_device_count() > local, plug.err()
+    _, quota_before_binding = host_cpu_budget()
+    cpu_binding = bind_rank_to_its_gpus_node(plug, world, rank, dist) if world > 1 and os.environ.get("QZ_BENCH_BIND", "1") != "0" else {"bound": False, "why": "one rank: the threads run where the scheduler puts them"}
 
     block, nb, level = a.block, a.blocks, a.level
     size = block * nb
@@ -600,6 +630,8 @@ def main():
     # poll leaves its core idle; two more threads than cores fill those gaps (tools/fe_dbg.sh on a 16-core box, 2 MiB claims, two announced ahead:
     # 14 threads 14.9 GB/s, 16: 20.7, 18: 22.3, 20: 22.1, 24: 22.5)
     share = max(1.0, quota / world)
+    if cpu_binding.get("bound"):  # (the affinity is this rank's own CPUs now: not to be divided by the ranks again)
+        share = max(1.0, min(quota_before_binding / world, float(len(os.sched_getaffinity(0)))))
     e2e_threads = a.e2e_threads if a.e2e_threads > 0 else max(1, min(int(share + share / 8.0), 128))
     e2e_nb = max(1, min(a.e2e_blocks, nb))
     e2e_buf = shard[:e2e_nb * block]
@@ -632,7 +664,7 @@ def main():
                                    "threads per rank (usable host cores %.0f / %d rank(s), plus an eighth), 2 MiB announcements; host buffers in, frames out"
                                    % (level & 0xFF, block >> 10, e2e_nb, len(e2e_buf) >> 20, e2e_info["producer_errors"]["total"], e2e_threads, quota, world),
                        "corpus": prov[:300], "level": level, "block_bytes": block, "chunks_per_gpu_per_step": e2e_nb,
-                       "threads_per_rank": e2e_threads, "libzstd": B.Zstd().version(), "libzstd_build": B.libzstd_build(B.find_libzstd()),
+                       "threads_per_rank": e2e_threads, "libzstd": B.Zstd().version(), "libzstd_build": B.libzstd_build(B.find_libzstd()), "cpu_binding_rank0": cpu_binding,
                        "parallelism": "block-sharded x%d (one process per GPU, each rank's plugin sees its own GPU only), no collective" % world},
             "e2e": dict(e2e_info, served_by_gpu=served_by_gpu, pass_s_median=round(srt[len(srt) // 2], 4), pass_s_min=round(srt[0], 4),
                         pass_s_max=round(srt[-1], 4),

@@ -325,3 +325,55 @@ def test_bench_rank_sees_its_own_gpu_only(monkeypatch):
     assert bench.narrow_to_own_gpu(8, 5) is None and os.environ["HIP_VISIBLE_DEVICES"] == "5"
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
     assert bench.narrow_to_own_gpu(4, 2) == "4,5,6,7" and os.environ["HIP_VISIBLE_DEVICES"] == "6"
+
+
+def test_bench_ranks_share_out_the_cpus_of_their_gpus_node(monkeypatch):
+    """bench.py --gpus N on a two-socket node: a rank's threads go to the CPUs of the NUMA node its GPU hangs off, the ranks of one node share
+    them out in whole runs of the sibling-ordered list; unknown nodes, missing lists or too few CPUs leave the affinity alone.  The planning
+    is a pure function (tools/qz_shard.py); the binding itself never costs the bench line (any exception -> not bound)"""
+    import importlib.util
+    import qz_shard as S
+    assert S.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and S.parse_cpulist("") == [] and S.parse_cpulist("a-b") == []
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    allowed = list(range(256))
+    got = [S.plan_rank_cpus(r, nodes, cpus, allowed) for r in range(8)]
+    assert all(len(g) == 32 for g in got)
+    assert sorted(c for g in got[:4] for c in g) == sorted(cpus[0]) and sorted(c for g in got[4:] for c in g) == sorted(cpus[1])  # a partition per node
+    assert S.plan_rank_cpus(0, [0], {0: list(range(16))}, list(range(16))) == list(range(16))
+    assert S.plan_rank_cpus(1, nodes, cpus, list(range(0, 256, 2))) == [c for c in cpus[0] if c % 2 == 0][16:32]  # only what the process may use
+    assert S.plan_rank_cpus(0, [-1, -1], cpus, allowed) == [] and S.plan_rank_cpus(0, [0, 0], {1: [1, 2, 3, 4]}, allowed) == []
+    assert S.plan_rank_cpus(0, [0, 0, 0, 0], {0: [0, 1, 2, 3, 4, 5, 6]}, allowed) == []  # fewer than two CPUs per rank: hands off
+    assert S.plan_rank_cpus(9, nodes, cpus, allowed) == []
+
+    spec = importlib.util.spec_from_file_location("qz_bench2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class FakePlug:
+        class lib:
+            @staticmethod
+            def qzstd_hip_device_numa_node(d):
+                return 0
+
+    class FakeDist:
+        @staticmethod
+        def all_gather_object(out, obj):
+            for i in range(len(out)):
+                out[i] = obj
+
+    before = os.sched_getaffinity(0)
+    try:
+        r = bench.bind_rank_to_its_gpus_node(FakePlug, 2, 1, FakeDist)
+        assert isinstance(r, dict) and "bound" in r
+        if r["bound"]:
+            assert os.sched_getaffinity(0) <= before and len(os.sched_getaffinity(0)) == r["cpus"] >= 2
+    finally:
+        os.sched_setaffinity(0, before)
+
+    class Broken:
+        class lib:
+            @staticmethod
+            def qzstd_hip_device_numa_node(d):
+                raise OSError("no such symbol")
+    assert bench.bind_rank_to_its_gpus_node(Broken, 2, 0, FakeDist)["bound"] is False and os.sched_getaffinity(0) == before

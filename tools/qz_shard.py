@@ -43,3 +43,38 @@ def gather_counts(local_counts, dist=None):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, list(local_counts))
     return [c for part in out for c in part]
+
+
+def parse_cpulist(text: str) -> list[int]:
+    """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]; anything unparsable -> []"""
+    out = []
+    try:
+        for part in text.strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            out.extend(range(int(lo), int(hi or lo) + 1))
+    except ValueError:
+        return []
+    return sorted(set(out))
+
+
+def plan_rank_cpus(rank: int, node_of_rank: list[int], cpus_of_node: dict[int, list[int]], allowed: list[int]) -> list[int]:
+    """CPUs for rank `rank` of a one-process-per-GPU job on one host: the CPUs of the NUMA node its GPU hangs off (reference: DMA memory on the
+    instance's node, src/qatseqprod.c:216-246 — here the threads that copy into that memory go there too), restricted to what the process
+    may use, shared out evenly between the ranks whose GPUs sit on the same node (the k-th such rank takes every n-th CPU from k on, so
+    hyperthread siblings — usually numbered far apart — stay together as the kernel lists them).  [] = leave the affinity alone: unknown
+    node, no CPU list, or fewer than two CPUs per rank to hand out."""
+    if not (0 <= rank < len(node_of_rank)):
+        return []
+    node = node_of_rank[rank]
+    if node is None or node < 0 or node not in cpus_of_node:
+        return []
+    ok = set(allowed)
+    cpus = [c for c in cpus_of_node[node] if c in ok]
+    mates = [r for r, n in enumerate(node_of_rank) if n == node]
+    if len(cpus) < 2 * len(mates):
+        return []
+    per = len(cpus) // len(mates)
+    k = mates.index(rank)
+    return cpus[k * per:(k + 1) * per]
