@@ -5,7 +5,7 @@
 = what BASELINE.json's metric literally names: INPUT MB/s THROUGH ZSTD_compress2 with qatSequenceProducer registered, level 1,
 one frame per 128 KiB chunk (the framing of /root/reference/test/benchmark.c:300-321, timing shape :305-319,:374-382).  A "step"
 is one pass of ONE buffer of --e2e-blocks chunks (default 8192 x 128 KiB = 1 GiB per GPU: BASELINE configs[1]) through the batch front-end
-(include/qzstd_frontend.h: a pool of CCtx threads, one per usable host core, every 2 MiB segment announced one claim ahead, the
+(include/qzstd_frontend.h: a pool of CCtx threads, the usable host cores + an eighth, claims of at most 2 MiB with two announced ahead, the
 GPU match-finds while the threads entropy-code), called IN THIS PROCESS through its C ABI.  W untimed warm-up passes, then exactly
 K passes between barrier + synchronize brackets, MAX over ranks; `value` = chunks' bytes of all ranks x K / that time.  One
 process per GPU (torch.distributed.run): rank r sees only GPU r (HIP_VISIBLE_DEVICES is narrowed before HIP starts), blocks are
@@ -769,7 +769,7 @@ def main():
                 return {k: r[k] for k in keep if k in r}
 
             # ---- the first-class end-to-end legs (input MB/s through ZSTD_compress2 with the plugin registered):
-            #   frontend            include/qzstd_frontend.h: one big buffer, a pool of CCtx threads announcing one segment ahead -> value_e2e
+            #   frontend            include/qzstd_frontend.h: one big buffer, a pool of CCtx threads keeping two claims announced ahead -> value_e2e
             #   unchanged_callers   library defaults, nothing announced: every block through the resident service (levels 1-2) / the batches
             #   announced           the benchmark tool with QZSTD_hintSource 2 MiB ahead (-H2)
             #   e2e_ceiling_replay  the plugin's own sequences replayed by a memcpy-only producer: what ANY external producer can reach here

@@ -473,8 +473,8 @@ def test_dense_block_is_redone_alone(mock, zstd, oracle):
 
 
 def test_batch_front_end_over_the_mock(mock, zstd, oracle):
-    """include/qzstd_frontend.h: a pool of CCtx threads fed from one segment counter, every segment
-    announced one claim ahead; frames are the oracle's, every block comes from an announcement"""
+    """include/qzstd_frontend.h: a pool of CCtx threads fed from one chunk cursor, two claims kept
+    announced ahead; frames are the oracle's, every block comes from an announcement"""
     front_so = os.path.join(ROOT, "tests", "mock", "libqzstdfront_mock.so")
     build_shared(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
                   "-I" + os.path.join(ROOT, "include"), "-o", front_so,
