@@ -305,6 +305,9 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
     try:
         assert h_in, plug.err()
         C.memmove(h_in, shard[:nchunks * cbytes], nchunks * cbytes)
+        dv_in = L.qzstd_hip_host_device_ptr(C.c_void_p(h_in))
+        copy_kernel = bool(dv_in) and os.environ.get("QZ_BENCH_PCIE_COPY", "memcpy") == "kernel"
+        L.qzstd_hip_copy_in.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         for _ in range(depth):
             ln = {"stream": L.qzstd_hip_stream_create(device), "d_src": L.qzstd_hip_malloc(device, C.c_size_t(cbytes + 64)),
                   "h_seqs": L.qzstd_hip_host_alloc(C.c_size_t(chunk_blocks * pitch * 16)),
@@ -334,8 +337,15 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
                         else:
                             seqs += v
                 if k < nchunks:
-                    rc = L.qzstd_hip_memcpy_h2d(device, C.c_void_p(ln["stream"]), C.c_void_p(ln["d_src"]),
-                                                C.c_void_p(h_in + k * cbytes), C.c_size_t(cbytes))
+                    # one thread drives 64 MiB chunks here: hipMemcpyAsync's cost to the caller does not matter and its DMA engine is a little
+                    # faster than a copy kernel (29.7 vs 27.1 GB/s, tools/pcie_probe.py); QZ_BENCH_PCIE_COPY=kernel: the copy kernel the
+                    # product's announcements use (many threads, 2 MiB each: there the call's cost decides)
+                    if copy_kernel:
+                        rc = L.qzstd_hip_copy_in(device, C.c_void_p(ln["stream"]), C.c_void_p(ln["d_src"]),
+                                                 C.c_void_p(dv_in + k * cbytes), C.c_size_t(cbytes))
+                    else:
+                        rc = L.qzstd_hip_memcpy_h2d(device, C.c_void_p(ln["stream"]), C.c_void_p(ln["d_src"]),
+                                                    C.c_void_p(h_in + k * cbytes), C.c_size_t(cbytes))
                     rc = rc or L.qzstd_hip_find_sequences(device, C.c_void_p(ln["stream"]), level, C.c_void_p(ln["d_src"]),
                                                           C.c_void_p(ln["dv"][2]), chunk_blocks, block, C.c_void_p(ln["dv"][0]),
                                                           C.c_void_p(ln["dv"][1]), C.c_void_p(ln["d_work"]) if ln["d_work"] else None,
@@ -358,8 +368,8 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
                 "bytes_per_pass": nbytes, "chunk_blocks": chunk_blocks, "chunks_in_flight": depth, "passes": passes,
                 "t_begin": t_begin, "t_end": time.perf_counter(), "device": device,
                 "result_bytes_per_pass": 16 * seqs, "dense_blocks_over_pitch": errs,
-                "what": "pinned host -> H2D -> kernel -> counts + sequences written by the kernel into pinned host memory; "
-                        "%d chunks of %d blocks in flight on separate streams" % (depth, chunk_blocks)}
+                "what": "pinned host -> device memory (%s) -> kernel -> counts + sequences written by the kernel into pinned host memory; "
+                        "%d chunks of %d blocks in flight on separate streams" % ("copy kernel" if copy_kernel else "hipMemcpyAsync", depth, chunk_blocks)}
     except AssertionError as e:
         return {"error": str(e)[:300]}
     finally:
