@@ -1173,6 +1173,7 @@ static int qzSetupSlotService(QZSTD_Slot_T *sl)
     if (sl->vSrc) return 0;
     sl->vSrc = (unsigned char *)qzHostAlloc(QZSTD_HIP_BLOCK_MAX + 64, sl->device, 1);
     sl->vSeqs = (ZSTD_Sequence *)qzHostAlloc(QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP * sizeof(ZSTD_Sequence), sl->device, 1);
+    if (sl->vSeqs) memset(sl->vSeqs, 0, QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP * sizeof(ZSTD_Sequence)); /* (fresh pinned pages may hold marked entries of an earlier life) */
     sl->vCount = (unsigned int *)qzHostAlloc(QZ_SVC_ITEMS_MAX * sizeof(unsigned int), sl->device, 1);
     sl->vdSrc = (unsigned char *)qzstd_hip_malloc(sl->device, QZSTD_HIP_BLOCK_MAX + 64);
     if (!sl->vSrc || !sl->vSeqs || !sl->vCount || !sl->vdSrc) {
@@ -1621,6 +1622,10 @@ static void *qzGrowHostC(void *old, size_t *cap, size_t need, int dev, int coher
     if (old) memset(old, 0, *cap); /* staged caller data: scrubbed before the pages go back */
     qzstd_hip_host_free(old);
     p = qzHostAlloc(need, dev, coherent); /* next to the state's own GPU (the first of the GPUs an announcement is split across) */
+    /* a result area completed by count words: its entries certify themselves by the announcement's epoch, and fresh pinned pages may
+     * hold anything — entries of another announcement's earlier life included, whose epochs count from 1 like everybody's.  Mark 0 is
+     * never valid: the area starts out wiped */
+    if (p && coherent) memset(p, 0, need);
     *cap = p ? need : 0;
     return p;
 }
