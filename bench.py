@@ -546,7 +546,8 @@ def main():
     visible_before = narrow_to_own_gpu(world, local)
     # the plugin asks for 16 hardware queues when it makes the process's first HIP call (csrc/qzstd_kernels.hip, probe_devices: launches of
     # different streams that share a queue run one after the other); here torch starts HIP first, so the variable is set for it
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("QZSTD_HIP_HW_QUEUES") or "16")
+    if os.environ.get("QZSTD_HIP_HW_QUEUES", "16") != "0":  # (0 = leave the runtime's default, as in the library)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("QZSTD_HIP_HW_QUEUES") or "16")
     import torch
     import torch.distributed as dist
 
