@@ -204,3 +204,37 @@ def test_two_workgroups_per_cu_where_the_design_says_so(gpu_plugin):
     L = gpu_plugin.lib
     for level, want in ((1, 2), (2, 2), (3, 1), (4, 1), (5, 2), (6, 2), (9, 2), (12, 2), (0x101, 2), (0x106, 2)):
         assert L.qzstd_hip_occupancy(0, level) == want, (level, L.qzstd_hip_occupancy(0, level), gpu_plugin.err())
+
+
+def test_copy_in_kernel_moves_pinned_bytes_to_device_memory(gpu_plugin):
+    """qzstd_hip_copy_in (round 4: an announcement's staging copy reaches device memory by a kernel on the launch's stream, not by the runtime's
+    copy path): byte-exact for sizes from one 16-byte unit to several MiB — fewer units than lanes, a grid-stride tail, more units than the
+    1024-workgroup grid covers in one step — ordered with what follows on the stream; unaligned or odd-sized requests are refused"""
+    L = gpu_plugin.lib
+    L.qzstd_hip_copy_in.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.qzstd_hip_host_device_ptr.argtypes = [C.c_void_p]
+    L.qzstd_hip_host_device_ptr.restype = C.c_void_p
+    cap = 20 << 20
+    h_in, h_out = L.qzstd_hip_host_alloc(cap), L.qzstd_hip_host_alloc(cap)
+    d = L.qzstd_hip_malloc(0, cap)
+    assert h_in and h_out and d, gpu_plugin.err()
+    try:
+        dv = L.qzstd_hip_host_device_ptr(h_in)
+        assert dv, gpu_plugin.err()
+        data = K.by_name("mix", cap, seed=77)
+        C.memmove(h_in, data, cap)
+        for n in (16, 48, 4096, 16384 + 16, 1 << 20, (1 << 24) + 4096 + 16, cap):
+            C.memset(h_out, 0xEE, n)
+            assert L.qzstd_hip_copy_in(0, None, d, dv, n) == 0, gpu_plugin.err()
+            assert L.qzstd_hip_memcpy_d2h(0, None, h_out, d, n) == 0, gpu_plugin.err()  # (same stream: ordered behind the copy kernel)
+            assert L.qzstd_hip_stream_sync(0, None) == 0, gpu_plugin.err()
+            assert C.string_at(h_out, n) == data[:n], "copy of %d bytes differs" % n
+        # from an offset inside the pinned buffer (a part of an announcement starts at its first block)
+        assert L.qzstd_hip_copy_in(0, None, d, dv + 131072 * 3, 131072) == 0 and L.qzstd_hip_memcpy_d2h(0, None, h_out, d, 131072) == 0
+        assert L.qzstd_hip_stream_sync(0, None) == 0 and C.string_at(h_out, 131072) == data[131072 * 3:131072 * 4]
+        assert L.qzstd_hip_copy_in(0, None, d, dv, 0) == 0
+        assert L.qzstd_hip_copy_in(0, None, d, dv, 24) != 0 and L.qzstd_hip_copy_in(0, None, d, dv + 8, 32) != 0 and L.qzstd_hip_copy_in(0, None, None, dv, 32) != 0
+    finally:
+        L.qzstd_hip_free(0, d)
+        L.qzstd_hip_host_free(h_in)
+        L.qzstd_hip_host_free(h_out)
