@@ -95,3 +95,24 @@ def test_the_point_of_it_a_faster_library(shim):
         pytest.skip("the exported libzstd here is not Pillow's slow build")
     fast, slow = child(shim, "rate")["MBps"], child(slow_path, "rate")["MBps"]
     assert fast >= 1.5 * slow, (fast, slow)
+
+
+def test_front_end_binds_to_its_own_libzstd_when_another_one_is_preloaded():
+    """under a tool that preloads libraries (rocprofv3 brings the system's libzstd 1.4.8 in through libdw) another libzstd sits in front of
+    the one Zstd() loads; the front-end library's ZSTD_* references would bind to it and QZSTD_createFront fail on a parameter 1.4.8 does
+    not know.  tools/qz_bind.py: Front() notices and binds the library to its own dependencies first (RTLD_DEEPBIND).  On CPU the producer
+    reports "device down" and libzstd falls back to its own match-finder: the frames still have to round-trip"""
+    old = [p for p in ("/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/lib/x86_64-linux-gnu/libzstd.so.1") if os.path.exists(p)]
+    if not old or not os.path.isfile(B.FRONT_SO):
+        pytest.skip("no second libzstd to preload, or the front-end library is not built")
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import qz_bind as B, qz_corpus as K
+z = B.Zstd(); plug = B.Plugin(); f = B.Front()
+data = K.by_name("system", 5 * 131072 + 11, seed=3)
+frames, st, fs = f.frames(data, 131072, 1, 3)
+assert b"".join(z.decompress(fr, 131072) for fr in frames) == data
+print("ok")
+""" % os.path.join(B.ROOT, "tools")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, LD_PRELOAD=old[0]))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]

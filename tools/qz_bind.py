@@ -506,7 +506,19 @@ class Front:
     def __init__(self, path: str = FRONT_SO):
         if not os.path.isfile(path):
             raise OSError("%s missing: `make -C qat-zstd-plugin_amd front` needs a libzstd >= 1.5.4" % path)
-        F = self.lib = C.CDLL(path)
+        # The library's ZSTD_* references bind through the process's global scope first: normally that is the libzstd Zstd() loaded
+        # (RTLD_GLOBAL).  Under a tool that preloads libraries (rocprofv3: libdw -> the system's libzstd 1.4.8) ANOTHER libzstd sits in
+        # front of it, and the front-end's ZSTD_CCtx_setParameter(ZSTD_c_enableSeqProducerFallback) would go to a library that does not
+        # know the parameter: then the library is bound to its own dependencies first (RTLD_DEEPBIND: the libzstd it was linked against).
+        mode = C.DEFAULT_MODE
+        try:
+            want = C.cast(Zstd().lib.ZSTD_versionNumber, C.c_void_p).value
+            seen = C.cast(C.CDLL(None).ZSTD_versionNumber, C.c_void_p).value
+            if seen != want:
+                mode |= os.RTLD_DEEPBIND
+        except (AttributeError, OSError):
+            pass
+        F = self.lib = C.CDLL(path, mode=mode)
         F.QZSTD_createFront.restype = C.c_void_p
         F.QZSTD_createFront.argtypes = [C.POINTER(FrontParams)]
         F.QZSTD_frontFrameStride.restype = C.c_size_t
