@@ -1013,18 +1013,22 @@ static int qzTakeMarked(ZSTD_Sequence *dst, const ZSTD_Sequence *q, size_t n, un
 static int qzBlocksWait(const QZSTD_Hint_T *h, size_t b0, size_t b1)
 {
     const unsigned long t0 = qzNowNs(), limit = (unsigned long)gProc.timeoutMs * 1000000ul;
+    unsigned long spinNs = 50000ul;
     size_t b = b0;
     for (;;) {
         unsigned long el;
         while (b < b1 && __atomic_load_n(&h->hCount[b], __ATOMIC_ACQUIRE) != QZ_COUNT_PENDING) b++;
         if (b >= b1) return 0;
         el = qzNowNs() - t0;
+        if (el < 1000ul && 2 * __atomic_load_n(&gProc.liveStates, __ATOMIC_RELAXED) > 3 * qzUsableCores()) spinNs = 0ul; /* (decided once, at the first miss) */
         if (el > limit) {
             qzCause = QZ_CAUSE_TIMEOUT;
             QZ_LOG(1, "announcement: block %zu still not published after %d ms\n", b, gProc.timeoutMs);
             return 1;
         }
-        if (el > 50000ul) { /* 50 us of polling, then naps: a waiting caller does not burn a core others could entropy-code on */
+        /* 50 us of polling, then naps: a waiting caller does not burn a core others could entropy-code on; with far more callers than
+         * cores (states alive > 1.5 x usable cores) no polling at all (front-end, 64 workers on 16 cores: 4.4 GB/s polling) */
+        if (el > spinNs) {
             const struct timespec nap = { 0, el < 20000000ul ? 20000l : 200000l };
             nanosleep(&nap, NULL);
         }
