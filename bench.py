@@ -881,9 +881,10 @@ def main():
                         if "MBps_wall" in sw14l:
                             pl["speedup_vs_libzstd_1_4"] = round(pl["MBps_wall"] / max(sw14l["MBps_wall"], 1e-9), 2)
                     # the batch front-end at that level (its defaults: 2 MiB claims at levels 1-4, uniform 4 MiB claims at the chain levels), one
-                    # 128 MiB buffer (level 12: the web-log corpus in 32 KiB chunks, BASELINE config 4's shape), median pass of about 1.5 s
+                    # 512 MiB buffer (level 12: 256 MiB of the web-log corpus in 32 KiB chunks, BASELINE config 4's shape) — a pass over 128 MiB
+                    # takes 6 ms at level 3 and is all ramp and tail —, median pass of about 1.5 s
                     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
-                        f.write(K.weblog(4, 64 * K.MiB) * 2 if lv == 12 else shard[:1024 * block])
+                        f.write(K.weblog(4, 64 * K.MiB) * 4 if lv == 12 else shard[:4096 * block])
                         fl = f.name
                     fe = measured(lambda l: frontbench(fl, blk, lv, base_t, 1, loops=l, seg_mib=0), 1.5)
                     os.unlink(fl)
