@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--e2e-threads", type=int, default=0, help="front-end worker threads per rank (0 = the rank's share of the usable host cores + an eighth)")
     ap.add_argument("--kernel-only", action="store_true", help="only the roofline leg (K timed launches of the dominant kernel, resident input): what "
                     "tools/prof_stats.sh / prof_pmc.sh run under rocprofv3, so that the profile holds these launches and no others")
+    ap.add_argument("--allow-slow-libzstd", action="store_true", help="run the metric even when the callers' libzstd is the image's 4x slower Pillow build "
+                    "(default: refuse — every end-to-end number and cpu_baseline would be that build's)")
     ap.add_argument("--product-multi-gpu", type=int, default=0, help=argparse.SUPPRESS)  # internal: only that leg, in a process that sees every GPU
     return ap.parse_args()
 
@@ -95,6 +97,63 @@ def load_corpus(name: str, size: int) -> tuple[bytes, str]:
     raw = K.by_name(name, unit, seed)
     reps = -(-size // len(raw))
     return (raw * reps)[:size], "synthetic:%s(seed=%d,%d B) repeated" % (name, seed, unit)
+
+
+SLIM_LINE_MAX = 4096  # the driver parses the LAST stdout line; round 4's 20 KB line came back as parsed = null
+
+
+def _short(x, n):
+    x = str(x)
+    return x if len(x) <= n else x[:n - 1] + "~"
+
+
+def slim_line(out: dict, details_file: str | None) -> dict:
+    """The measurement of record: ONE short JSON line (the shape of the reference's one-line report, test/benchmark.c:374-382) with the
+    contract's keys and nothing else; every side leg lives in the details file the line names.  Raises when the line would not fit."""
+    cfg, rf, cb = out.get("config", {}), out.get("roofline", {}), out.get("cpu_baseline")
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype")}
+    line["data"] = _short(out.get("data", "synthetic"), 120)
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 420)}
+    for k in ("level", "block_bytes", "chunks_per_gpu_per_step", "threads_per_rank", "libzstd"):
+        line["config"][k] = cfg.get(k)
+    line["config"]["libzstd_build"] = _short(cfg.get("libzstd_build", ""), 160)
+    line["config"]["libzstd_fast_build"] = cfg.get("libzstd_fast_build")
+    line["config"]["parallelism"] = _short(cfg.get("parallelism", ""), 120)
+    line["config"]["cpu_binding_rank0"] = {k: v if not isinstance(v, str) else _short(v, 80) for k, v in (cfg.get("cpu_binding_rank0") or {}).items()}
+    line["config"]["producer_errors"] = (out.get("e2e", {}).get("producer_errors") or {}).get("total")
+    line["config"]["roundtrip_sampled"] = out.get("e2e", {}).get("roundtrip_sampled")
+    line["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg",
+                                               "algorithmic_bytes_per_launch", "launches_timed")}
+    line["roofline"]["launch_workload"] = _short(rf.get("launch_workload", ""), 160)
+    if cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")}
+        line["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 360)
+    else:
+        line["cpu_baseline"] = None  # (--no-cpu, or N > 1: the CPU legs run on rank 0 at N = 1 only)
+    line["vs_cpu_baseline"] = out.get("vs_cpu_baseline")
+    line["details_file"] = details_file
+    n = len(json.dumps(line))
+    if n >= SLIM_LINE_MAX:
+        raise AssertionError("bench line is %d bytes (limit %d): move keys to the details file" % (n, SLIM_LINE_MAX))
+    return line
+
+
+def write_details(out: dict) -> str | None:
+    """every leg of the run, pretty-printed: bench_details.json next to bench.py (and a copy under gpurun_out/ when that exists, so that a
+    gpurun call brings it back)"""
+    name = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_details.json"), "w") as f:
+                    json.dump(out, f, indent=1)
+                name = name or os.path.relpath(os.path.join(d, "bench_details.json"), ROOT)
+            except OSError:
+                pass
+    return name
+
+
 
 
 # ----------------------------------------------------------------------------- CPU legs
@@ -543,6 +602,12 @@ def main():
         data, _ = load_corpus(a.corpus, a.block * 4096)
         print(json.dumps(product_multi_gpu_leg(plug, data, a.block, a.level, a.product_multi_gpu)))
         return
+    zpath = B.find_libzstd()
+    if "pillow.libs" in zpath and not a.allow_slow_libzstd and not a.kernel_only:
+        # (round-4 verdict, weak 11: the headline must not silently fall back to the 4x slower build)
+        raise SystemExit("bench.py: the callers' libzstd would be %s — the image's slow build (tools/zstdshim over pyarrow's libarrow.so did not "
+                         "resolve: %s). Every ZSTD_compress2 number of this run, cpu_baseline included, would be that build's; pass "
+                         "--allow-slow-libzstd to measure anyway." % (zpath, "QZ_ZSTD_NO_SHIM is set" if os.environ.get("QZ_ZSTD_NO_SHIM") else "see tools/zstdshim/zstdshim.c"))
     visible_before = narrow_to_own_gpu(world, local)
     # the plugin asks for 16 hardware queues when it makes the process's first HIP call (csrc/qzstd_kernels.hip, probe_devices: launches of
     # different streams that share a queue run one after the other); here torch starts HIP first, so the variable is set for it
@@ -675,7 +740,8 @@ def main():
                                    "threads per rank (usable host cores %.0f / %d rank(s), plus an eighth), 2 MiB announcements; host buffers in, frames out"
                                    % (level & 0xFF, block >> 10, e2e_nb, len(e2e_buf) >> 20, e2e_info["producer_errors"]["total"], e2e_threads, quota, world),
                        "corpus": prov[:300], "level": level, "block_bytes": block, "chunks_per_gpu_per_step": e2e_nb,
-                       "threads_per_rank": e2e_threads, "libzstd": B.Zstd().version(), "libzstd_build": B.libzstd_build(B.find_libzstd()), "cpu_binding_rank0": cpu_binding,
+                       "threads_per_rank": e2e_threads, "libzstd": B.Zstd().version(), "libzstd_build": B.libzstd_build(B.find_libzstd()),
+                       "libzstd_fast_build": "pillow.libs" not in B.find_libzstd(), "cpu_binding_rank0": cpu_binding,
                        "parallelism": "block-sharded x%d (one process per GPU, each rank's plugin sees its own GPU only), no collective" % world},
             "e2e": dict(e2e_info, served_by_gpu=served_by_gpu, pass_s_median=round(srt[len(srt) // 2], 4), pass_s_min=round(srt[0], 4),
                         pass_s_max=round(srt[-1], 4),
@@ -931,7 +997,12 @@ def main():
                     out["product_multi_gpu"] = json.loads(line[-1]) if line else {"error": (r.stdout + r.stderr)[-300:]}
                 except Exception as e:  # noqa: BLE001
                     out["product_multi_gpu"] = {"error": repr(e)[:300]}
-        print(json.dumps(out))
+        details = write_details(out)
+        for k in out:  # the side legs, one earlier line per key ('# ' in front: not the line of record)
+            if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+                print("# %s: %s" % (k, json.dumps(out[k])))
+        print(json.dumps(slim_line(out, details)))  # the LAST stdout line, < 4 KB: what the driver parses
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()  # rank 0's product leg uses every GPU: the others keep still until it is done
         dist.destroy_process_group()

@@ -1,0 +1,70 @@
+"""bench.py's line of record: the LAST stdout line must be one short JSON object with the contract's keys (round-4 verdict: a 20 KB
+line came back from the driver as parsed = null).  Shape to match: the reference's one-line report, /root/reference/test/benchmark.c:374-382."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+       "config", "roofline", "cpu_baseline", "vs_cpu_baseline", "details_file")
+CONFIG = ("workload", "level", "block_bytes", "chunks_per_gpu_per_step", "threads_per_rank", "libzstd", "libzstd_build")
+ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg", "algorithmic_bytes_per_launch")
+CPU = ("value", "unit", "cores", "kind", "sample")
+
+
+def canned():
+    """the full result object of round 4's run (20 KB, 30 side legs): what slim_line has to cut down"""
+    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as f:
+        return json.load(f)
+
+
+def test_slim_line_has_the_contract_keys_and_fits():
+    import bench
+    out = canned()
+    assert len(json.dumps(out)) > 15000  # the canned object IS the oversized one
+    line = bench.slim_line(out, "bench_details.json")
+    s = json.dumps(line)
+    assert len(s) < 4096 and "\n" not in s
+    assert set(TOP) == set(line)
+    assert all(k in line["config"] for k in CONFIG)
+    assert all(k in line["roofline"] for k in ROOFLINE)
+    assert all(k in line["cpu_baseline"] for k in CPU)
+    assert line["value"] == out["value"] and line["roofline"]["frac"] == out["roofline"]["frac"]
+    assert line["cpu_baseline"]["value"] == out["cpu_baseline"]["value"]
+    assert line["vs_cpu_baseline"] == out["vs_cpu_baseline"]
+    assert json.loads(s) == line  # a round trip through the text the driver sees
+
+
+def test_slim_line_survives_long_strings_and_missing_cpu_legs():
+    import bench
+    out = canned()
+    out["config"]["workload"] = "w" * 5000
+    out["config"]["libzstd_build"] = "b" * 5000
+    out["cpu_baseline"]["sample"] = "s" * 5000
+    out["data"] = "d" * 5000
+    assert len(json.dumps(bench.slim_line(out, "x.json"))) < 4096
+    out.pop("cpu_baseline")
+    out.pop("vs_cpu_baseline")
+    line = bench.slim_line(out, None)  # --no-cpu / N > 1
+    assert line["cpu_baseline"] is None and line["vs_cpu_baseline"] is None
+
+
+def test_slim_line_refuses_to_grow(monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "SLIM_LINE_MAX", 512)
+    with pytest.raises(AssertionError):
+        bench.slim_line(canned(), "bench_details.json")
+
+
+def test_write_details_names_a_file(tmp_path, monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.mkdir(tmp_path / "gpurun_out")
+    name = bench.write_details({"a": 1})
+    assert name == "bench_details.json"
+    assert json.load(open(tmp_path / "bench_details.json")) == {"a": 1}
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_details.json")) == {"a": 1}
