@@ -912,7 +912,6 @@ def main():
                     row[name] = {k: r.get(k) for k in ("MBps_wall", "latency_us_p50", "producer_errors", "error") if k in r}
                 sweep.append(row)
             out["e2e_sweep_indicative"] = {"rows": sweep, "note": "about a second of passes each, median pass: how the rates move past usable_cores threads (the other keys here: short single runs)",
-                                           "lookahead_optin_%d_threads" % base_t: slim(c_benchmark(fname, block, level, base_t, mode=1, loops=4, env={"QZSTD_HIP_LOOKAHEAD": "1"})),
                                            "unchanged_callers_launch_path_%d_threads" % base_t:
                                                slim(c_benchmark(fname, block, level, base_t, mode=1, loops=4, env={"QZSTD_HIP_SERVICE": "0"})),
                                            "frontend_%d_threads" % t_more: slim(frontbench(fbig, block, level, t_more, 1, loops=3, seg_mib=2)),

@@ -118,21 +118,31 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
  * callbacks of these blocks have come — what a compress call's const source promises anyway, here promised from the
  * announcement on — and the per-callback memcmp against the staged copy is skipped (6-8 us of every 128 KiB callback; the
  * batch front-end, include/qzstd_frontend.h, announces this way: its source is the const argument of one call).  Blocks are
- * then matched by ADDRESS only.  Breaking the promise produces frames that do not decode to the input: use it only for
- * memory nobody else writes.  Unknown flag bits are refused (-1). */
+ * then matched by ADDRESS only, every block is served ONCE, going forward, and the announcement ends at the first callback that does
+ * not look like its announcer walking it (see "Lifetime" below).  Breaking the promise while the announcement is alive produces
+ * frames that do not decode to the input: use it only for memory nobody else writes, and end it with QZSTD_dropHints() when the
+ * job is over.  Every 16th block served from a STABLE announcement is compared with the staged copy anyway (0.5 us per block on
+ * average): a mismatch ends the announcement, the block is match-found afresh and QZSTD_hintBroken() counts it — a sampled check
+ * that reveals a caller who does not keep the promise, not a guarantee.  Unknown flag bits are refused (-1). */
 #define QZSTD_HINT_STABLE 1u
 int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcSize,
                        size_t blockSize, int compressionLevel, unsigned int flags);
 
-/* Transparent look-ahead (no API, OPT-IN): with the environment variable QZSTD_HIP_LOOKAHEAD=1 (or 2: always through a
- * pipe) set before QZSTD_startQatDevice(), a state whose caller announces nothing guesses, after a callback that had
- * to wait for the GPU, that the bytes BEHIND that callback's block are the next blocks.  It reads them with a
- * fault-safe copy (process_vm_readv on itself, or write/read through a close-on-exec pipe; unreadable memory ends the
- * copy) — never past the end of the memory mapping that holds the block the callback named — match-finds them ahead of
- * time, and serves a later callback from the guess only if its address sits on the guessed grid and its bytes still
- * equal the copy.  It therefore READS (never writes) process memory the caller did not hand over, which is why it is
- * off unless asked for; the first guess is logged at debug level 1, and staged copies are zeroed before their pinned
- * pages are released.  Default (unset or 0): the library touches nothing but [src, src + srcSize) of each callback. */
+/* Lifetime of an announcement — bounded, whatever the caller does: it ends when the callback of its last block has come; when a
+ * callback finds its bytes changed (verified announcements); when a callback asks a STABLE announcement for a block a second time or
+ * off its grid (a buffer that is being used again); when one of its blocks could not be served (a STABLE one ends there, a verified
+ * one only if that was its last block); when a newer announcement names addresses it covers; after 16 callbacks in a row it could not
+ * serve; at QZSTD_dropHints(); with its state.  A state keeps at most four; callbacks look at the newest first.
+ *
+ * QZSTD_dropHints(state): every announcement of the state ends now (launches in flight are waited for).  Call it when the job
+ * the announcements belonged to is over — in particular before a buffer announced with QZSTD_HINT_STABLE is rewritten or freed
+ * while callbacks for some of its blocks never came (libzstd does not call the producer for blocks below 7 bytes, nor after an
+ * error).  The batch front-end does, at the end of every QZSTD_frontCompress. */
+void QZSTD_dropHints(void *sequenceProducerState);
+
+/* The library reads nothing but [src, src + srcSize) of a callback or an announcement: the opt-in "transparent look-ahead" of
+ * rounds 1-4 (QZSTD_HIP_LOOKAHEAD: guessed reads behind a callback's block) is gone — it lost to the resident service at every
+ * level but one and read memory the caller never handed over; the variable is ignored. */
 
 /* Time-out (reference: 2 s of polling, src/qatseqprod.c:1099-1104): a request that is still running after
  * QZSTD_HIP_TIMEOUT_MS (default 2000) returns ZSTD_SEQUENCE_PRODUCER_ERROR, so that ZSTD_c_enableSeqProducerFallback
@@ -141,6 +151,8 @@ int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcS
 /* Diagnostics for the above: stats[0] = blocks served from an announcement, [1] = blocks that took
  * the per-block path, [2] = announcements accepted, [3] = microseconds spent waiting for the GPU. */
 void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4]);
+/* blocks of QZSTD_HINT_STABLE announcements whose sampled comparison with the staged copy failed (a broken promise: see above) */
+unsigned long QZSTD_hintBroken(void *sequenceProducerState);
 
 /* Callbacks of this state that returned ZSTD_SEQUENCE_PRODUCER_ERROR, by cause — with ZSTD_c_enableSeqProducerFallback = 1
  * libzstd compresses such a block with its own match-finder and says nothing, so this is the only place they show (the

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+extern int zstdshim_ok(void) __attribute__((weak)); /* tools/zstdshim, when that is the libzstd in the process; else absent */
+
 #define QF_NONE ((size_t)-1)
 #define QF_HINT_MAX ((size_t)16 << 20)
 #define QF_AHEAD_MAX 3u
@@ -129,7 +131,7 @@ static void *qfWorker(void *arg)
                 more = qfClaim(f, claims, &q[n]);
                 if (!more) break;
                 claims++;
-                qfAnnounce(f, w, &q[n]);
+                if (!bad) qfAnnounce(f, w, &q[n]);
                 n++;
             }
             if (n == 0) break;
@@ -137,6 +139,10 @@ static void *qfWorker(void *arg)
             memmove(&q[0], &q[1], (n - 1) * sizeof(q[0]));
             n--;
         }
+        /* the job is over for this worker: whatever it announced ends here.  An announcement otherwise lives until the callback of its
+         * last block — which never comes for a last block below 7 bytes (libzstd does not ask the producer), after a failed part, or
+         * after `bad` — and a STABLE one would serve the NEXT job by address if the caller used the same buffer again (round-4 ADVICE) */
+        if (f->p.useProducer && w->state) QZSTD_dropHints(w->state);
         pthread_mutex_lock(&f->mu);
         if (bad) f->failed = 1;
         if (--f->running == 0) pthread_cond_signal(&f->cvDone);
@@ -151,6 +157,10 @@ QZSTD_Front *QZSTD_createFront(const QZSTD_FrontParams *p)
     int t, made = 0;
     size_t seg;
     if (!p || p->nThreads < 1 || p->nThreads > 1024 || p->level < 1 || p->level > 12 || p->chunkSize == 0) return NULL;
+    /* the libzstd this was linked against must be one that works: when it is tools/zstdshim (tests and bench only) and its look-up of
+     * libarrow.so's copy failed, every ZSTD_* call would abort() the process — refuse instead; and the producer API needs >= 1.5.4 */
+    if (zstdshim_ok && zstdshim_ok() != 1) return NULL;
+    if (ZSTD_versionNumber() < 10504u) return NULL;
     f = (QZSTD_Front *)calloc(1, sizeof(*f));
     if (!f) return NULL;
     f->p = *p;

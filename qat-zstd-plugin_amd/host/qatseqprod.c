@@ -27,7 +27,7 @@
  * No QAT / icp_sal / cpa symbol is used or emulated.
  */
 #ifndef _GNU_SOURCE
-#define _GNU_SOURCE /* process_vm_readv, pipe2, F_GETPIPE_SZ: the fault-safe read behind the opt-in transparent look-ahead */
+#define _GNU_SOURCE /* SYS_getcpu, sched_getaffinity */
 #endif
 #include "qatseqprod.h"
 #include "qzstd_hip.h"
@@ -43,7 +43,6 @@
 #include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <sys/types.h>
-#include <sys/uio.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -176,8 +175,6 @@ typedef struct {
     QZSTD_Coalescer_T *coal; /* one per device */
     int coalesce;            /* QZSTD_HIP_COALESCE (default 1) */
     int levelFlags;          /* QZSTD_HIP_LEVEL_REPCODES when QZSTD_HIP_EXT_REPCODES=1 */
-    int lookahead;           /* transparent look-ahead (opt-in): 0 off, 1 fault-safe read by process_vm_readv, 2 through a pipe */
-    int lookaheadLogged;
     int timeoutMs;           /* QZSTD_HIP_TIMEOUT_MS */
     int split;               /* QZSTD_HIP_SPLIT: announced buffers are split across this many GPUs (default: all) */
     int splitBlocks;         /* QZSTD_HIP_SPLIT_BLOCKS (default 1): per-block requests of segmentable levels go as segments */
@@ -205,7 +202,9 @@ typedef struct {
                                     * memory, 0.96 ms over the bus; hipMemcpyAsync holds the caller 0.8-1.1 ms per 4 MiB) */
 } QZSTD_Process_T;
 
-static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DEFAULT_TIMEOUT_MS, 0, 1, 1, 4096, 400, { { 0 } }, PTHREAD_MUTEX_INITIALIZER, 1, -1, { 0 }, { 0 }, 0, 0, 0, 1, 0 };
+static QZSTD_Process_T gProc = { .status = QZSTD_FAIL, .coalesce = 1, .timeoutMs = QZ_DEFAULT_TIMEOUT_MS, .splitBlocks = 1, .service = 1,
+                                 .svcItemBytes = 4096, .svcSpinUs = 400, .mutex = PTHREAD_MUTEX_INITIALIZER, .numa = 1, .numaThreadNode = -1,
+                                 .hintFlags = 1 };
 
 /* One announced buffer: staged in pinned memory, match-found asynchronously — split into contiguous block ranges, one
  * per GPU, each on a slot's stream — results (count + the first QZ_HINT_PITCH sequences of every block) written by
@@ -214,10 +213,7 @@ static QZSTD_Process_T gProc = { QZSTD_FAIL, 0, 0, NULL, NULL, 1, 0, 0, 0, QZ_DE
 #define QZ_HINT_PITCH ((size_t)16384) /* blocks with more sequences take the per-block path */
 #define QZ_HINT_PARTS 8
 #define QZ_COUNT_PENDING 0xFFFFFFFDu /* an announced block's count word until its workgroup publishes it (gProc.hintFlags) */
-#define QZ_HINTS 6
-#define QZ_IS_GUESS(k) ((k) == 2 || (k) == 3)
-#define QZ_ANNOUNCED 4
-static const int kAnnounced[QZ_ANNOUNCED] = { 0, 1, 4, 5 };
+#define QZ_HINTS 4 /* announcements a state keeps: a ring (QZSTD_hintSource) */
 #define QZ_CONTENT_LOOKUP_BLOCKS 256u /* announcements with more grid blocks are matched by address only */
 typedef struct {
     int st;   /* 0 none, 1 in flight on the GPU (slot held), 2 ready, 3 failed */
@@ -232,6 +228,8 @@ typedef struct {
     int touched; /* a callback was served from it */
     unsigned int epoch; /* count-word completion: the mark (24 bits, never 0) every entry of THIS announcement carries in its fourth word */
     int stable;  /* QZSTD_HINT_STABLE: the announcer holds the bytes still until their callbacks have come (no memcmp per callback) */
+    unsigned int seq;   /* the state's announcement number (QZSTD_Session_T.hintSeq): callbacks look at the newest announcement first */
+    size_t servedUpTo;  /* grid blocks below this one have been served: a STABLE announcement serves every block once, going forward */
     unsigned misses; /* callbacks that found nothing to serve since the announcement was last used */
     int nParts;
     QZSTD_Part_T part[QZ_HINT_PARTS];
@@ -272,29 +270,22 @@ typedef struct {
     unsigned int failOffloadCnt;
     /* look-ahead batches served to later callbacks (QZSTD_hintSource): two, so that the GPU can
      * work on the next buffer while libzstd entropy-codes the current one on this thread */
-    QZSTD_Hint_T hint[QZ_HINTS]; /* [0..1] and [4..5] announced by the caller (a ring of four: kAnnounced), [2..3] speculative (transparent
-                                  * look-ahead, opt-in) */
-    int hintNext, autoNext;
-    unsigned autoDepth, autoBackoff, autoFails; /* blocks to speculate on, callbacks to sit out, misses in a row */
-    int autoOutstanding;                        /* a guess was launched and nothing has been served from it yet */
-    int pipeFd[2];                              /* the fault-safe read's pipe (mode 2), -1 = not opened */
-    size_t pipeChunk;
-    uintptr_t mapLo, mapHi;                     /* the caller's mapping the last guess was confined to */
-    unsigned long autoLaunched, autoServed;
+    QZSTD_Hint_T hint[QZ_HINTS]; /* announced by the caller, a ring of four */
+    int hintNext;                /* the ring slot the next announcement tries first */
+    unsigned int hintSeq;        /* announcements made so far: every one gets the next number (the look-up goes newest first) */
+    unsigned int stableSampler;  /* blocks looked up in STABLE announcements: every 16th is compared with the staged copy all the same */
+    unsigned long stableBroken;  /* ... and differed (QZSTD_hintBroken) */
     unsigned long servedFromBatch, servedSync, servedService;
     unsigned long fail[QZ_CAUSE_N]; /* callbacks that returned the error code, by cause ([0] = all of them) */
     unsigned long redoneAlone;      /* blocks too dense for a batch's result area, redone on a slot of their own (not errors) */
     unsigned long hintCalls, hintStageNs, hintQueueNs, hintWaitNs, hintCopyCallNs, hintLaunchCallNs, hintPrepNs, hintDropNs; /* event log only */
 } QZSTD_Session_T;
 
-#define QZ_AUTO_DEPTH_MIN 2u  /* transparent look-ahead: blocks guessed ahead, doubling while guesses are consumed */
-#define QZ_AUTO_DEPTH_MAX 32u
 #define QZ_HINT_STALE_MISSES 16u /* an announcement that was used and then missed this often is dropped */
-static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block);
 static void qzReapOrphans(int force);
 static size_t qzFailed(QZSTD_Session_T *s, int cause);
-static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t blockSize, int compressionLevel);
 static void *qzGrowDev(int dev, void *old, size_t *cap, size_t need);
+static int qzUsableCores(void);
 
 /* cheap fingerprint of a block: its size and its first and last 8 bytes (a candidate is always verified with memcmp) */
 static unsigned long long qzBlockKey(const unsigned char *p, size_t n)
@@ -834,18 +825,7 @@ int QZSTD_startQatDevice(void)
         gProc.svcSpinSet = getenv("QZSTD_HIP_SERVICE_SPIN_US") != NULL;
         gProc.hintFlags = qzEnvInt("QZSTD_HIP_HINT_FLAGS", 1, 0, 1);
         gProc.hintDirect = qzEnvInt("QZSTD_HIP_HINT_DIRECT", 0, 0, 3);
-        {
-            /* The transparent look-ahead READS memory behind the block a callback names, so it is strictly opt-in:
-             * QZSTD_HIP_LOOKAHEAD = 0 / unset: off; 1: on; 2: on and always through a pipe.  It needs a fault-safe read:
-             * process_vm_readv is only tried where no seccomp filter could make an unusual system call fatal, and only
-             * kept if a probe on ourselves works; otherwise the pipe. */
-            char probe[16] = "qzstd", back[16];
-            const int want = qzEnvInt("QZSTD_HIP_LOOKAHEAD", 0, 0, 2);
-            gProc.lookahead = want;
-            if (want == 1 && (prctl(PR_GET_SECCOMP, 0, 0, 0, 0) != 0 || qzSafeRead(back, probe, 16, 16) != 16 ||
-                              memcmp(back, probe, 16) != 0))
-                gProc.lookahead = 2;
-        }
+        (void)qzUsableCores(); /* (read once here, under the process mutex: the waits only load it) */
     }
     if (gProc.status == QZSTD_FAIL) {
         /* runtime up? (reference: QZSTD_salUserStart, :498-527) */
@@ -886,11 +866,12 @@ void QZSTD_stopQatDevice(void)
 /* the cores this process may use: its affinity mask, capped by a cgroup CPU quota (cpu.max) */
 static int qzUsableCores(void)
 {
-    static int cached;
+    static int cached; /* written once with the same value by whoever gets here first (QZSTD_startQatDevice does, under the process mutex) */
     int n = 0;
     cpu_set_t set;
     FILE *f;
-    if (cached) return cached;
+    if ((n = __atomic_load_n(&cached, __ATOMIC_RELAXED)) != 0) return n;
+    n = 0;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
     if (n <= 0) n = (int)sysconf(_SC_NPROCESSORS_ONLN);
     f = fopen("/sys/fs/cgroup/cpu.max", "re");
@@ -903,8 +884,9 @@ static int qzUsableCores(void)
         }
         fclose(f);
     }
-    cached = n > 0 ? n : 1;
-    return cached;
+    n = n > 0 ? n : 1;
+    __atomic_store_n(&cached, n, __ATOMIC_RELAXED);
+    return n;
 }
 
 void *QZSTD_createSeqProdState(void)
@@ -912,7 +894,6 @@ void *QZSTD_createSeqProdState(void)
     QZSTD_Session_T *s = (QZSTD_Session_T *)calloc(1, sizeof(QZSTD_Session_T));
     if (!s) return NULL;
     s->slotHint = -1;
-    s->pipeFd[0] = s->pipeFd[1] = -1;
     __atomic_fetch_add(&gProc.liveStates, 1, __ATOMIC_RELAXED);
     return s;
 }
@@ -1013,21 +994,26 @@ static int qzTakeMarked(ZSTD_Sequence *dst, const ZSTD_Sequence *q, size_t n, un
 static int qzBlocksWait(const QZSTD_Hint_T *h, size_t b0, size_t b1)
 {
     const unsigned long t0 = qzNowNs(), limit = (unsigned long)gProc.timeoutMs * 1000000ul;
+    /* 50 us of polling, then naps: a waiting caller does not burn a core others could entropy-code on; with far more callers than
+     * cores (states alive > 1.5 x usable cores) no polling at all (front-end, 64 workers on 16 cores: 4.4 GB/s polling).
+     * Decided once, at the first miss (round-4 ADVICE: not by how long the first scan happened to take) */
     unsigned long spinNs = 50000ul;
+    int decided = 0;
     size_t b = b0;
     for (;;) {
         unsigned long el;
         while (b < b1 && __atomic_load_n(&h->hCount[b], __ATOMIC_ACQUIRE) != QZ_COUNT_PENDING) b++;
         if (b >= b1) return 0;
+        if (!decided) { /* at the first miss, whenever that is */
+            decided = 1;
+            if (2 * __atomic_load_n(&gProc.liveStates, __ATOMIC_RELAXED) > 3 * qzUsableCores()) spinNs = 0ul;
+        }
         el = qzNowNs() - t0;
-        if (el < 1000ul && 2 * __atomic_load_n(&gProc.liveStates, __ATOMIC_RELAXED) > 3 * qzUsableCores()) spinNs = 0ul; /* (decided once, at the first miss) */
         if (el > limit) {
             qzCause = QZ_CAUSE_TIMEOUT;
             QZ_LOG(1, "announcement: block %zu still not published after %d ms\n", b, gProc.timeoutMs);
             return 1;
         }
-        /* 50 us of polling, then naps: a waiting caller does not burn a core others could entropy-code on; with far more callers than
-         * cores (states alive > 1.5 x usable cores) no polling at all (front-end, 64 workers on 16 cores: 4.4 GB/s polling) */
         if (el > spinNs) {
             const struct timespec nap = { 0, el < 20000000ul ? 20000l : 200000l };
             nanosleep(&nap, NULL);
@@ -1071,9 +1057,9 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
     int k;
     if (!s) return;
     __atomic_fetch_sub(&gProc.liveStates, 1, __ATOMIC_RELAXED);
-    QZ_LOG(2, "state %p: %lu block(s) served from a look-ahead batch (%lu of them speculative, %lu speculation(s)), %lu per "
+    QZ_LOG(2, "state %p: %lu block(s) served from announcements, %lu per "
               "block; %lu hint(s), timers from the 9th on: drop %.2f ms, buffers %.2f ms, staging %.2f ms, queueing %.2f ms (%.2f ms of it in the copy call, %.2f in the launch call), waited %.2f ms for the GPU\n", (void *)s,
-           s->servedFromBatch, s->autoServed, s->autoLaunched, s->servedSync, s->hintCalls, s->hintDropNs / 1e6, s->hintPrepNs / 1e6, s->hintStageNs / 1e6,
+           s->servedFromBatch, s->servedSync, s->hintCalls, s->hintDropNs / 1e6, s->hintPrepNs / 1e6, s->hintStageNs / 1e6,
            s->hintQueueNs / 1e6, s->hintCopyCallNs / 1e6, s->hintLaunchCallNs / 1e6, s->hintWaitNs / 1e6);
     for (k = 0; k < QZ_HINTS; k++) {
         qzHintDrop(&s->hint[k]);
@@ -1086,8 +1072,6 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState)
         qzstd_hip_host_free(s->hint[k].hDesc);
         free(s->hint[k].keys);
     }
-    if (s->pipeFd[0] >= 0) close(s->pipeFd[0]);
-    if (s->pipeFd[1] >= 0) close(s->pipeFd[1]);
     free(s);
 }
 
@@ -1434,40 +1418,55 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     if (!qzDeviceUsable(s)) return qzFailed(s, QZ_CAUSE_DEVICE_DOWN);
     qzCause = QZ_CAUSE_RUNTIME; /* until a failing site below says otherwise */
 
-    /* look-ahead batch hit?  (src, srcSize) must start on an announced (k < 2) or guessed (k >= 2) block grid and
+    /* Served from an announcement?  (src, srcSize) must start on an announced block grid and
      * cover one or more whole blocks of it: libzstd 1.5.7 cuts multi-block frames into blocks of 32..128 KiB at 32 KiB
      * steps, so a finer grid serves several sizes — independently parsed neighbours are simply concatenated, the trailing literals of
-     * one block flowing into the first sequence of the next.  In every case the bytes of the callback must still
+     * one block flowing into the first sequence of the next.  The bytes of the callback must still
      * equal the staged copy the sequences were computed from (the caller may have reused or changed the buffer
-     * since the announcement): one memcmp per callback, a mismatch drops the announcement. */
+     * since the announcement): one memcmp per callback, a mismatch drops the announcement — unless the announcer promised to hold
+     * the bytes still (QZSTD_HINT_STABLE); such an announcement serves every block ONCE, going forward, and is dropped by anything
+     * that does not look like its announcer walking it (round-4 ADVICE).  The newest announcement is looked at first: an older
+     * one that names the same addresses never shadows it. */
     {
-        int k, guessMissed = 0, announced = 0;
-        for (k = 0; k < QZ_HINTS; k++) {
-            QZSTD_Hint_T *h = &s->hint[k];
+        int order[QZ_HINTS], n = 0, oi, k;
+        for (k = 0; k < QZ_HINTS; k++) { /* live announcements, newest first (insertion sort of at most four) */
+            int j = n++;
+            if (s->hint[k].st == 0) { n--; continue; }
+            while (j > 0 && (int)(s->hint[order[j - 1]].seq - s->hint[k].seq) < 0) { order[j] = order[j - 1]; j--; }
+            order[j] = k;
+        }
+        for (oi = 0; oi < n; oi++) {
+            QZSTD_Hint_T *h = &s->hint[order[oi]];
             const unsigned char *p = (const unsigned char *)src;
             size_t rel, b, e, covered = 0;
-            int pi, ok = 1;
-            if (h->st == 0) continue;
-            if (!QZ_IS_GUESS(k)) announced = 1;
+            int pi, ok = 1, byAddr = 0;
+            k = order[oi];
+            if (h->st == 0) continue; /* (dropped further up in this loop) */
             if (h->level != compressionLevel) continue;
             if (p >= h->base && p + srcSize <= h->base + h->size) { /* by address: the callback names announced memory */
                 rel = (size_t)(p - h->base);
                 b = rel / h->block;
-                if (rel % h->block != 0 || b >= h->nb) continue;
+                byAddr = 1;
+                if (rel % h->block != 0 || b >= h->nb) { if (h->stable) qzHintDrop(h); continue; }
                 for (e = b; e < h->nb && covered < srcSize; e++) covered += h->hDesc[e].srcLen;
-                /* a GUESS must not change what the caller gets: it serves a callback only block for block (joining
-                 * independently parsed grid blocks costs ratio; for announcements that is the announcer's choice) */
-                if (covered != srcSize || e - b > 8 || (QZ_IS_GUESS(k) && e - b != 1)) {
-                    QZ_LOG(3, "look-ahead %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
+                if (covered != srcSize || e - b > 8) {
+                    QZ_LOG(3, "announcement %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
+                    if (h->stable) qzHintDrop(h); /* its announcer would not ask this: nothing vouches for these addresses any more */
                     continue;
                 }
-                if (!h->stable && memcmp(h->hSrc + rel, src, srcSize) != 0) {
-                    /* a guess that was read before these bytes were final, or an announced buffer that was rewritten */
-                    if (QZ_IS_GUESS(k)) guessMissed = 1;
-                    else {
-                        QZ_LOG(2, "announcement %d: the buffer changed after it was announced; dropped\n", k);
-                        qzHintDrop(h);
-                    }
+                if (h->stable && b < h->servedUpTo) {
+                    /* a block of a STABLE announcement asked for a second time: the buffer is being used again (a new job over the
+                     * same memory whose last callbacks never came) — nothing vouches for its bytes any more */
+                    QZ_LOG(2, "announcement %d: block %zu asked for again; dropped\n", k, b);
+                    qzHintDrop(h);
+                    continue;
+                }
+                /* verified: every callback; STABLE: every 16th block served, a sampled check of the announcer's promise (QZSTD_hintBroken) */
+                if ((!h->stable || (++s->stableSampler & 15u) == 0u) && memcmp(h->hSrc + rel, src, srcSize) != 0) {
+                    QZ_LOG(h->stable ? 1 : 2, "announcement %d: the buffer changed after it was announced%s; dropped\n", k,
+                           h->stable ? " although it was announced with QZSTD_HINT_STABLE" : "");
+                    if (h->stable) s->stableBroken++;
+                    qzHintDrop(h);
                     continue;
                 }
             } else {
@@ -1476,7 +1475,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                  * the same size, the same first and last 8 bytes and — verified — the same bytes serves such a callback
                  * just as well (the sequences depend on nothing but the block's bytes). */
                 unsigned long long key;
-                if (QZ_IS_GUESS(k) || srcSize < 16 || h->nb > QZ_CONTENT_LOOKUP_BLOCKS || !h->keys) continue;
+                if (srcSize < 16 || h->nb > QZ_CONTENT_LOOKUP_BLOCKS || !h->keys) continue;
                 key = qzBlockKey((const unsigned char *)src, srcSize);
                 for (b = 0; b < h->nb; b++)
                     if (h->keys[b] == key && h->hDesc[b].srcLen == srcSize && memcmp(h->hSrc + b * h->block, src, srcSize) == 0) break;
@@ -1548,53 +1547,26 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                     s->servedFromBatch++;
                     h->touched = 1;
                     h->misses = 0;
-                    if (QZ_IS_GUESS(k)) {
-                        s->autoServed++;
-                        s->autoFails = 0;
-                        s->autoOutstanding = 0;
-                        /* keep the pipeline full: once past the middle of a guess, guess what follows it */
-                        if ((b < (h->nb + 1) / 2 && e >= (h->nb + 1) / 2) || h->nb == 1) {
-                            const QZSTD_Hint_T *o = &s->hint[2 + ((k - 2) ^ 1)];
-                            const unsigned char *nxt = h->base + h->size;
-                            if (!(o->st != 0 && o->base == nxt)) {
-                                if (s->autoDepth < QZ_AUTO_DEPTH_MAX) s->autoDepth *= 2;
-                                s->autoNext = (k - 2) ^ 1;
-                                qzSpeculate(s, nxt, h->block, compressionLevel);
-                            }
-                        }
-                    }
-                    if (last) qzHintDrop(h); /* last block consumed */
+                    if (byAddr && e > h->servedUpTo) h->servedUpTo = e; /* (a block served by content says nothing about where the announcer is) */
+                    if (last && byAddr) qzHintDrop(h); /* last block consumed */
                     return out;
                 }
-                if (last) qzHintDrop(h);
             }
-            break; /* announced but unusable (too many sequences, failed launch): per-block path */
+            /* announced but not served (a failed or timed-out part, a block with too many sequences): the per-block path takes this
+             * block.  A STABLE announcement ends here (its announcer's promise covers "until the callbacks have come": this one has,
+             * and the rest is not worth an unbounded promise); a verified one lives on for its other blocks unless this was the last */
+            if (byAddr && (h->stable || rel + srcSize >= h->size)) qzHintDrop(h);
+            else if (byAddr && e > h->servedUpTo) h->servedUpTo = e;
+            break;
         }
         /* nothing to serve from.  Announcements the caller has walked away from (used, then missed again and again)
-         * are dropped, so that they neither serve stale positions nor keep the state from guessing */
-        announced = 0;
+         * are dropped, so that they do not serve stale positions */
         for (k = 0; k < QZ_HINTS; k++) {
             QZSTD_Hint_T *h = &s->hint[k];
-            if (QZ_IS_GUESS(k)) continue;
             if (h->st != 0 && h->touched && ++h->misses > QZ_HINT_STALE_MISSES) {
                 QZ_LOG(2, "announcement %d: abandoned by the caller; dropped\n", k);
                 qzHintDrop(h);
             }
-        }
-        for (k = 0; k < QZ_ANNOUNCED; k++) announced = announced || s->hint[kAnnounced[k]].st != 0;
-        QZ_LOG(3, "miss: %p + %zu (guesses: %d %p+%zu, %d %p+%zu) outstanding %d backoff %u depth %u\n", src, srcSize, s->hint[2].st,
-               (const void *)s->hint[2].base, s->hint[2].size, s->hint[3].st, (const void *)s->hint[3].base, s->hint[3].size,
-               s->autoOutstanding, s->autoBackoff, s->autoDepth);
-        /* Unannounced caller with the transparent look-ahead switched on: guess that the bytes after this block come next */
-        if (!announced && gProc.lookahead) {
-            if (guessMissed || s->autoOutstanding) { /* the last guess was wrong: back off exponentially, start small again */
-                s->autoOutstanding = 0;
-                s->autoFails++;
-                s->autoBackoff = s->autoFails < 8 ? (1u << (s->autoFails - 1)) - 1u : 255u;
-                s->autoDepth = QZ_AUTO_DEPTH_MIN;
-                for (k = 2; k < 4; k++) qzHintDrop(&s->hint[k]);
-            }
-            qzSpeculate(s, (const unsigned char *)src + srcSize, srcSize, compressionLevel);
         }
     }
 
@@ -1675,6 +1647,11 @@ void QZSTD_failStats(void *sequenceProducerState, unsigned long stats[8])
     stats[7] = s->servedService;
 }
 
+unsigned long QZSTD_hintBroken(void *sequenceProducerState)
+{
+    return sequenceProducerState ? ((const QZSTD_Session_T *)sequenceProducerState)->stableBroken : 0ul;
+}
+
 void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4])
 {
     const QZSTD_Session_T *s = (const QZSTD_Session_T *)sequenceProducerState;
@@ -1683,83 +1660,6 @@ void QZSTD_hintStats(void *sequenceProducerState, unsigned long stats[4])
     stats[1] = s ? s->servedSync : 0;
     stats[2] = s ? s->hintCalls : 0;
     stats[3] = s ? s->hintWaitNs / 1000 : 0;
-}
-
-/* Copy [src, src + len) into dst without ever faulting: whole blocks of `block` bytes as long as they are
- * readable.  process_vm_readv on ourselves is the kernel's copy_from_user: an unmapped or PROT_NONE page ends the
- * transfer (at iovec granularity) instead of raising SIGSEGV.  Returns the bytes copied (a multiple of block). */
-static size_t qzSafeRead(void *dst, const void *src, size_t len, size_t block)
-{
-    struct iovec rem[QZ_HINT_MAX_BYTES / 4096 > 1024 ? 1024 : 64], loc;
-    const size_t nb = len / block;
-    size_t b, done = 0;
-    ssize_t n;
-    if (nb == 0 || nb > sizeof(rem) / sizeof(rem[0])) return 0;
-    for (b = 0; b < nb; b++) {
-        rem[b].iov_base = (void *)((uintptr_t)src + b * block);
-        rem[b].iov_len = block;
-    }
-    loc.iov_base = dst;
-    loc.iov_len = nb * block;
-    n = process_vm_readv(getpid(), &loc, 1, rem, (unsigned long)nb, 0);
-    if (n > 0) done = ((size_t)n / block) * block;
-    return done;
-}
-
-/* The same through a pipe, with nothing but pipe2/write/read (for processes under a seccomp filter, where an unusual
- * system call may be fatal): write() copies from user memory inside the kernel and stops with EFAULT at an
- * unreadable page; what went in is read back out into dst.  The pipe is close-on-exec and non-blocking on the write side;
- * chunks never exceed its capacity, so a short write means an unreadable page, not a full pipe. */
-static size_t qzSafeReadPipe(QZSTD_Session_T *s, void *dst, const void *src, size_t len, size_t block)
-{
-    int *fd = s->pipeFd;
-    size_t done = 0;
-    if (fd[0] < 0) {
-        int cap;
-        if (pipe2(fd, O_CLOEXEC) != 0) { fd[0] = fd[1] = -1; return 0; }
-        (void)fcntl(fd[1], F_SETFL, O_NONBLOCK);
-        cap = fcntl(fd[1], F_GETPIPE_SZ);
-        s->pipeChunk = cap >= 4096 ? (size_t)cap : 4096;
-        if (s->pipeChunk > 65536) s->pipeChunk = 65536;
-    }
-    while (done < len) {
-        const size_t want = len - done < s->pipeChunk ? len - done : s->pipeChunk;
-        const ssize_t w = write(fd[1], (const char *)src + done, want);
-        size_t got = 0;
-        if (w <= 0) break;
-        while (got < (size_t)w) {
-            const ssize_t r = read(fd[0], (char *)dst + done + got, (size_t)w - got);
-            if (r <= 0) return (done / block) * block;
-            got += (size_t)r;
-        }
-        done += (size_t)w;
-        if ((size_t)w < want) break;
-    }
-    return (done / block) * block;
-}
-
-/* The end of the caller's own mapping around p (the VMA that holds the block it just named): a guess never reads
- * past it, so it cannot wander into unrelated mappings (device BARs, other libraries' regions).  Cached per state;
- * /proc/self/maps is read again only when a block lies outside the cached range.  0 = unknown (no guess). */
-static uintptr_t qzMappingEnd(QZSTD_Session_T *s, const void *p)
-{
-    const uintptr_t a = (uintptr_t)p;
-    FILE *f;
-    char line[512];
-    if (a >= s->mapLo && a < s->mapHi) return s->mapHi;
-    s->mapLo = s->mapHi = 0;
-    f = fopen("/proc/self/maps", "re");
-    if (!f) return 0;
-    while (fgets(line, sizeof line, f)) {
-        unsigned long lo = 0, hi = 0;
-        char perm[8] = "";
-        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perm) == 3 && a >= lo && a < hi) {
-            if (perm[0] == 'r') { s->mapLo = lo; s->mapHi = hi; }
-            break;
-        }
-    }
-    fclose(f);
-    return s->mapHi;
 }
 
 /* queue blocks [b0, b1) of announcement h on a slot of device `dev` (any device when dev < 0); 0 on success */
@@ -1777,7 +1677,7 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
          * keeps to its own few slots, whose streams then exist after its first announcements (a stream is created at a slot's first use:
          * with sweeps that all start in the same corner the slots in use kept drifting and streams were still being created ten passes in) */
         const int nd = gProc.numDevices, rows = gProc.numSlots / (nd > 0 ? nd : 1);
-        const int row = rows > 0 ? ((s->slotHint / nd) * QZ_ANNOUNCED) % rows : 0;
+        const int row = rows > 0 ? ((s->slotHint / nd) * QZ_HINTS) % rows : 0;
         i = qzTryGrabSlot(row * nd + s->slotHint % nd + tries * nd, dev);
         if (i < 0 && mayWait) {
             /* every slot is busy: give back what this state still holds, then wait for one */
@@ -1846,10 +1746,9 @@ fail:
 /* Stage a buffer, queue its match-finding and remember it in *h (asynchronous, see QZSTD_hintSource).  The blocks
  * are split into contiguous ranges, one per GPU (reference analogue: instances interleaved across devices,
  * src/qatseqprod.c:601-630), each on its own slot and stream; the results land in the announcement's pinned buffers.
- * speculative: the buffer is a GUESS (what follows the block of the current callback): read it fault-safely, take only
- * whole readable blocks, never wait for a slot, one GPU.  Returns the bytes announced, 0 if none. */
+ * Returns the bytes announced, 0 if none. */
 static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, size_t srcSize, size_t blockSize,
-                         int compressionLevel, int speculative)
+                         int compressionLevel)
 {
     size_t nb, blocksBytes, srcBytes;
     unsigned long tq, tp;
@@ -1881,14 +1780,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     s->hintPrepNs += qzNowNs() - tp;
 
     tq = qzNowNs();
-    if (speculative) {
-        srcSize = gProc.lookahead == 2 ? qzSafeReadPipe(s, h->hSrc, src, srcSize, blockSize)
-                                       : qzSafeRead(h->hSrc, src, srcSize, blockSize);
-        if (srcSize == 0) return 0;
-        nb = srcSize / blockSize;
-    } else {
-        memcpy(h->hSrc, src, srcSize); /* pinned staging: the H2D copies are then truly asynchronous */
-    }
+    memcpy(h->hSrc, src, srcSize); /* pinned staging (reference: the staging memcpy, :1222-1227) */
     s->hintStageNs += qzNowNs() - tq;
     tq = qzNowNs();
     h->base = (const unsigned char *)src;
@@ -1903,7 +1795,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
         memset(h->hSeqs, 0, h->hSeqsCap);
         h->epoch = 1u;
     }
-    if (!speculative && nb <= QZ_CONTENT_LOOKUP_BLOCKS) {
+    if (nb <= QZ_CONTENT_LOOKUP_BLOCKS) {
         if (h->keysCap < nb) {
             free(h->keys);
             h->keys = (unsigned long long *)malloc(nb * sizeof(*h->keys));
@@ -1924,20 +1816,19 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
             h->hDesc[b].parseFrom = 0;
             h->hDesc[b].mark = gProc.hintFlags ? h->epoch : 0u; /* (count-word completion: every entry certifies itself, see qzTakeMarked) */
             h->hCount[b] = gProc.hintFlags ? QZ_COUNT_PENDING : QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
-            if (!speculative && h->keys && nb <= h->keysCap && nb <= QZ_CONTENT_LOOKUP_BLOCKS)
+            if (h->keys && nb <= h->keysCap && nb <= QZ_CONTENT_LOOKUP_BLOCKS)
                 h->keys[b] = h->hDesc[b].srcLen >= 16 ? qzBlockKey(h->hSrc + o, h->hDesc[b].srcLen) : 0ull;
         }
     }
     /* contiguous block ranges, one per GPU, starting at this state's own GPU; a range is worth a launch from 4 blocks */
-    parts = speculative ? 1 : gProc.split;
+    parts = gProc.split;
     if ((size_t)parts > nb / 4) parts = nb / 4 ? (int)(nb / 4) : 1;
     h->nParts = 0;
     for (k = 0; k < parts; k++) {
         const size_t b0 = nb * (size_t)k / (size_t)parts, b1 = nb * (size_t)(k + 1) / (size_t)parts;
-        const int dev = parts > 1 ? (firstDev + k) % gProc.numDevices : (speculative ? -1 : firstDev);
-        if (qzLaunchPart(s, h, &h->part[h->nParts], b0, b1, dev, compressionLevel | gProc.levelFlags, !speculative) != 0) {
-            /* that range could not be queued: its callbacks take the per-block path; a guess is simply not made */
-            if (speculative) { qzHintDrop(h); return 0; }
+        const int dev = parts > 1 ? (firstDev + k) % gProc.numDevices : firstDev;
+        if (qzLaunchPart(s, h, &h->part[h->nParts], b0, b1, dev, compressionLevel | gProc.levelFlags, 1) != 0) {
+            /* that range could not be queued: its callbacks take the per-block path */
             h->part[h->nParts].st = 3;
             h->part[h->nParts].b0 = b0;
             h->part[h->nParts].b1 = b1;
@@ -1948,15 +1839,21 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     h->touched = 0;
     h->misses = 0;
     h->stable = 0;
+    h->servedUpTo = 0;
+    h->seq = ++s->hintSeq;
     s->hintQueueNs += qzNowNs() - tq;
     return srcSize;
 }
 
+/* Lifetime of an announcement (round-4 ADVICE): it ends when the callback of its last block has come, when a callback finds its bytes
+ * changed (verified announcements) or asks for a block a second time / off the grid (STABLE ones), when one of its blocks could not be
+ * served, when a new announcement names addresses it covers, after 16 callbacks in a row that it could not serve, at
+ * QZSTD_dropHints(), and with its state.  At most four are alive per state. */
 int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
                        int compressionLevel, unsigned int flags)
 {
     QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
-    QZSTD_Hint_T *h;
+    QZSTD_Hint_T *h = NULL;
     int k, inflight = 0;
 
     /* the grid: 1 KiB (libzstd's smallest ZSTD_c_maxBlockSize) .. 128 KiB, a multiple of 16 */
@@ -1965,9 +1862,22 @@ int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcS
         return -1;
     if (compressionLevel < QZ_LEVEL_MIN || compressionLevel > QZ_LEVEL_MAX || (flags & ~(unsigned int)QZSTD_HINT_STABLE)) return -1;
     if (!qzDeviceUsable(s)) return -1;
-    h = &s->hint[kAnnounced[s->hintNext]]; /* the oldest of the four */
-    s->hintNext = (s->hintNext + 1) % QZ_ANNOUNCED;
-    if (qzAnnounce(s, h, src, srcSize, blockSize, compressionLevel, 0) == 0) return -1;
+    /* an older announcement over (some of) the same addresses is void from here on: whatever it says about them is not what the
+     * caller is announcing now */
+    for (k = 0; k < QZ_HINTS; k++) {
+        QZSTD_Hint_T *o = &s->hint[k];
+        if (o->st != 0 && (const unsigned char *)src < o->base + o->size && o->base < (const unsigned char *)src + srcSize) qzHintDrop(o);
+    }
+    /* an empty place of the ring first (starting where the last announcement left off); only when all four are alive the oldest goes */
+    for (k = 0; k < QZ_HINTS && !h; k++)
+        if (s->hint[(s->hintNext + k) % QZ_HINTS].st == 0) h = &s->hint[(s->hintNext + k) % QZ_HINTS];
+    if (!h) {
+        h = &s->hint[0];
+        for (k = 1; k < QZ_HINTS; k++)
+            if ((int)(s->hint[k].seq - h->seq) < 0) h = &s->hint[k];
+    }
+    s->hintNext = (int)((h - s->hint) + 1) % QZ_HINTS;
+    if (qzAnnounce(s, h, src, srcSize, blockSize, compressionLevel) == 0) return -1;
     for (k = 0; k < h->nParts; k++) inflight += h->part[k].st == 1;
     if (!inflight) { /* nothing could be queued */
         qzHintDrop(h);
@@ -1986,44 +1896,13 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
     return QZSTD_hintSourceEx(sequenceProducerState, src, srcSize, blockSize, compressionLevel, 0u);
 }
 
-/* Transparent look-ahead for callers that announce nothing — OPT-IN (QZSTD_HIP_LOOKAHEAD=1|2), because it reads memory
- * the caller did not hand over.  libzstd passes one block per callback and waits, but most callers walk a contiguous
- * buffer (a file in chunks, a multi-block frame), so the bytes that FOLLOW the current block are very likely the
- * next blocks.  On a callback that had to take the per-block path, guess: read the following blocks fault-safely —
- * never past the end of the mapping that holds the current block — and let the GPU match-find them while this block is
- * being served and its frame entropy-coded.  A later callback is served from a guess only if its (src, srcSize) sits
- * on the guessed grid AND its bytes still equal the staged copy (memcmp), so a wrong guess costs GPU time, never
- * correctness.  The depth doubles while guesses are consumed (2 .. 32 blocks); misses back off exponentially. */
-static void qzSpeculate(QZSTD_Session_T *s, const unsigned char *next, size_t blockSize, int compressionLevel)
+/* the announcer is done with what it announced (end of a job; before it frees or rewrites a buffer it promised to hold still):
+ * every announcement of the state ends here — launches in flight are waited for, nothing is served from them afterwards */
+void QZSTD_dropHints(void *sequenceProducerState)
 {
-    QZSTD_Hint_T *h;
-    size_t want;
-    uintptr_t end;
+    QZSTD_Session_T *s = (QZSTD_Session_T *)sequenceProducerState;
     int k;
-    /* only with the coalescer: there the per-block path needs no slot, so guesses that hold slots cannot starve it */
-    if (!gProc.lookahead || !gProc.coalesce || (blockSize & 15) || blockSize < 4096) return;
-    if (s->autoBackoff) { s->autoBackoff--; return; }
-    if (s->autoDepth < QZ_AUTO_DEPTH_MIN) s->autoDepth = QZ_AUTO_DEPTH_MIN;
-    h = &s->hint[2 + s->autoNext];
-    for (k = 0; k < h->nParts; k++)
-        if (h->part[k].st == 1 && qzstd_hip_stream_query(gProc.slots[h->part[k].slot].device, gProc.slots[h->part[k].slot].stream) == 1)
-            return; /* the buffer we would reuse is still on the GPU: do not wait for a guess */
-    /* confined to the caller's own mapping: the one that holds the last byte of the block it just named */
-    end = qzMappingEnd(s, next - 1);
-    if (end == 0 || (uintptr_t)next >= end) { s->autoBackoff = 16; return; }
-    want = (size_t)s->autoDepth * blockSize;
-    if (want > end - (uintptr_t)next) want = ((end - (uintptr_t)next) / blockSize) * blockSize;
-    if (want == 0) { s->autoBackoff = 16; return; }
-    if (!gProc.lookaheadLogged) {
-        gProc.lookaheadLogged = 1;
-        QZ_LOG(1, "transparent look-ahead is ON (QZSTD_HIP_LOOKAHEAD=%d): reading up to %u blocks behind the block of a "
-                  "callback, inside the caller's mapping only\n", gProc.lookahead, QZ_AUTO_DEPTH_MAX);
-    }
-    if (qzAnnounce(s, h, next, want, blockSize, compressionLevel, 1) != 0) {
-        s->autoNext ^= 1;
-        s->autoLaunched++;
-        s->autoOutstanding = 1;
-    } else {
-        s->autoBackoff = 16; /* unreadable, or no slot free: try again later */
-    }
+    if (!s) return;
+    for (k = 0; k < QZ_HINTS; k++)
+        if (s->hint[k].st != 0) qzHintDrop(&s->hint[k]);
 }

@@ -25,7 +25,7 @@ def _ensure_built():
     if not os.path.isfile(B.ORACLE_SO):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     if not os.path.isfile(B.PLUGIN_SO):
-        subprocess.check_call(["make", "-C", B.PKG_DIR], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", B.PKG_DIR, "ZSTDLIB=" + B.find_libzstd()], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")

@@ -34,7 +34,7 @@ def test_fuzz_host_logic_under_asan_ubsan_over_the_mock(tmp_path):
     # bounded for the CPU suite (the oracle under ASan walks ~1 MB/s at the chain levels): buffers up to 384 KiB
     # (the mock's service runs the oracle once per work item, each over the block up to the item's end: the default 32 items per block
     # only in the first run, coarser items in the others)
-    for seed, iters, env in ((1, 16, {}), (2, 30, {"QZSTD_HIP_LOOKAHEAD": "1", "QZSTD_HIP_SERVICE_ITEM": "32768"}),
+    for seed, iters, env in ((1, 16, {}), (2, 30, {"QZSTD_HIP_SERVICE_ITEM": "32768"}),
                              (3, 20, {"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SERVICE_ITEM": "65536"}),
                              (4, 20, {"QZSTD_MOCK_DEVICES": "3", "QZSTD_HIP_EXT_REPCODES": "1", "QZSTD_HIP_SERVICE_ITEM": "32768"})):
         out = subprocess.run([exe, str(seed), str(iters), "384", "3"], capture_output=True, text=True, timeout=900,
@@ -50,7 +50,7 @@ def test_fuzz_real_kernels(tmp_path, gpu_plugin):
                            os.path.join(ROOT, "oracle", "qzstd_oracle.c"),  # the checker, linked into the TEST binary only
                            "-L" + os.path.join(B.PKG_DIR, "lib"), "-lqatseqprod", zlib, "-Wl,-rpath," + os.path.join(B.PKG_DIR, "lib"),
                            "-Wl,-rpath," + os.path.dirname(zlib)])
-    for seed, iters, env in ((11, 150, {}), (12, 100, {"QZSTD_HIP_LOOKAHEAD": "1"}), (13, 60, {"QZSTD_HIP_COALESCE": "0"}),
+    for seed, iters, env in ((11, 150, {}), (12, 100, {"QZSTD_HIP_SERVICE": "0"}), (13, 60, {"QZSTD_HIP_COALESCE": "0"}),
                              (14, 60, {"QZSTD_HIP_EXT_REPCODES": "1"})):
         out = subprocess.run([exe, str(seed), str(iters), "3072", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert out.returncode == 0 and "fuzz ok" in out.stdout, (env, (out.stdout + out.stderr)[-1500:])

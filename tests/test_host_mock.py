@@ -83,79 +83,27 @@ def stats_of(plug, st):
 
 
 @pytest.mark.parametrize("level,chunk", [(1, 131072), (3, 65536), (6, 131072), (12, 32768)])
-def test_unchanged_caller_guessed_lookahead(mock, zstd, oracle, level, chunk):
-    """the transparent look-ahead is opt-in (QZSTD_HIP_LOOKAHEAD=1): off by default, nothing behind a block is read"""
-    data = K.by_name("mix", 24 * chunk + 777, seed=level)
-    buf = (C.c_char * len(data)).from_buffer_copy(data)
-    st = mock.lib.QZSTD_createSeqProdState()
-    got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, level)
-    stats = stats_of(mock, st)
-    mock.lib.QZSTD_freeSeqProdState(st)
-    assert got == oracle_frames(zstd, oracle, data, chunk, level)
-    assert stats[0] == 0 and stats[1] == 25, stats  # default: every block took the per-block path
-    with restarted(mock, QZSTD_HIP_LOOKAHEAD="1"):
-        st = mock.lib.QZSTD_createSeqProdState()
-        got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, level)
-        stats = stats_of(mock, st)
-        mock.lib.QZSTD_freeSeqProdState(st)
-    assert got == oracle_frames(zstd, oracle, data, chunk, level)
-    assert stats[2] == 0 and stats[0] >= 16, stats  # nothing announced; most blocks came from guesses
-
-
-def test_guess_stays_inside_the_callers_mapping(mock, zstd, oracle):
-    """a guess never reads past the end of the mapping that holds the block of the callback, even when the next
-    mapping is readable"""
-    chunk, nblk = 65536, 6
-    big = mmap.mmap(-1, 2 * nblk * chunk)  # one mapping; split into two VMAs by giving the halves different protections
-    base = C.addressof(C.c_char.from_buffer(big))
+def test_unchanged_caller_reads_nothing_but_the_callbacks_block(mock, zstd, oracle, level, chunk):
+    """the library touches [src, src + srcSize) of a callback and nothing else: the opt-in transparent look-ahead of rounds 1-4
+    (QZSTD_HIP_LOOKAHEAD) is gone (round-4 verdict, item 6), the variable is ignored.  The page behind the buffer is unreadable:
+    a read behind the last block would fault."""
     libc = C.CDLL(None, use_errno=True)
-    data = K.by_name("text", nblk * chunk, seed=5)
-    big[:nblk * chunk] = data
-    big[nblk * chunk:] = K.by_name("binary", nblk * chunk, seed=6)
-    assert libc.mprotect(C.c_void_p(base + nblk * chunk), C.c_size_t(nblk * chunk), 1) == 0  # PROT_READ only: another VMA
-    with restarted(mock, QZSTD_HIP_LOOKAHEAD="1", QZSTD_HIP_DEBUG="3"):
-        st = mock.lib.QZSTD_createSeqProdState()
-        got = frames_of(zstd, mock.producer_addr, st, base, nblk * chunk, chunk, 1)
-        served = stats_of(mock, st)[0]
-        mock.lib.QZSTD_freeSeqProdState(st)
-    assert got == oracle_frames(zstd, oracle, data, chunk, 1)
-    assert served >= 3
-    assert libc.mprotect(C.c_void_p(base + nblk * chunk), C.c_size_t(nblk * chunk), 3) == 0
-    del got
-
-
-@pytest.mark.parametrize("mode", ["1", "2"])  # fault-safe read by process_vm_readv / through a pipe
-def test_stale_guess_and_unreadable_page(mock, zstd, oracle, mode):
-    with restarted(mock, QZSTD_HIP_LOOKAHEAD=mode):
-        _stale_guess_and_unreadable_page(mock, zstd, oracle)
-
-
-def _stale_guess_and_unreadable_page(mock, zstd, oracle):
-    libc = C.CDLL(None, use_errno=True)
-    page, nblk, chunk = mmap.PAGESIZE, 10, 65536
-    total = nblk * chunk
-    mm = mmap.mmap(-1, total + page)
+    page = mmap.PAGESIZE
+    data = K.by_name("mix", 24 * chunk, seed=level)
+    mm = mmap.mmap(-1, len(data) + page)
     base = C.addressof(C.c_char.from_buffer(mm))
-    assert libc.mprotect(C.c_void_p(base + total), C.c_size_t(page), 0) == 0
-    final = K.by_name("text", total, seed=11)
-    mm[:total] = K.by_name("binary", total, seed=12)
-
-    def rewrite(c):  # the caller produces every chunk only just before compressing it
-        mm[c * chunk:(c + 1) * chunk] = final[c * chunk:(c + 1) * chunk]
-
-    st = mock.lib.QZSTD_createSeqProdState()
-    got = frames_of(zstd, mock.producer_addr, st, base, total, chunk, 1, before=rewrite)
-    assert got == oracle_frames(zstd, oracle, final, chunk, 1)
-    got = frames_of(zstd, mock.producer_addr, st, base, total, chunk, 1, order=[7, 2, 9, 0, 1, 3, 8, 4, 6, 5])
-    assert got == oracle_frames(zstd, oracle, final, chunk, 1)
-    mock.lib.QZSTD_freeSeqProdState(st)
-    st = mock.lib.QZSTD_createSeqProdState()  # a fresh state (the old one has backed off): in order, stable content
-    got = frames_of(zstd, mock.producer_addr, st, base, total, chunk, 1)
-    served = stats_of(mock, st)[0]
-    mock.lib.QZSTD_freeSeqProdState(st)
-    assert served >= 5, served  # guesses are used right up to the unreadable page
-    assert got == oracle_frames(zstd, oracle, final, chunk, 1)
-    assert libc.mprotect(C.c_void_p(base + total), C.c_size_t(page), 3) == 0
+    mm[:len(data)] = data
+    assert libc.mprotect(C.c_void_p(base + len(data)), C.c_size_t(page), 0) == 0
+    want = oracle_frames(zstd, oracle, data, chunk, level)
+    for env in ({}, {"QZSTD_HIP_LOOKAHEAD": "1"}, {"QZSTD_HIP_LOOKAHEAD": "2"}):
+        with restarted(mock, **env):
+            st = mock.lib.QZSTD_createSeqProdState()
+            got = frames_of(zstd, mock.producer_addr, st, base, len(data), chunk, level)
+            stats = stats_of(mock, st)
+            mock.lib.QZSTD_freeSeqProdState(st)
+        assert got == want
+        assert stats[0] == 0 and stats[1] == 24 and stats[2] == 0, (env, stats)  # every block took the per-block path, nothing announced
+    assert libc.mprotect(C.c_void_p(base + len(data)), C.c_size_t(page), 3) == 0
     del got
 
 
@@ -255,7 +203,7 @@ def test_one_shot_multi_block_frame_and_stream(mock, zstd):
 
 
 def test_modes_through_environment(tmp_path):
-    """QZSTD_HIP_COALESCE=0 (a slot per caller, fewer slots than threads), QZSTD_HIP_LOOKAHEAD=0,
+    """QZSTD_HIP_COALESCE=0 (a slot per caller, fewer slots than threads), four devices,
     QZSTD_HIP_EXT_REPCODES=1: a fresh process each, frames must round-trip"""
     script = r'''
 import sys, ctypes as C, threading
@@ -281,32 +229,10 @@ plug.lib.QZSTD_stopQatDevice()
 assert ok == [True] * 6, ok
 print("OK")
 ''' % (os.path.join(ROOT, "tools"), MOCK_SO)
-    for env in ({"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SLOTS": "3"}, {"QZSTD_HIP_LOOKAHEAD": "1"}, {"QZSTD_HIP_LOOKAHEAD": "2"},
-                {"QZSTD_MOCK_DEVICES": "4"},
+    for env in ({"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SLOTS": "3"}, {"QZSTD_MOCK_DEVICES": "4"},
                 {"QZSTD_HIP_EXT_REPCODES": "1"}):
         out = subprocess.run(["python", "-c", script], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
         assert out.returncode == 0 and "OK" in out.stdout, (env, out.stderr[-800:])
-
-
-def test_lookahead_never_changes_the_output(mock, zstd):
-    """multi-block frames (libzstd 1.5.7 cuts them into irregular 32-128 KiB blocks): byte-identical frames with the
-    transparent look-ahead on and off"""
-    data = K.by_name("system", 3 * (1 << 20) + 4321)
-    buf = (C.c_char * len(data)).from_buffer_copy(data)
-
-    def run(chunk):
-        st = mock.lib.QZSTD_createSeqProdState()
-        fr = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1)
-        mock.lib.QZSTD_freeSeqProdState(st)
-        return fr
-
-    off = {c: run(c) for c in (1 << 20, 393216)}  # the default
-    with restarted(mock, QZSTD_HIP_LOOKAHEAD="1"):
-        on = {c: run(c) for c in (1 << 20, 393216)}
-    with restarted(mock, QZSTD_HIP_LOOKAHEAD="2"):
-        piped = {c: run(c) for c in (1 << 20, 393216)}
-    assert on == off == piped
-    assert b"".join(zstd.decompress(f, 1 << 20) for f in on[1 << 20]) == data
 
 
 def test_announced_buffer_that_changes_is_never_served_stale(mock, zstd, oracle):
@@ -517,6 +443,122 @@ def test_batch_front_end_over_the_mock(mock, zstd, oracle):
         assert total == sum(sizes) and dst.raw[:total] == b"".join(frames)
         F.QZSTD_freeFront(f)
     assert F.QZSTD_createFront(C.byref(Params(0, 1, chunk, 0, 0, 1))) is None
+
+
+def _front_lib(zstd):
+    front_so = os.path.join(ROOT, "tests", "mock", "libqzstdfront_mock.so")
+    build_shared(["gcc", "-O2", "-g", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-DQZ_TEST_HOOKS", "-shared", "-fPIC", "-pthread",
+                  "-I" + os.path.join(ROOT, "include"), "-o", front_so,
+                           os.path.join(B.PKG_DIR, "frontend", "qzstd_frontend.c"), MOCK_SO, zstd.path,
+                           "-Wl,-rpath," + os.path.dirname(MOCK_SO), "-Wl,-rpath," + os.path.dirname(zstd.path)], front_so)
+    F = C.CDLL(front_so)
+    F.QZSTD_createFront.restype = C.c_void_p
+    F.QZSTD_createFront.argtypes = [C.POINTER(B.FrontParams)]
+    F.QZSTD_frontFrameStride.restype = C.c_size_t
+    F.QZSTD_frontFrameStride.argtypes = [C.c_void_p]
+    F.QZSTD_frontCompress.restype = C.c_size_t
+    F.QZSTD_frontCompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    F.QZSTD_freeFront.argtypes = [C.c_void_p]
+    return F
+
+
+@pytest.mark.parametrize("tail", [3, 1234, 0])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_front_end_jobs_over_a_reused_buffer(mock, zstd, oracle, tail, threads):
+    """round-4 ADVICE (high): the front-end announces with QZSTD_HINT_STABLE, and an announcement used to live until the callback
+    of its last block — which never comes for a last chunk below 7 bytes (libzstd does not ask the producer).  The stale announcement
+    then served the NEXT job by address when the caller used the same buffer again: frames that did not decode to the input.
+    Now every worker ends its announcements with its job (QZSTD_dropHints)."""
+    F = _front_lib(zstd)
+    chunk = 65536
+    size = 3 * chunk + tail
+    a = K.by_name("system", size, seed=41)
+    b = K.by_name("text", size, seed=42)
+    buf = (C.c_char * size).from_buffer_copy(a)
+    prm = B.FrontParams(threads, 1, chunk, 4 * chunk, 0, 1)
+    f = F.QZSTD_createFront(C.byref(prm))
+    assert f
+    stride = F.QZSTD_frontFrameStride(f)
+    n = (size + chunk - 1) // chunk
+    dst = C.create_string_buffer(n * stride)
+    sizes = (C.c_size_t * n)()
+    try:
+        for content in (a, b, a, b):
+            C.memmove(buf, content, size)
+            assert F.QZSTD_frontCompress(f, buf, size, dst, len(dst), sizes) == n
+            frames = [dst.raw[c * stride:c * stride + sizes[c]] for c in range(n)]
+            back = b"".join(zstd.decompress(fr, chunk) for fr in frames)
+            assert back == content
+            assert frames == oracle_frames(zstd, oracle, content, chunk, 1)
+    finally:
+        F.QZSTD_freeFront(f)
+
+
+def test_stable_announcement_has_a_bounded_life(mock, zstd, oracle):
+    """round-4 ADVICE (medium): a STABLE announcement serves every block once, going forward; it ends when a block is asked for a
+    second time, when a newer announcement names its addresses, at QZSTD_dropHints; the newest announcement is looked at first; the
+    sampled comparison (every 16th block) reveals a broken promise (QZSTD_hintBroken)"""
+    L = mock.lib
+    L.QZSTD_hintSourceEx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint]
+    L.QZSTD_dropHints.argtypes = [C.c_void_p]
+    L.QZSTD_hintBroken.argtypes = [C.c_void_p]
+    L.QZSTD_hintBroken.restype = C.c_ulong
+    chunk, nb = 65536, 8
+    a = K.by_name("system", nb * chunk, seed=51)
+    b = K.by_name("text", nb * chunk, seed=52)
+    buf = (C.c_char * len(a)).from_buffer_copy(a)
+    addr = C.addressof(buf)
+    # 1. a block asked for again (the buffer is being used again, the last blocks' callbacks never came): dropped, fresh match-finding
+    st = L.QZSTD_createSeqProdState()
+    assert L.QZSTD_hintSourceEx(st, buf, len(a), chunk, 1, 1) == 0
+    got = frames_of(zstd, mock.producer_addr, st, addr, 5 * chunk, chunk, 1)  # walks 5 of the 8 blocks, then away
+    assert stats_of(mock, st)[0] == 5
+    C.memmove(buf, b, len(b))
+    got = frames_of(zstd, mock.producer_addr, st, addr, len(b), chunk, 1)      # a new job over the same memory, nothing announced
+    assert got == oracle_frames(zstd, oracle, b, chunk, 1)
+    assert stats_of(mock, st)[0] == 5  # nothing more was served from the stale announcement
+    L.QZSTD_freeSeqProdState(st)
+    # 2. a newer announcement over the same addresses voids the older one, and the newest is looked at first
+    C.memmove(buf, a, len(a))
+    st = L.QZSTD_createSeqProdState()
+    assert L.QZSTD_hintSourceEx(st, buf, len(a), chunk, 1, 1) == 0
+    C.memmove(buf, b, len(b))
+    assert L.QZSTD_hintSourceEx(st, buf, len(b), chunk, 1, 1) == 0
+    got = frames_of(zstd, mock.producer_addr, st, addr, len(b), chunk, 1)
+    assert got == oracle_frames(zstd, oracle, b, chunk, 1) and stats_of(mock, st)[0] == nb
+    L.QZSTD_freeSeqProdState(st)
+    # 3. QZSTD_dropHints ends everything announced
+    C.memmove(buf, a, len(a))
+    st = L.QZSTD_createSeqProdState()
+    assert L.QZSTD_hintSourceEx(st, buf, len(a), chunk, 1, 1) == 0
+    L.QZSTD_dropHints(st)
+    C.memmove(buf, b, len(b))
+    got = frames_of(zstd, mock.producer_addr, st, addr, len(b), chunk, 1)
+    assert got == oracle_frames(zstd, oracle, b, chunk, 1) and stats_of(mock, st)[0] == 0
+    L.QZSTD_dropHints(None)
+    L.QZSTD_freeSeqProdState(st)
+    # 4. the sampled check: 40 blocks announced STABLE and then rewritten — by the 16th block served the library notices, drops the
+    # announcement, counts it, and everything from there on is match-found afresh
+    big_a = K.by_name("system", 40 * chunk, seed=53)
+    big_b = K.by_name("mix", 40 * chunk, seed=54)
+    bb = (C.c_char * len(big_a)).from_buffer_copy(big_a)
+    st = L.QZSTD_createSeqProdState()
+    for k in range(0, 40, 10):
+        assert L.QZSTD_hintSourceEx(st, C.byref(bb, k * chunk), 10 * chunk, chunk, 1, 1) == 0
+    C.memmove(bb, big_b, len(big_b))
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(bb), len(big_b), chunk, 1)
+    want = oracle_frames(zstd, oracle, big_b, chunk, 1)
+    assert L.QZSTD_hintBroken(st) >= 1
+    assert got[16:20] == want[16:20]      # the rest of the announcement that was caught: afresh
+    assert stats_of(mock, st)[0] < 40
+    L.QZSTD_freeSeqProdState(st)
+    # ... and a caller that keeps the promise is never counted
+    st = L.QZSTD_createSeqProdState()
+    for k in range(0, 40, 10):
+        assert L.QZSTD_hintSourceEx(st, C.byref(bb, k * chunk), 10 * chunk, chunk, 1, 1) == 0
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(bb), len(big_b), chunk, 1)
+    assert got == want and L.QZSTD_hintBroken(st) == 0 and stats_of(mock, st)[0] == 40
+    L.QZSTD_freeSeqProdState(st)
 
 
 def test_streaming_caller_is_served_from_an_announcement_by_content(mock, zstd, oracle):
@@ -816,10 +858,11 @@ def test_timed_out_announcement_parks_its_buffers(mock, zstd, oracle):
         assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) == 0
         seqs = (B.Sequence * B.sequence_bound(chunk))()
         assert L.qatSequenceProducer(st, seqs, len(seqs), buf, chunk, None, 0, 3, 1 << 17) == B.SEQ_ERROR  # the part times out, the launch path too
-        # a state holds four announcements (round 4; two before): the fourth call from here reuses - drops - the one whose part timed out
+        # a new announcement over the same addresses ends the older one (round 5): the one whose part timed out is dropped by the first of
+        # these calls, and so is each of these (still stalled) by the next
         for _ in range(4):
             assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) in (0, -1)
-        assert L.qzstd_test_orphans() == before + 1  # its buffers are parked, not reused
+        assert L.qzstd_test_orphans() >= before + 1  # its buffers are parked, not reused
         L.qzstd_mock_stall_ms(0)
         time.sleep(0.35)
         assert L.QZSTD_hintSource(st, buf, len(data), chunk, 3) == 0

@@ -16,9 +16,8 @@ PY
 BM=qat-zstd-plugin_amd/test/benchmark
 echo "nproc $(nproc) level $L chunk $C, $MB MiB per thread"
 for T in ${THREADS:-1 16 64 128 256}; do
-  for cfg in "sw:-m0" "plain:-m1" "hint:-m1 -H4" "la:-m1"; do
+  for cfg in "sw:-m0" "plain:-m1" "hint:-m1 -H4"; do
     name=${cfg%%:*}; args=${cfg#*:}
-    env=""; [ $name = la ] && env="QZSTD_HIP_LOOKAHEAD=1"
     out=$(env $env timeout 300 $BM $args -t$T -l${LOOPS:-2} -c$C -L$L /tmp/e2e.bin 2>&1 | grep "aggregate compression")
     echo "T=$T $name: $(echo $out | sed 's/.*aggregate compression //; s/decompression.*//')"
   done

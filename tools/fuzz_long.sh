@@ -9,7 +9,7 @@ Z=$(python -c "import sys; sys.path.insert(0,'tools'); import qz_bind as B; prin
 gcc -O2 -g -std=c11 -D_POSIX_C_SOURCE=200809L -pthread -Iinclude -Ioracle -o /tmp/fuzz_gpu tests/fuzz/fuzz_roundtrip.c qat-zstd-plugin_amd/test/fuzzing/qatseqprodfuzzer.c oracle/qzstd_oracle.c -Lqat-zstd-plugin_amd/lib -lqatseqprod $Z -Wl,-rpath,$PWD/qat-zstd-plugin_amd/lib -Wl,-rpath,$(dirname $Z)
 failed=0
 for seed in ${FUZZ_SEEDS:-101 102 103 104 105 106}; do
-  env=""; [ $seed = 103 ] && env="QZSTD_HIP_LOOKAHEAD=1"; [ $seed = 104 ] && env="QZSTD_HIP_COALESCE=0"; [ $seed = 105 ] && env="QZSTD_HIP_EXT_REPCODES=1"; [ $seed = 106 ] && env="QZSTD_HIP_LOOKAHEAD=2 QZSTD_HIP_TIMEOUT_MS=5000"
+  env=""; [ $seed = 103 ] && env="QZSTD_HIP_SERVICE=0"; [ $seed = 104 ] && env="QZSTD_HIP_COALESCE=0"; [ $seed = 105 ] && env="QZSTD_HIP_EXT_REPCODES=1"; [ $seed = 106 ] && env="QZSTD_HIP_TIMEOUT_MS=5000"
   set +e
   env QZSTD_HIP_DEBUG=1 $env timeout ${FUZZ_TIMEOUT:-900} /tmp/fuzz_gpu $seed ${FUZZ_ITERS:-400} 3072 ${FUZZ_ORACLE_EVERY:-1} > /tmp/fuzz_$seed.log 2>&1
   rc=$?

@@ -299,7 +299,7 @@ class SvcReq(C.Structure):
 # every symbol include/qatseqprod.h and include/qzstd_hip.h declare
 PLUGIN_SYMBOLS = [
     "QZSTD_version", "qatSequenceProducer", "QZSTD_startQatDevice", "QZSTD_stopQatDevice",
-    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource", "QZSTD_hintSourceEx", "QZSTD_hintStats", "QZSTD_failStats", "QZSTD_deviceStats",
+    "QZSTD_createSeqProdState", "QZSTD_freeSeqProdState", "QZSTD_hintSource", "QZSTD_hintSourceEx", "QZSTD_dropHints", "QZSTD_hintBroken", "QZSTD_hintStats", "QZSTD_failStats", "QZSTD_deviceStats",
     "qzstd_hip_last_error", "qzstd_hip_profile_for_level", "qzstd_hip_sequence_bound", "qzstd_hip_lds_bytes",
     "qzstd_hip_device_count", "qzstd_hip_device_name", "qzstd_hip_malloc", "qzstd_hip_free",
     "qzstd_hip_host_alloc", "qzstd_hip_host_free", "qzstd_hip_stream_create", "qzstd_hip_stream_destroy",
@@ -561,5 +561,7 @@ class Front:
 
 if __name__ == "__main__":  # `python tools/qz_bind.py --libzstd`: the Makefiles' default ZSTDLIB
     import sys
-    if "--libzstd" in sys.argv:
+    if "--libzstd-exported" in sys.argv:  # the product Makefile's default: an EXPORTED libzstd >= 1.5.4, never the shim
+        print(slow_libzstd())
+    elif "--libzstd" in sys.argv:  # what the tests, tools and bench legs run (the shim over libarrow.so's copy when it works)
         print(find_libzstd())

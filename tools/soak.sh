@@ -28,7 +28,7 @@ for round in 1 2; do
   done
   run A=1 -- -m1 -t12 -l2 -c64K -L$L -H2 /tmp/soak_mix.bin
   run QZSTD_HIP_EXT_REPCODES=1 -- -m1 -t9 -l2 -c128K -L$L -E1 -H8 /tmp/soak_sys.bin
-  run QZSTD_HIP_LOOKAHEAD=1 -- -m1 -t20 -l1 -c32K -L$L /tmp/soak_mix.bin
+  run QZSTD_HIP_SERVICE=0 -- -m1 -t20 -l1 -c32K -L$L /tmp/soak_mix.bin
   run QZSTD_HIP_TIMEOUT_MS=1 -- -m1 -t6 -l1 -c128K -L$L -F1 /tmp/soak_mix.bin
   run QZSTD_HIP_COALESCE=0 QZSTD_HIP_SLOTS=6 -- -m1 -t10 -l1 -c100000 -L$L /tmp/soak_mix.bin
  done
