@@ -18,6 +18,12 @@ in the BUILD CONTAINER only, where /root/reference exists —
   4. writes inputs and the reference's outputs to tests/golden/lz4s_ref_vectors.json.  A fixture is data: inputs and expected
      outputs, no reference text.
 
+  5. (round 5) ORACLE vectors: the oracle's own sequences of seeded blocks (every offset < 65536: LZ4s' range), serialised as LZ4s
+     by serialise_lz4s() below, decoded by the same lifted reference decoder: the reference's code certifies the oracle's emission
+     rules on REAL output of this match-finder (minimum match, delimiter, literal carry-over), not only on synthetic streams.  One
+     vector runs the oracle without segment boundaries (profile.segLog = 0, extLog = 17) on a 128 KiB periodic block: a match longer than 65535,
+     which the reference truncates to 16 bits (:1062).
+
 tests/test_oracle_golden.py::test_lz4s_decoder_matches_the_reference_decoder then requires qzo_lz4s_decode to agree on every
 vector (CPU suite; it reads only the committed JSON — /root/reference does not exist on the GPU box).
 
@@ -157,6 +163,73 @@ def make_streams(seed=20260929):
     return vecs
 
 
+def serialise_lz4s(seqs, block: bytes) -> bytes:
+    """(offset, litLength, matchLength) triples incl. the delimiter + the block's literals -> an LZ4s stream (token, literal-run
+    extension, literals, LE16 offset, match-length extension; stored match length = matchLength - 2: LZ4MINMATCH, reference :104,:1061)"""
+    out = bytearray()
+    pos = 0
+    for off, lit, ml in seqs[:-1]:
+        stored = ml - 2
+        assert 0 < off < 65536 and stored >= 1
+        out.append((min(lit, 15) << 4) | min(stored, 15))
+        if lit >= 15:
+            out += length_bytes(lit - 15)
+        out += block[pos:pos + lit]
+        out += bytes((off & 0xFF, off >> 8))
+        if stored >= 15:
+            out += length_bytes(stored - 15)
+        pos += lit + ml
+    off, lit, ml = seqs[-1]
+    assert off == 0 and ml == 0 and pos + lit == len(block)
+    out.append(min(lit, 15) << 4)
+    if lit >= 15:
+        out += length_bytes(lit - 15)
+    out += block[pos:pos + lit]
+    return bytes(out)
+
+
+# (name, generator of tools/qz_corpus.py, seed, bytes, level, segLog override or None)
+ORACLE_CASES = (("oracle_text_8k_L1", "text", 21, 8192, 1, None), ("oracle_weblog_8k_L1", "weblog", 22, 8192, 1, None),
+                ("oracle_binary_8k_L3", "binary", 23, 8192, 3, None), ("oracle_text_6000_L6", "text", 24, 6000, 6, None),
+                ("oracle_weblog_8k_L12", "weblog", 25, 8192, 12, None), ("oracle_mix_16k_L1", "mix", 26, 16384, 1, None),
+                ("oracle_mixed_entropy_8k_L3", "mixed_entropy", 27, 8192, 3, None), ("oracle_random_2k_L1", "random", 28, 2048, 1, None),
+                ("oracle_periodic_128k_L1_no_segments", "periodic", 29, 131072, 1, 0))
+
+
+def oracle_block(gen: str, seed: int, size: int) -> bytes:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import qz_corpus as K
+    if gen == "periodic":  # 37 seeded bytes over and over: one long match at offset 37
+        rng = random.Random(seed)
+        unit = bytes(rng.randrange(256) for _ in range(37))
+        return (unit * (size // 37 + 1))[:size]
+    return K.by_name(gen, size, seed)
+
+
+def oracle_sequences(gen: str, seed: int, size: int, level: int, seglog):
+    """the oracle's sequences of the case's block: [(offset, litLength, matchLength), ...] incl. the delimiter"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import qz_bind as B
+    orc = B.Oracle()
+    blk = oracle_block(gen, seed, size)
+    prof = orc.profile(level, len(blk))
+    if seglog is not None:  # no segment boundaries, and the extension's own bound (profile.extLog) out of the way: the match may run to the block's end
+        prof.segLog = seglog
+        prof.extLog = 17
+    n, seqs = orc.find(prof, blk)
+    assert n != B.SEQ_ERROR and n >= 1
+    return blk, [(seqs[i].offset, seqs[i].litLength, seqs[i].matchLength) for i in range(n)]
+
+
+def make_oracle_streams():
+    vecs = []
+    for name, gen, seed, size, level, seglog in ORACLE_CASES:
+        blk, seqs = oracle_sequences(gen, seed, size, level, seglog)
+        vecs.append({"name": name, "cap": len(seqs) + 8, "gen": gen, "seed": seed, "size": size, "level": level, "seglog": seglog,
+                     "oracle_sequences": len(seqs), "hex": serialise_lz4s(seqs, blk).hex()})
+    return vecs
+
+
 def run_reference(vecs):
     tmp = tempfile.mkdtemp(prefix="qz_lz4s_")
     try:
@@ -180,7 +253,11 @@ def main():
     doc = {"source": "outputs of the reference's own QZSTD_decLz4s (src/qatseqprod.c:1013-1091, compiled from the reference tree by "
                      "tools/make_lz4s_golden.py with the image's zstd.h 1.4.9) on seeded random LZ4s streams; expect = [offset, litLength, "
                      "matchLength] per sequence incl. the delimiter, or \"error\" (ZSTD_SEQUENCE_PRODUCER_ERROR)",
-           "generator": "tools/make_lz4s_golden.py", "seed": 20260929, "vectors": run_reference(make_streams())}
+           "generator": "tools/make_lz4s_golden.py", "seed": 20260929, "vectors": run_reference(make_streams()),
+           "oracle_source": "the ORACLE's sequences (oracle/qzstd_oracle.c, qzo_find_sequences) of seeded blocks — tools/qz_corpus.py generators, "
+                            "the case's seed / size / level — serialised as LZ4s by serialise_lz4s() and decoded by the same reference decoder: "
+                            "expect is what the reference's code makes of this match-finder's real output",
+           "oracle_vectors": run_reference(make_oracle_streams())}
     text = json.dumps(doc, indent=1) + "\n"
     if "--check" in sys.argv:
         same = open(OUT).read() == text
@@ -188,7 +265,8 @@ def main():
         sys.exit(0 if same else 1)
     with open(OUT, "w") as f:
         f.write(text)
-    print("wrote %s: %d vectors, %d of them decode errors" % (OUT, len(doc["vectors"]), sum(v["expect"] == "error" for v in doc["vectors"])))
+    print("wrote %s: %d vectors, %d of them decode errors; %d oracle vectors" % (OUT, len(doc["vectors"]), sum(v["expect"] == "error" for v in doc["vectors"]),
+                                                                               len(doc["oracle_vectors"])))
 
 
 if __name__ == "__main__":
