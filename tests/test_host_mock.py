@@ -913,3 +913,23 @@ def test_stress_driver_over_the_mock(mock, zstd, tmp_path):
     for args in (["items", corpus, "6", "3", "4"], ["items", corpus, "0xc", "2", "3", "32768"], ["frames", corpus, "1,6", "4", "5"]):
         out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "svc_stress ok" in out.stdout, (args, (out.stdout + out.stderr)[-1500:])
+
+
+def test_host_path_bench_over_the_replaying_mock(mock, tmp_path):
+    """tests/stress/hostpath_bench.c (round-4 verdict, item 7): the HOST side of the announcement path — claims announced two ahead,
+    every block taken through qatSequenceProducer, no libzstd — against the mock with QZSTD_MOCK_REPLAY=1 (a "device" that costs one
+    memcpy).  Here: it builds, every block comes from an announcement, no errors, the replay table was hit; the rate is printed
+    (profiles/r05_host_path.txt holds the measured figures), only a floor is asserted."""
+    import re
+    exe = str(tmp_path / "hostpath_bench")
+    subprocess.check_call(["gcc", "-O2", "-g", "-std=c11", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "stress", "hostpath_bench.c"), MOCK_SO, "-Wl,-rpath," + os.path.dirname(MOCK_SO)])
+    f = tmp_path / "in.bin"
+    f.write_bytes(K.by_name("system", 64 * 131072, seed=9))
+    out = subprocess.run([exe, str(f), "3", "3", "1", "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, QZSTD_MOCK_REPLAY="1"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r": (\d+) MB/s .*host path alone (\d+) MB/s; (\d+) block\(s\) from announcements, (\d+) per block, (\d+) error\(s\), \d+ sequences, (\d+) replay hits", out.stdout)
+    assert m, out.stdout
+    rate, host, served, sync, errs, hits = (int(x) for x in m.groups())
+    assert served == 4 * 64 and sync == 0 and errs == 0 and hits >= 3 * 64, out.stdout
+    assert host >= rate > 200, out.stdout  # (a floor far below any machine: the figure itself is a measurement, not a test)
