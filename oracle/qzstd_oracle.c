@@ -69,7 +69,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->tableSize = chains ? 5888u : (level >= 3 ? 16000u : 6400u);
     out->longSize = (!chains && level >= 3) ? 8192u : 0u;
     out->tileLog = 9;
-    out->capLen = level >= 9 ? 128u : (level >= 5 ? 64u : 48u);
+    out->capLen = level >= 5 ? 64u : 48u; /* (round 5: levels 9-12 128 -> 64) */
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;
@@ -84,7 +84,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->repWin = (repcodes || level >= 10) ? 16u : 0u;
     /* levels >= 5: links walked per position (software zstd: 2^searchLog = 4..128 attempts plus repcodes; the
      * producer API gives no repcodes below level 10, which deeper chains make up for) */
-    out->chainDepth = level >= 10 ? 48u : (level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u))));
+    out->chainDepth = level >= 10 ? 40u : (level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 12u : (level >= 5 ? 8u : 0u)))); /* (round 5: level 6 16 -> 12, levels 10-12 48 -> 40) */
     /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
      * level 2, which buys its better ratio with them */
     out->subTileLog = (chains || level == 2) ? 6u : 0u;

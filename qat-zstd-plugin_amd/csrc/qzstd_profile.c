@@ -41,14 +41,19 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
         out->longSize = (!chains && level >= 3) ? 8192u : 0u;
         out->tileLog = 9;
 #ifndef QZ_CAP_HI
-#define QZ_CAP_HI 128u /* candidate cap of levels 9-12 (A/B builds) */
+#define QZ_CAP_HI 64u /* candidate cap of levels 9-12 (round 5: 128 -> 64, kernel time -10 ... -11 %, compressed size +0.06 % over eleven corpora: a capped
+                       * match is extended when the parse takes it, the cap only blunts the lazy comparison between two very long candidates) */
+#endif
+#ifndef QZ_CAP_MID
+#define QZ_CAP_MID 64u /* ... of levels 5-8 (A/B builds) */
 #endif
 #ifndef QZ_DEPTH_HI
-#define QZ_DEPTH_HI 48u /* links walked at levels 10-12 (round 4: 64 -> 48; the repeat-aware parse of these levels leaves room in the 2 % bound:
+#define QZ_DEPTH_HI 40u /* links walked at levels 10-12 (round 5: 48 -> 40 = ten entries of four links, another -9 % of kernel time for +0.05 % of compressed
+                         * size; round 4: 64 -> 48; the repeat-aware parse of these levels leaves room in the 2 % bound:
                          * compressed size +0.1 % over eleven corpora (web-log 32 KiB blocks 0.996 -> 0.994 of software), kernel time -14 % (config 4's
                          * shape) to -18 % (128 KiB blocks): the walk's cost is linear in the links) */
 #endif
-        out->capLen = level >= 9 ? QZ_CAP_HI : (level >= 5 ? 64u : 48u); /* levels 1-4: one 32-byte step after the 16-byte head; capped matches are extended when taken */
+        out->capLen = level >= 9 ? QZ_CAP_HI : (level >= 5 ? QZ_CAP_MID : 48u); /* levels 1-4: one 32-byte step after the 16-byte head; capped matches are extended when taken */
         out->minMatch = 4;
         out->farLog1 = 12;
         out->farLog2 = 16;
@@ -63,7 +68,11 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
         out->repWin = (repcodes || level >= 10) ? 16u : 0u;
         /* levels >= 5: links walked per position (software zstd: 2^searchLog = 4..128 attempts plus repcodes; the
          * producer API gives no repcodes below level 10, which deeper chains make up for) */
-        out->chainDepth = level >= 10 ? QZ_DEPTH_HI : (level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? 16u : (level >= 5 ? 8u : 0u))));
+#ifndef QZ_DEPTH_6
+#define QZ_DEPTH_6 12u /* links walked at level 6 (round 5: 16 -> 12 = three entries of four links: kernel time -19 %, compressed size +0.28 % over eleven corpora,
+                        * 0.999 -> 0.997 of software zstd level 6 — whose own chain search makes 8 attempts; the walk's cost is linear in the links) */
+#endif
+        out->chainDepth = level >= 10 ? QZ_DEPTH_HI : (level >= 9 ? 64u : (level >= 7 ? 32u : (level >= 6 ? QZ_DEPTH_6 : (level >= 5 ? 8u : 0u))));
         /* the tables are updated per 64 positions, in position order, at the chain levels (there: exactly) and at
          * level 2, which buys its better ratio with them */
         out->subTileLog = (chains || level == 2) ? 6u : 0u;

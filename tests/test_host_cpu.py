@@ -97,7 +97,7 @@ def test_workspace_only_for_chain_levels(plugin):
         assert W(level, 100, 131072) == 0 and plugin.profile(level, 131072).chainDepth == 0
         assert plugin.profile(level, 131072).subTileLog == (6 if level == 2 else 0)
     for level in range(5, 13):
-        assert plugin.profile(level, 131072).chainDepth in (8, 16, 32, 48, 64) and plugin.profile(level, 131072).subTileLog == 6
+        assert plugin.profile(level, 131072).chainDepth in (8, 12, 32, 40, 64) and plugin.profile(level, 131072).subTileLog == 6
         assert W(level, 100, 131072) == 100 * 131072 * 20
         assert W(level, 3, 1000) == 3 * 1024 * 20
     assert W(6, 1, 131073) == 0 and W(0, 1, 1000) == 0
