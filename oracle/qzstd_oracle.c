@@ -69,7 +69,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     out->tableSize = chains ? 5888u : (level >= 3 ? 16000u : 6400u);
     out->longSize = (!chains && level >= 3) ? 8192u : 0u;
     out->tileLog = 9;
-    out->capLen = level >= 5 ? 64u : 48u; /* (round 5: levels 9-12 128 -> 64) */
+    out->capLen = 48u; /* every level (round 5; levels 5-8 had 64, levels 9-12 128): the 16-byte head + one step of 32 bytes, capped matches are extended when taken */
     out->minMatch = 4;
     out->farLog1 = 12;
     out->farLog2 = 16;

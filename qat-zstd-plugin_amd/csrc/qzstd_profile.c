@@ -41,11 +41,12 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
         out->longSize = (!chains && level >= 3) ? 8192u : 0u;
         out->tileLog = 9;
 #ifndef QZ_CAP_HI
-#define QZ_CAP_HI 64u /* candidate cap of levels 9-12 (round 5: 128 -> 64, kernel time -10 ... -11 %, compressed size +0.06 % over eleven corpora: a capped
-                       * match is extended when the parse takes it, the cap only blunts the lazy comparison between two very long candidates) */
+#define QZ_CAP_HI 48u /* candidate cap of levels 9-12 (A/B builds).  Round 5: ONE cap at every level — the 16-byte head and one step of 32 bytes; a capped
+                       * match is extended to its true end when the parse takes it, the cap only blunts the lazy comparison between two long candidates.
+                       * Levels 9-12 128 -> 64 -> 48: kernel time -11 % and another -4 %, compressed size +0.06 % / +0.05 % over eleven corpora */
 #endif
 #ifndef QZ_CAP_MID
-#define QZ_CAP_MID 64u /* ... of levels 5-8 (A/B builds) */
+#define QZ_CAP_MID 48u /* ... of levels 5-8: 64 -> 48, kernel time -7 % (level 6: 82.4 -> 76.3 ms per GiB), compressed size +0.08 % */
 #endif
 #ifndef QZ_DEPTH_HI
 #define QZ_DEPTH_HI 40u /* links walked at levels 10-12 (round 5: 48 -> 40 = ten entries of four links, another -9 % of kernel time for +0.05 % of compressed
@@ -53,7 +54,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
                          * compressed size +0.1 % over eleven corpora (web-log 32 KiB blocks 0.996 -> 0.994 of software), kernel time -14 % (config 4's
                          * shape) to -18 % (128 KiB blocks): the walk's cost is linear in the links) */
 #endif
-        out->capLen = level >= 9 ? QZ_CAP_HI : (level >= 5 ? QZ_CAP_MID : 48u); /* levels 1-4: one 32-byte step after the 16-byte head; capped matches are extended when taken */
+        out->capLen = level >= 9 ? QZ_CAP_HI : (level >= 5 ? QZ_CAP_MID : 48u); /* one 32-byte step after the 16-byte head; capped matches are extended when taken */
         out->minMatch = 4;
         out->farLog1 = 12;
         out->farLog2 = 16;
