@@ -173,6 +173,14 @@ int qzstd_hip_occupancy(int device, int level);
  *                              service is down): the caller takes the launch path;  < 0 = error
  */
 #define QZSTD_HIP_NSEQ_REJECTED 0xFFFFFFFEu
+/* Progressive staging (round 5): a count word the caller sets to QZSTD_HIP_NSEQ_STAGING instead of 0 says "slice k of hSrc is not staged
+ * yet": the worker that gets item k waits for the word to leave that value before it reads the slice.  The caller may therefore queue
+ * the request FIRST and copy the block into hSrc behind it, slice by slice, turning every word to 0 (compare-and-swap: a request that was
+ * handed back has REJECTED there) as its slice is in — the staging copy of a 128 KiB block (13 us) then overlaps the request's way to
+ * the first worker (8 us).  qzstd_hip_service_progressive(): 1 = this device layer's workers look (the resident kernels), 0 = they do
+ * not: stage everything before qzstd_hip_service_submit (a synchronous stand-in, e.g. the tests' mock). */
+#define QZSTD_HIP_NSEQ_STAGING 0xFFFFFFFCu
+int qzstd_hip_service_progressive(int device);
 #define QZSTD_HIP_SVC_MAX_ITEMS 32u
 #define QZSTD_HIP_SVC_MAX_SLOTS 1024u
 typedef struct {

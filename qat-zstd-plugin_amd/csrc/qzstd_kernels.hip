@@ -1875,7 +1875,19 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
         /* ---- the item's slice: pinned host memory -> the request's device staging buffer, written through ---- */
         {
             const uint32_t end = (blk.srcLen + 15u) & ~15u;
-            for (uint32_t o = blk.parseFrom + tid * 16u; o < end; o += (uint32_t)kThreads * 16u) {
+            /* progressive staging (qzstd_hip.h): the caller queued the request before it copied the block into hSrc; the item's count word
+             * says QZSTD_HIP_NSEQ_STAGING until slice k is there (usually long gone: the request took 8 us to get here, a slice 0.4) */
+            if (wave == 0u) {
+                uint32_t spins = 0u, okS = 1u;
+                while (__hip_atomic_load(countWord, QZ_RLX_SYSTEM) == QZSTD_HIP_NSEQ_STAGING) {
+                    if (++spins > spinLimit) { okS = 0u; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (lane == 0u) ctl[18] = okS;
+            }
+            __syncthreads();
+            const bool staged = rdfirst(ctl[18]) != 0u;
+            for (uint32_t o = blk.parseFrom + tid * 16u; o < end && staged; o += (uint32_t)kThreads * 16u) {
                 const u64 a = __hip_atomic_load((const u64 *)(hSrc + o), QZ_RLX_SYSTEM);
                 const u64 b = __hip_atomic_load((const u64 *)(hSrc + o + 8u), QZ_RLX_SYSTEM);
                 __hip_atomic_store((u64 *)(dSrc + o), a, QZ_RLX_AGENT);
@@ -1884,7 +1896,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every storing wave drains before the flag */
             __syncthreads();
             if (wave == 0u) {
-                if (lane == 0u) __hip_atomic_store(&sv->sliceFlag[slotIdx][k], epoch, QZ_RLX_AGENT);
+                if (lane == 0u && staged) __hip_atomic_store(&sv->sliceFlag[slotIdx][k], epoch, QZ_RLX_AGENT); /* (never staged: the items behind this one give up as well) */
                 /* the slices before this one: copied by the items before it (handed out earlier, waiting for nothing) */
                 uint32_t spins = 0u, ok = 1u;
                 for (;;) {
@@ -1894,7 +1906,7 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
                     __builtin_amdgcn_s_sleep(2);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* ONE acquire after the match; plain loads from here */
-                if (lane == 0u) ctl[17] = ok;
+                if (lane == 0u) ctl[17] = staged ? ok : 0u;
             }
             __syncthreads();
         }
@@ -2849,6 +2861,16 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
     }
     __atomic_fetch_add(&s.requests, 1ul, __ATOMIC_RELAXED);
     return 0;
+}
+
+int qzstd_hip_service_progressive(int device)
+{
+    /* the resident workers wait for a count word to leave QZSTD_HIP_NSEQ_STAGING before they read its slice (qzstd_service_worker);
+     * QZSTD_HIP_SERVICE_EARLY=0: the callers stage first, as in rounds 3-4 (A/B) */
+    static int on = -1;
+    (void)device;
+    if (on < 0) { const char *v = getenv("QZSTD_HIP_SERVICE_EARLY"); on = !(v && *v && atoi(v) == 0); }
+    return on;
 }
 
 int qzstd_hip_service_poke(int device, int level)

@@ -124,11 +124,29 @@ static void *late_marks(void *p)
     free(lt);
     return NULL;
 }
+/* QZSTD_MOCK_PROGRESSIVE=1: the mock serves requests on a thread of its own and its "workers" wait for a count word to leave
+ * QZSTD_HIP_NSEQ_STAGING before they read its slice — the protocol of the resident kernels' progressive staging (qzstd_hip.h), so that the
+ * host's queue-first-stage-behind path runs in the CPU suite */
+static int progressiveOn(void)
+{
+    const char *v = getenv("QZSTD_MOCK_PROGRESSIVE");
+    return v && atoi(v) > 0;
+}
+int qzstd_hip_service_progressive(int device) { (void)device; return progressiveOn(); }
+static int serve_request(int level, const qzstd_hip_svc_req_t *r);
+typedef struct { int level; qzstd_hip_svc_req_t r; } async_req_t;
+static void *serve_async(void *p)
+{
+    async_req_t *a = (async_req_t *)p;
+    (void)serve_request(a->level, &a->r);
+    free(a);
+    return NULL;
+}
+
 int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r)
 {
     const char *v = getenv("QZSTD_MOCK_SERVICE");
     qzo_profile_t pf;
-    uint32_t k;
     (void)device;
     if ((v && atoi(v) == 0) || gSvcBroken) return 1;
     if (qzo_profile_for_level(level, r->srcLen, &pf)) return 1;
@@ -140,10 +158,32 @@ int qzstd_hip_service_submit(int device, int level, const qzstd_hip_svc_req_t *r
     }
     __sync_fetch_and_add(&gSvcRequests, 1);
     if (nowNs() < gStallUntilNs) return 0; /* queued, never served */
+    if (progressiveOn()) {
+        async_req_t *a = (async_req_t *)malloc(sizeof *a);
+        pthread_t th;
+        if (!a) return -1;
+        a->level = level;
+        a->r = *r;
+        if (pthread_create(&th, NULL, serve_async, a) != 0) { free(a); return -1; }
+        pthread_detach(th);
+        return 0;
+    }
+    return serve_request(level, r);
+}
+
+static int serve_request(int level, const qzstd_hip_svc_req_t *r)
+{
+    qzo_profile_t pf;
+    uint32_t k;
+    if (qzo_profile_for_level(level, r->srcLen, &pf)) return 1;
     for (k = 0; k < r->nItems; k++) {
         const uint32_t from = k * r->itemBytes, upTo = from + r->itemBytes < r->srcLen ? from + r->itemBytes : r->srcLen;
         size_t n;
-        if (gSvcLevel && gSvcLevel != level) { r->hCount[k] = QZSTD_HIP_NSEQ_REJECTED; continue; }
+        if (gSvcLevel && gSvcLevel != level) { __atomic_store_n(&r->hCount[k], QZSTD_HIP_NSEQ_REJECTED, __ATOMIC_RELEASE); continue; }
+        while (__atomic_load_n(&r->hCount[k], __ATOMIC_ACQUIRE) == QZSTD_HIP_NSEQ_STAGING) { /* the caller is still copying slice k in */
+            const struct timespec nap = { 0, 1000 };
+            nanosleep(&nap, NULL);
+        }
         memcpy((uint8_t *)r->dSrc + from, (const uint8_t *)r->hSrc + from, upTo - from); /* the item's slice */
         n = qzo_find_sequences_from(&pf, (const uint8_t *)r->dSrc, upTo, from, (qzo_seq_t *)r->hSeqs + (size_t)k * r->seqCapPerItem, r->seqCapPerItem);
         if (n != QZO_ERROR) { /* every entry carries the request's epoch in its fourth word, as the real workers' do */

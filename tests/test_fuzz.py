@@ -35,7 +35,7 @@ def test_fuzz_host_logic_under_asan_ubsan_over_the_mock(tmp_path):
     # (the mock's service runs the oracle once per work item, each over the block up to the item's end: the default 32 items per block
     # only in the first run, coarser items in the others)
     for seed, iters, env in ((1, 16, {}), (2, 30, {"QZSTD_HIP_SERVICE_ITEM": "32768"}),
-                             (3, 20, {"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SERVICE_ITEM": "65536"}),
+                             (3, 20, {"QZSTD_HIP_COALESCE": "0", "QZSTD_HIP_SERVICE_ITEM": "65536"}), (5, 16, {"QZSTD_MOCK_PROGRESSIVE": "1", "QZSTD_HIP_SERVICE_ITEM": "16384"}),
                              (4, 20, {"QZSTD_MOCK_DEVICES": "3", "QZSTD_HIP_EXT_REPCODES": "1", "QZSTD_HIP_SERVICE_ITEM": "32768"})):
         out = subprocess.run([exe, str(seed), str(iters), "384", "3"], capture_output=True, text=True, timeout=900,
                              env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", **env))

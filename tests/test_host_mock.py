@@ -792,6 +792,39 @@ def test_service_coarser_items_and_other_levels(mock, zstd, oracle):
         L.qzstd_mock_service_level(0)
 
 
+@pytest.mark.parametrize("level,chunk", [(1, 131072), (2, 100001), (6, 131072), (12, 32768), (1, 5000)])
+def test_service_progressive_staging(mock, zstd, oracle, level, chunk):
+    """round 5 (include/qzstd_hip.h: QZSTD_HIP_NSEQ_STAGING): where the device layer's workers look at a count word before they read
+    its slice, the host queues the request FIRST and copies the block into the pinned buffer behind it, slice by slice.  The mock
+    with QZSTD_MOCK_PROGRESSIVE=1 serves requests on a thread of its own and waits for every slice like the resident kernels do:
+    frames are the oracle's, every block went through the service; a request the dispatcher hands back while the host is still
+    staging (another level is resident) takes the launch path"""
+    data = K.by_name("system", 5 * chunk + 77, seed=level)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_service_level.argtypes = [C.c_int]
+    nblk = (len(data) + chunk - 1) // chunk
+    with restarted(mock, QZSTD_MOCK_PROGRESSIVE="1"):
+        assert L.qzstd_hip_service_progressive(0) == 1
+        st = L.QZSTD_createSeqProdState()
+        for _ in range(2):
+            got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, level)
+            assert got == oracle_frames(zstd, oracle, data, chunk, level)
+        fs = fail_stats(mock, st)
+        assert fs[0] == 0 and fs[7] == 2 * nblk, fs
+        L.QZSTD_freeSeqProdState(st)
+        L.qzstd_mock_service_level(level + 1 if level < 12 else 1)  # handed back: the words say REJECTED, not STAGING, when the host gets there
+        try:
+            st = L.QZSTD_createSeqProdState()
+            assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, level) == oracle_frames(zstd, oracle, data, chunk, level)
+            fs = fail_stats(mock, st)
+            assert fs[7] == 0 and fs[0] == 0 and stats_of(mock, st)[1] == nblk, fs
+            L.QZSTD_freeSeqProdState(st)
+        finally:
+            L.qzstd_mock_service_level(0)
+    assert L.qzstd_hip_service_progressive(0) == 0
+
+
 def test_service_time_out_is_an_error_then_the_launch_path_takes_over(mock, zstd):
     """a service request whose counts never arrive: the error code after QZSTD_HIP_TIMEOUT_MS (reference: 2 s of polling,
     src/qatseqprod.c:1261-1285), counted as a time-out; the service is not used again, the slot not before its counts have

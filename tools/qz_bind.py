@@ -305,7 +305,7 @@ PLUGIN_SYMBOLS = [
     "qzstd_hip_host_alloc", "qzstd_hip_host_free", "qzstd_hip_stream_create", "qzstd_hip_stream_destroy",
     "qzstd_hip_stream_sync", "qzstd_hip_stream_query", "qzstd_hip_stream_wait", "qzstd_hip_memcpy_h2d", "qzstd_hip_copy_in", "qzstd_hip_memcpy_d2h",
     "qzstd_hip_memset", "qzstd_hip_memcpy2d_d2h", "qzstd_hip_host_device_ptr", "qzstd_hip_workspace_bytes", "qzstd_hip_find_sequences",
-    "qzstd_hip_service_submit", "qzstd_hip_service_stop", "qzstd_hip_service_poke", "qzstd_hip_service_mark_broken", "qzstd_hip_service_info", "qzstd_hip_service_debug",
+    "qzstd_hip_service_submit", "qzstd_hip_service_stop", "qzstd_hip_service_poke", "qzstd_hip_service_progressive", "qzstd_hip_service_mark_broken", "qzstd_hip_service_info", "qzstd_hip_service_debug",
     "qzstd_hip_host_alloc_coherent", "qzstd_hip_device_numa_node", "qzstd_hip_host_alloc_on_node", "qzstd_hip_host_node_of", "qzstd_hip_occupancy",
 ]
 
