@@ -5,7 +5,7 @@
 = what BASELINE.json's metric literally names: INPUT MB/s THROUGH ZSTD_compress2 with qatSequenceProducer registered, level 1,
 one frame per 128 KiB chunk (the framing of /root/reference/test/benchmark.c:300-321, timing shape :305-319,:374-382).  A "step"
 is one pass of ONE buffer of --e2e-blocks chunks (default 8192 x 128 KiB = 1 GiB per GPU: BASELINE configs[1]) through the batch front-end
-(include/qzstd_frontend.h: a pool of CCtx threads, the usable host cores + an eighth, claims of at most 2 MiB with two announced ahead, the
+(include/qzstd_frontend.h: a pool of CCtx threads, the usable host cores + a sixteenth, claims of at most 2 MiB with two announced ahead, the
 GPU match-finds while the threads entropy-code), called IN THIS PROCESS through its C ABI.  W untimed warm-up passes, then exactly
 K passes between barrier + synchronize brackets, MAX over ranks; `value` = chunks' bytes of all ranks x K / that time.  One
 process per GPU (torch.distributed.run): rank r sees only GPU r (HIP_VISIBLE_DEVICES is narrowed before HIP starts), blocks are
@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-seconds", type=float, default=5.5, help="continuous load per first-class end-to-end side leg")
     ap.add_argument("--e2e-blocks", type=int, default=8192, help="chunks per GPU per step of the timed ZSTD_compress2 leg (8192 x 128 KiB = 1 GiB: BASELINE configs[1])")
-    ap.add_argument("--e2e-threads", type=int, default=0, help="front-end worker threads per rank (0 = the rank's share of the usable host cores + an eighth)")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="front-end worker threads per rank (0 = the rank's share of the usable host cores + a sixteenth)")
     ap.add_argument("--kernel-only", action="store_true", help="only the roofline leg (K timed launches of the dominant kernel, resident input): what "
                     "tools/prof_stats.sh / prof_pmc.sh run under rocprofv3, so that the profile holds these launches and no others")
     ap.add_argument("--allow-slow-libzstd", action="store_true", help="run the metric even when the callers' libzstd is the image's 4x slower Pillow build "
@@ -702,13 +702,14 @@ def main():
         return
     # ---- THE METRIC: input MB/s through ZSTD_compress2, plugin registered (module docstring); exactly a.steps timed passes
     ncpu, quota = host_cpu_budget()
-    # threads per rank: the rank's share of the usable cores + an eighth — a worker that waits for the GPU's first results of a pass or naps in a
+    # threads per rank: the rank's share of the usable cores + a sixteenth (round 5: 17 on 16 cores; an eighth before — four runs of 20 steps each on one box:
+    # 16 threads 21.4-23.2 GB/s, 17: 23.0-23.6, 18: 21.9-23.7, 20: 21.2-24.0: the quota is a CFS quota, the busier the threads the more often it throttles) — a worker that waits for the GPU's first results of a pass or naps in a
     # poll leaves its core idle; two more threads than cores fill those gaps (tools/fe_dbg.sh on a 16-core box, 2 MiB claims, two announced ahead:
     # 14 threads 14.9 GB/s, 16: 20.7, 18: 22.3, 20: 22.1, 24: 22.5)
     share = max(1.0, quota / world)
     if cpu_binding.get("bound"):  # (the affinity is this rank's own CPUs now: not to be divided by the ranks again)
         share = max(1.0, min(quota_before_binding / world, float(len(os.sched_getaffinity(0)))))
-    e2e_threads = a.e2e_threads if a.e2e_threads > 0 else max(1, min(int(share + share / 8.0), 128))
+    e2e_threads = a.e2e_threads if a.e2e_threads > 0 else max(1, min(int(share + share / 16.0 + 0.5), 128))
     e2e_nb = max(1, min(a.e2e_blocks, nb))
     e2e_buf = shard[:e2e_nb * block]
     B.Zstd()  # libzstd >= 1.5.4 first (RTLD_GLOBAL): the front-end links against it
@@ -737,7 +738,7 @@ def main():
             "data": "synthetic batch assembled from real files of the ROCm image (system corpus, tools/qz_corpus.py), repeated to size" if a.corpus == "system" else "synthetic",
             "config": {"workload": "through ZSTD_compress2: level-%d, one frame per %d KiB chunk, %d chunks (%d MiB) per GPU per step, qatSequenceProducer "
                                    "registered (no software match-finder: %d producer errors), batch front-end (include/qzstd_frontend.h) with %d CCtx "
-                                   "threads per rank (usable host cores %.0f / %d rank(s), plus an eighth), 2 MiB announcements; host buffers in, frames out"
+                                   "threads per rank (usable host cores %.0f / %d rank(s), plus a sixteenth), 2 MiB announcements; host buffers in, frames out"
                                    % (level & 0xFF, block >> 10, e2e_nb, len(e2e_buf) >> 20, e2e_info["producer_errors"]["total"], e2e_threads, quota, world),
                        "corpus": prov[:300], "level": level, "block_bytes": block, "chunks_per_gpu_per_step": e2e_nb,
                        "threads_per_rank": e2e_threads, "libzstd": B.Zstd().version(), "libzstd_build": B.libzstd_build(B.find_libzstd()),

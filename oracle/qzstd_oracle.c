@@ -66,7 +66,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
      * levels >= 5: exact hash chains (zstd: greedy / lazy / lazy2 / btlazy2 over a 4-byte hash), where the size
      * of the head table hardly matters (a collision costs one chain step): 5888 entries, two blocks per CU */
     const int chains = level >= 5;
-    out->tableSize = chains ? 5888u : (level >= 3 ? 16000u : 6400u);
+    out->tableSize = chains ? 5888u : (level >= 3 ? 16384u : 8192u); /* (round 5: powers of two below the chain levels — the slot is a shift, not a multiply-high; 16000 / 6400 before) */
     out->longSize = (!chains && level >= 3) ? 8192u : 0u;
     out->tileLog = 9;
     out->capLen = 48u; /* every level (round 5; levels 5-8 had 64, levels 9-12 128): the 16-byte head + one step of 32 bytes, capped matches are extended when taken */
@@ -100,13 +100,16 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
 /* ---- candidate phase -------------------------------------------------------- */
 
 #define QZO_HASH_PRIME2 0x85EBCA77u
-/* 32-bit mix of the first hashBytes (4..8) bytes at a position: two 32-bit multiplies */
+/* 32-bit mix of the first hashBytes (4..7) bytes at a position: ONE 32-bit multiply, the bytes behind the fourth (at most three: < 2^24) come
+ * in through a 24 x 24-bit product (round 5: the kernel's v_mul_u32_u24 is a full-rate instruction, its 32-bit multiplies quarter-rate — the
+ * insert pass in front of a service item is bound by them).  The 8-byte key of the second table (qzo_mix8) keeps two full multiplies. */
 static inline uint32_t qzo_mix(const uint8_t *p, uint32_t hashBytes)
 {
     uint32_t lo = qzo_rd32(p), hi = 0;
-    if (hashBytes > 4) hi = qzo_rd32(p + hashBytes - 4) >> (8u * (8u - hashBytes)); /* bytes 4.. */
-    return (lo * QZO_HASH_PRIME) ^ (hi * QZO_HASH_PRIME2);
+    if (hashBytes > 4) hi = qzo_rd32(p + hashBytes - 4) >> (8u * (8u - hashBytes)); /* bytes 4.. (hashBytes <= 7: below 2^24) */
+    return (lo * QZO_HASH_PRIME) ^ (hi * (QZO_HASH_PRIME2 & 0xFFFFFFu));
 }
+
 /* main table slot: multiply-high range reduction (any table size) */
 static inline uint32_t qzo_slot(uint32_t m, uint32_t tableSize)
 {
@@ -459,7 +462,7 @@ size_t qzo_find_sequences_from(const qzo_profile_t *pf, const uint8_t *src, size
 
     if (!pf || !out || cap < 2 || srcSize > QZO_BLOCK_MAX || (srcSize && !src)) return QZO_ERROR;
     if (pf->tableSize < 256 || pf->tableSize > (1u << 18) || pf->tileLog > 10 || pf->minMatch < 3 ||
-        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->lazy > 4 || (pf->chainDepth && (pf->nearTab || pf->longSize)) || pf->chainDepth > 64 || pf->subTileLog > pf->tileLog || (pf->subTileLog && pf->subTileLog < 4) || pf->hashBytes < 4 || pf->hashBytes > 8 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
+        pf->capLen < pf->minMatch + 2 || pf->repWin > 32 || pf->lazy > 4 || (pf->chainDepth && (pf->nearTab || pf->longSize)) || pf->chainDepth > 64 || pf->subTileLog > pf->tileLog || (pf->subTileLog && pf->subTileLog < 4) || pf->hashBytes < 4 || pf->hashBytes > 7 || pf->extLog < 8 || pf->extLog > 17 || pf->longSize > (1u << 18))
         return QZO_ERROR;
     if (pf->segLog && (pf->segLog < pf->tileLog || pf->segLog > 17)) return QZO_ERROR;
     if (parseFrom && (!pf->segLog || (parseFrom & ((1u << pf->segLog) - 1u)) || parseFrom >= srcSize)) return QZO_ERROR;

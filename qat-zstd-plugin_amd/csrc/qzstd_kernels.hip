@@ -815,6 +815,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     const qzstd_hip_profile_t pf = args.prof;
     const uint32_t nh = n >= pf.hashBytes ? n - pf.hashBytes + 1u : 0u; /* hashable positions */
     const uint32_t nTiles = (nh + kTile - 1u) >> kTileLog;
+    /* below the chain levels the tables are powers of two (csrc/qzstd_profile.c; the launcher refuses anything else): slot = mix >> shift */
+    const uint32_t tabShift = (uint32_t)__builtin_clz(pf.tableSize) + 1u, longShift = pf.longSize ? (uint32_t)__builtin_clz(pf.longSize) + 1u : 31u;
     /* segment mode (qzstd_hip_block_t.parseFrom): tiles before the segment are only inserted into the tables */
     const uint32_t firstTile = blk.parseFrom >> kTileLog;
     if (blk.parseFrom != 0u && (pf.segLog == 0u || (blk.parseFrom & ((1u << pf.segLog) - 1u)) != 0u || blk.parseFrom >= n)) {
@@ -822,7 +824,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     }
     if (NEAR && n > kRing) return QZSTD_HIP_NSEQ_ERROR; /* a descriptor longer than the launch's maxBlockLen: refused, never compared from a ring that lost its bytes */
 
-    /* ---- LDS layout (qzstd_hip_lds_bytes(): 65 392 B at levels 1-2 and 5-12 = two workgroups per CU; 136 560 B at levels 3-4) ---- */
+    /* ---- LDS layout (qzstd_hip_lds_bytes(): 72 560 B at levels 1-2, 65 392 B at levels 5-12 = two workgroups per CU; 138 096 B at levels 3-4) ---- */
     /* The workgroup's LDS is addressed from an integer constant, not from the `smem` symbol: the dynamic allocation starts at
      * LDS address 0 (the kernel has no static LDS), but the compiler resolves the symbol too late to fold it and every LDS
      * address would carry a dead `v_add 0`.  kLdsBase (16: never the null pointer) is part of qzstd_hip_lds_bytes(). */
@@ -1194,11 +1196,11 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     if (p + pf.hashBytes <= segEc) { /* oracle: qzo_hashable */
                         const uint32_t v = __builtin_amdgcn_alignbyte(W[(k >> 2) + 1u], W[k >> 2], k & 3u);
                         const uint32_t w = __builtin_amdgcn_alignbyte(W[(k >> 2) + 2u], W[(k >> 2) + 1u], k & 3u);
-                        const uint32_t mixH = (v * kPrime1) ^ ((pf.hashBytes > 4 ? w & hiMaskH : 0u) * kPrime2);
-                        atomicMax(&tbl[__umulhi(mixH, pf.tableSize)], ((p + 1u) << kTagBits) | ((mixH >> 3) & kTagMask));
+                        const uint32_t mixH = (v * kPrime1) ^ __umul24(pf.hashBytes > 4 ? w & hiMaskH : 0u, kPrime2 & 0xFFFFFFu);
+                        atomicMax(&tbl[mixH >> tabShift], ((p + 1u) << kTagBits) | ((mixH >> 3) & kTagMask));
                         if (HAS_LONG && p + 8u <= segEc) {
                             const uint32_t m8 = (v * kPrime1) ^ (w * kPrime2);
-                            atomicMax(&tblL[__umulhi(m8, pf.longSize)], ((p + 1u) << kTagBits) | ((m8 >> 3) & kTagMask));
+                            atomicMax(&tblL[m8 >> longShift], ((p + 1u) << kTagBits) | ((m8 >> 3) & kTagMask));
                         }
                     }
                 }
@@ -1400,14 +1402,16 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             const uint32_t v = oa[0];
             uint32_t hi = 0;
             if (pf.hashBytes > 4) hi = oa[1] & hiMask;
-            mix = (v * kPrime1) ^ (hi * kPrime2);
-            slot = __umulhi(mix, pf.tableSize);
+            /* ONE quarter-rate multiply per position below the chain levels (round 5; three before): the bytes behind the fourth come in through a
+             * full-rate 24-bit product (hashBytes <= 7), the tables are powers of two (the slot is a shift) */
+            mix = (v * kPrime1) ^ __umul24(hi, kPrime2 & 0xFFFFFFu);
+            slot = CHAIN ? __umulhi(mix, pf.tableSize) : mix >> tabShift;
             nslot = mix >> nearShift;
             if (!TURNS) old = tbl[slot]; /* with turns the slot is read when the wave's turn comes */
             if (pf.nearTab && !history) atomicMin(&nearTab[nslot], stamp | (tid << kTagBits) | ((mix >> 3) & kTagMask));
             if (validL) { /* second table, keyed by the first 8 bytes */
                 const uint32_t m8 = (v * kPrime1) ^ (oa[1] * kPrime2);
-                slotL = __umulhi(m8, pf.longSize);
+                slotL = m8 >> longShift;
                 tagL = (m8 >> 3) & kTagMask;
                 if (!TURNS) oldL = tblL[slotL];
             }
@@ -2594,6 +2598,9 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     const void *kernel = variants[nearK][a.prof.longSize ? 1 : 0][a.prof.repWin ? 1 : 0][a.prof.chainDepth ? 2 : (a.prof.subTileLog ? 1 : 0)];
     void *kargs[1] = { &a };
     if (!kernel) return fail_msg("qzstd_hip_find_sequences: unsupported profile (no kernel variant)");
+    /* below the chain levels the kernels take the slot as a shift of the hash and mix at most three bytes behind the fourth through a 24-bit product */
+    if (!a.prof.chainDepth && ((a.prof.tableSize & (a.prof.tableSize - 1u)) != 0u || (a.prof.longSize & (a.prof.longSize - 1u)) != 0u || a.prof.hashBytes > 7u))
+        return fail_msg("qzstd_hip_find_sequences: unsupported profile (tables below the chain levels are powers of two, hashBytes <= 7)");
     QZ_CHECK(hipLaunchKernel(kernel, grid, wg, kargs, ldsLaunch, (hipStream_t)stream), "launch qzstd_find_sequences_kernel");
     QZ_CHECK(hipGetLastError(), "launch qzstd_find_sequences_kernel");
     if (big && bigLock.owns_lock()) {

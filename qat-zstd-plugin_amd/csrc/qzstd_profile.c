@@ -9,7 +9,7 @@
  * LDS budget per workgroup (gfx950: 160 KiB = 163840 B per CU, target: TWO workgroups per CU):
  *     32 KiB ring of recent block bytes (+128 B wrap mirror) + 4*tableSize + near table 4<<tileLog
  *     + 2 tiles of per-position parse words + per-window emission records + 64 B control
- *     (+ 96 B of item words for the resident service) = 65 392 B with 6400 table entries at tileLog 9.
+ *     (+ 96 B of item words for the resident service) = 72 560 B with 8192 table entries at tileLog 9 (levels 1-2).
  */
 #include "qzstd_hip.h"
 
@@ -27,9 +27,9 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
     (void)blockSize; /* the profile does not depend on the block size: the LDS footprint is fixed (ring + tables) */
-    /* levels 1-2: 6400 entries, no long table = 81.6 KB of LDS -> two blocks per CU;
-     * levels 3-4: 16000 entries + a second table keyed by 8 bytes (the double-fast idea of zstd's
-     * levels 3-4) = 152.8 KB -> one block per CU;
+    /* levels 1-2: 8192 entries, no long table = 72.6 KB of LDS -> two blocks per CU;
+     * levels 3-4: 16384 entries + a second table keyed by 8 bytes (the double-fast idea of zstd's
+     * levels 3-4) = 138.1 KB -> one block per CU;
      * levels >= 5: exact hash chains over a 4-byte hash (zstd: greedy / lazy / lazy2 / btlazy2); the size of the
      * head table hardly matters there (a collision costs one chain step): 5888 entries -> two blocks per CU */
     {
@@ -37,7 +37,7 @@ int qzstd_hip_profile_for_level(int level, size_t blockSize, qzstd_hip_profile_t
 #ifndef QZ_CHAIN_TABLE
 #define QZ_CHAIN_TABLE 5888u /* head-table entries of the chain levels (A/B builds: make variant XFLAGS=-DQZ_CHAIN_TABLE=n) */
 #endif
-        out->tableSize = chains ? QZ_CHAIN_TABLE : (level >= 3 ? 16000u : 6400u);
+        out->tableSize = chains ? QZ_CHAIN_TABLE : (level >= 3 ? 16384u : 8192u); /* below the chain levels powers of two: the slot is a shift (round 5; 16000 / 6400 and a multiply-high before) */
         out->longSize = (!chains && level >= 3) ? 8192u : 0u;
         out->tileLog = 9;
 #ifndef QZ_CAP_HI
@@ -105,7 +105,7 @@ size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockL
 #endif
 #define QZ_RING_BYTES (QZ_RING + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip: kRing) */
 
-/* LDS per workgroup: independent of the block size — 65 392 B at levels 1-2 (two workgroups per CU) */
+/* LDS per workgroup: independent of the block size — 72 560 B at levels 1-2 (two workgroups per CU) */
 size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
 {
     qzstd_hip_profile_t p;
