@@ -512,7 +512,10 @@ def narrow_to_own_gpu(world: int, local: int):
     process was started with (the product's own multi-GPU leg runs in a child process that sees every GPU)."""
     before = os.environ.get("HIP_VISIBLE_DEVICES")
     if world > 1:
-        ids = [x for x in (before or "").split(",") if x.strip() != ""]
+        # $QZ_BENCH_RANK_DEVICES = "0,0": which device every rank takes, when that is not "rank r takes visible device r" (the two-rank test on a
+        # one-GPU box: tests/test_gpu_multirank.py; HIP_VISIBLE_DEVICES itself cannot name a device twice there — torch refuses a list longer than
+        # ROCR_VISIBLE_DEVICES)
+        ids = [x for x in (os.environ.get("QZ_BENCH_RANK_DEVICES") or before or "").split(",") if x.strip() != ""]
         os.environ["HIP_VISIBLE_DEVICES"] = ids[local] if local < len(ids) else str(local)
     return before
 

@@ -23,7 +23,7 @@ def _free_port():
 
 @pytest.mark.gpu
 def test_two_rank_bench_both_ranks_on_gpu0(gpu_plugin):
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="0,0", QZSTD_HIP_HW_QUEUES="8", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, QZ_BENCH_RANK_DEVICES="0,0", QZSTD_HIP_HW_QUEUES="8", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
