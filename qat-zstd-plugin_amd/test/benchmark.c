@@ -362,7 +362,9 @@ int main(int argc, char **argv)
         const unsigned np = o.loops < MAX_PASSES ? o.loops : MAX_PASSES;
         double r[MAX_PASSES];
         unsigned n = 0;
-        for (unsigned l = 0; l < np; l++)
+        /* the first pass is the ramp (contexts, the device layer's start-up, the service's first launch): with three passes or more it is
+         * left out of the statistics (round-4 verdict, weak 2: minima 20 x below the median were ramp passes) */
+        for (unsigned l = np >= 3 ? 1u : 0u; l < np; l++)
             if (gPassEndNs[l] > gPassStartNs[l])
                 r[n++] = (double)o.srcSize * o.threads / MB_BYTES / ((double)(gPassEndNs[l] - gPassStartNs[l]) / 1e9);
         for (unsigned i = 1; i < n; i++) /* insertion sort */
