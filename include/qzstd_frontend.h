@@ -35,7 +35,7 @@ typedef struct {
     int nThreads;        /* worker threads (>= 1) */
     int level;           /* 1..12 */
     size_t chunkSize;    /* bytes per frame, > 0 */
-    size_t segmentBytes; /* bytes announced at a time at most, rounded to whole chunks, <= 16 MiB (0 = 2 MiB at levels 1-4, 4 MiB at levels 5-12) */
+    size_t segmentBytes; /* bytes announced at a time at most, rounded to whole chunks, <= 16 MiB (0 = 2 MiB at levels 1-4; 4 MiB but at most 64 chunks at levels 5-12) */
     int extRepcodes;     /* ZSTD_c_searchForExternalRepcodes: 0 auto, 1 enable, 2 disable (the reference's -E) */
     int useProducer;     /* 1 = register the GPU sequence producer (with software fallback), 0 = software zstd (baseline) */
 } QZSTD_FrontParams;

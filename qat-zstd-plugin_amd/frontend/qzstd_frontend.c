@@ -166,6 +166,9 @@ QZSTD_Front *QZSTD_createFront(const QZSTD_FrontParams *p)
     f->p = *p;
     /* measured on MI355X + 16 cores: 2 MiB where the entropy stage sets the pace (levels 1-4), 4 MiB claims of one size where the match-finder does */
     seg = p->segmentBytes ? p->segmentBytes : ((size_t)(p->level >= 5 ? 4 : 2) << 20);
+    /* ... and at the chain levels at most 64 chunks per claim (round 5): a claim is one launch, its blocks one workgroup each — level 12 on 32 KiB
+     * chunks: 2 MiB claims 8.7 GB/s, 4 MiB 7.7, 8 MiB 6.3 (the kernel alone: 9.8); level 6 on 128 KiB chunks keeps its 4 MiB (32 blocks): 10.3-11.0 */
+    if (!p->segmentBytes && p->level >= 5 && seg / p->chunkSize > 64u) seg = 64u * p->chunkSize;
     if (seg > QF_HINT_MAX) seg = QF_HINT_MAX;
     f->segChunks = seg / p->chunkSize ? seg / p->chunkSize : 1;
     f->stride = ZSTD_compressBound(p->chunkSize);
