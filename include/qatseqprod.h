@@ -118,8 +118,8 @@ int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSiz
  * callbacks of these blocks have come — what a compress call's const source promises anyway, here promised from the
  * announcement on — and the per-callback memcmp against the staged copy is skipped (6-8 us of every 128 KiB callback; the
  * batch front-end, include/qzstd_frontend.h, announces this way: its source is the const argument of one call).  Blocks are
- * then matched by ADDRESS only, every block is served ONCE, going forward, and the announcement ends at the first callback that does
- * not look like its announcer walking it (see "Lifetime" below).  Breaking the promise while the announcement is alive produces
+ * then matched by ADDRESS only, every block is served ONCE, going forward: a block asked for a second time ends the announcement
+ * (see "Lifetime" below).  Breaking the promise while the announcement is alive produces
  * frames that do not decode to the input: use it only for memory nobody else writes, and end it with QZSTD_dropHints() when the
  * job is over.  Every 16th block served from a STABLE announcement is compared with the staged copy anyway (0.5 us per block on
  * average): a mismatch ends the announcement, the block is match-found afresh and QZSTD_hintBroken() counts it — a sampled check
@@ -129,8 +129,8 @@ int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcS
                        size_t blockSize, int compressionLevel, unsigned int flags);
 
 /* Lifetime of an announcement — bounded, whatever the caller does: it ends when the callback of its last block has come; when a
- * callback finds its bytes changed (verified announcements); when a callback asks a STABLE announcement for a block a second time or
- * off its grid (a buffer that is being used again); when one of its blocks could not be served (a STABLE one ends there, a verified
+ * callback finds its bytes changed (verified announcements); when a callback asks a STABLE announcement for a block a second time
+ * (a buffer that is being used again); when one of its blocks could not be served (a STABLE one ends there, a verified
  * one only if that was its last block); when a newer announcement names addresses it covers; after 16 callbacks in a row it could not
  * serve; at QZSTD_dropHints(); with its state.  A state keeps at most four; callbacks look at the newest first.
  *

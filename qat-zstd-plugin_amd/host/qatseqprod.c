@@ -1440,8 +1440,8 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
      * one block flowing into the first sequence of the next.  The bytes of the callback must still
      * equal the staged copy the sequences were computed from (the caller may have reused or changed the buffer
      * since the announcement): one memcmp per callback, a mismatch drops the announcement — unless the announcer promised to hold
-     * the bytes still (QZSTD_HINT_STABLE); such an announcement serves every block ONCE, going forward, and is dropped by anything
-     * that does not look like its announcer walking it (round-4 ADVICE).  The newest announcement is looked at first: an older
+     * the bytes still (QZSTD_HINT_STABLE); such an announcement serves every block ONCE, going forward: a block asked for a second time
+     * ends it (round-4 ADVICE).  The newest announcement is looked at first: an older
      * one that names the same addresses never shadows it. */
     {
         int order[QZ_HINTS], n = 0, oi, k;
@@ -1463,11 +1463,10 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 rel = (size_t)(p - h->base);
                 b = rel / h->block;
                 byAddr = 1;
-                if (rel % h->block != 0 || b >= h->nb) { if (h->stable) qzHintDrop(h); continue; }
+                if (rel % h->block != 0 || b >= h->nb) continue; /* off the grid (libzstd 1.5.7 pre-splits multi-block frames at 32 KiB steps): not served from here */
                 for (e = b; e < h->nb && covered < srcSize; e++) covered += h->hDesc[e].srcLen;
                 if (covered != srcSize || e - b > 8) {
                     QZ_LOG(3, "announcement %d: block %zu+%zu does not fit the grid (%zu)\n", k, rel, srcSize, h->block);
-                    if (h->stable) qzHintDrop(h); /* its announcer would not ask this: nothing vouches for these addresses any more */
                     continue;
                 }
                 if (h->stable && b < h->servedUpTo) {
@@ -1862,7 +1861,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
 }
 
 /* Lifetime of an announcement (round-4 ADVICE): it ends when the callback of its last block has come, when a callback finds its bytes
- * changed (verified announcements) or asks for a block a second time / off the grid (STABLE ones), when one of its blocks could not be
+ * changed (verified announcements) or asks for a block a second time (STABLE ones), when one of its blocks could not be
  * served, when a new announcement names addresses it covers, after 16 callbacks in a row that it could not serve, at
  * QZSTD_dropHints(), and with its state.  At most four are alive per state. */
 int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
