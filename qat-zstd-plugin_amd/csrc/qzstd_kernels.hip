@@ -1503,7 +1503,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             }
             /* the walk: chainDepth links, newest first; a link whose tag differs is a slot collision (skipped without
              * touching its bytes); the candidate with the highest gain stays, the nearer one on a tie */
-            const uint32_t cap = valid ? umin(pf.capLen, segE - p) : 0u; /* a match never leaves its segment */
+            const uint32_t cap = valid ? umin(umin(pf.capLen, 48u), segE - p) : 0u; /* a match never leaves its segment; candidates are measured up to 48 bytes */
             uint32_t walked = 0;
             if (history) E[0] = 0u; /* a tile before the segment (segment mode): inserted and linked, not matched */
             int bg = 0;
@@ -1598,13 +1598,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         for (int g = 0; g < kG; g++) {
                             if (m[g] && cl < cap) { /* (a best that fills the cap cannot be beaten: the sequential walk would not have looked) */
                                 uint32_t l = head_cmp(oa, Q[g], q[g] & 3u);
-                                if (l == 16u && cap > 16u) {
-                                    for (;;) {
-                                        const uint32_t c = chunk_len(src, p + l, ring_fwd(rp, l), p - q[g], far[g]);
-                                        l += c;
-                                        if (c < 32u || l >= cap) break;
-                                    }
-                                }
+                                if (l == 16u && cap > 16u) l += chunk_len(src, p + 16u, ring_fwd(rp, 16u), p - q[g], far[g]); /* ONE step of 32: the cap is 48 at every level (round 5) */
                                 l = umin(l, cap);
                                 const int gn = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q[g] + 1u));
                                 if (l >= 4u && (cl == 0u || gn > bg)) { cl = l; off = p - q[g]; bg = gn; }
