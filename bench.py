@@ -1008,9 +1008,12 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     out["product_multi_gpu"] = {"error": repr(e)[:300]}
         details = write_details(out)
-        for k in out:  # the side legs, one earlier line per key ('# ' in front: not the line of record)
+        # the side legs go to the details file and, one line per key, to STDERR: stdout carries the line of record and nothing else (whatever
+        # the driver's capture limit is — round 4's 20 KB line was cut — 2 KB of stdout fit it, head or tail)
+        for k in out:
             if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
-                print("# %s: %s" % (k, json.dumps(out[k])))
+                print("# %s: %s" % (k, json.dumps(out[k])), file=sys.stderr)
+        sys.stderr.flush()
         print(json.dumps(slim_line(out, details)))  # the LAST stdout line, < 4 KB: what the driver parses
         sys.stdout.flush()
     if world > 1:
