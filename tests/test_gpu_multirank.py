@@ -43,4 +43,25 @@ def test_two_rank_bench_both_ranks_on_gpu0(gpu_plugin):
     assert "cpu_binding_rank0" in cfg and "bound" in cfg["cpu_binding_rank0"], cfg
     assert line["roofline"]["kernel_ms_avg"] > 0 and line["roofline"]["bound"] == "hbm"
     assert line["cpu_baseline"] is None  # the CPU legs run at N = 1 only (bench contract)
-    assert sum(1 for x in lines if x.startswith("{")) == 1  # exactly one JSON line: rank 0's
+    assert len(lines) == 1  # stdout carries exactly one line: rank 0's
+
+
+@pytest.mark.gpu
+def test_single_rank_bench_stdout_is_exactly_the_line_of_record(gpu_plugin):
+    """N = 1, a small shape: stdout carries ONE line — the short JSON line with the contract's keys — and nothing else (round 4's 20 KB
+    line came back from the driver as parsed = null; the side legs live in bench_details.json and on stderr)"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--blocks", "512",
+                          "--e2e-blocks", "512"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [x for x in out.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout[:500]
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "vs_cpu_baseline", "details_file"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["config"]["libzstd_fast_build"] is True and line["config"]["producer_errors"] == 0
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["peak"] == 8000.0
+    assert os.path.isfile(os.path.join(ROOT, line["details_file"]))
