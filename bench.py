@@ -626,7 +626,17 @@ def main():
         local_dev = 0  # the only device this rank sees
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (a barrier and a MAX of the elapsed time): gloo — the data path has no collective and no RCCL
-        dist.init_process_group("gloo")
+        # (gloo's C++ side prints "[Gloo] Rank r is connected to ..." on fd 1: stdout carries the line of record and nothing else, so the file
+        # descriptor points at stderr while the group comes up)
+        sys.stdout.flush()
+        fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            os.dup2(fd1, 1)
+            os.close(fd1)
     else:
         local_dev = local
     torch.cuda.set_device(local_dev)
