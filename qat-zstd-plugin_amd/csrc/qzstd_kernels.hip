@@ -1219,7 +1219,10 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
         if (!QZ_ABLATED(32u)) __builtin_amdgcn_s_setprio(3); /* the serial critical path: win issue arbitration on its SIMD */
-        constexpr uint32_t kSplit = 3; /* windows parsed in interval 1 (the short one), the rest in interval 2 */
+#ifndef QZ_PARSE_SPLIT
+#define QZ_PARSE_SPLIT 3 /* windows parsed in interval 1 (the short one), the rest in interval 2 (A/B builds) */
+#endif
+        constexpr uint32_t kSplit = QZ_PARSE_SPLIT;
 #ifdef QZ_DEBUG_DUMP
         u64 pI1 = 0, pW1 = 0, pI2 = 0, pW2 = 0, tQ = __builtin_amdgcn_s_memtime();
 #define QZ_PLAP(acc) { const u64 tN = __builtin_amdgcn_s_memtime(); acc += tN - tQ; tQ = tN; }
