@@ -921,7 +921,7 @@ def main():
                     out["value_e2e"]["frac_of_replay_ceiling"] = round(v / ceil["value"], 3)
                     if "value" in plain:
                         out["unchanged_callers"]["frac_of_replay_ceiling"] = round(plain["value"] / ceil["value"], 3)
-            # ---- indicative only (short runs, one value each): more threads than cores, the opt-in look-ahead, software through the front-end
+            # ---- indicative only (short runs, one value each): more threads than cores, the launch path, software through the front-end
             t_more = max(base_t + 1, int(1.25 * base_t))
             sweep = []
             for t in sorted({t_more, 2 * base_t, min(4 * base_t, 128)}):
@@ -966,7 +966,7 @@ def main():
                         pl["speedup_vs_libzstd_1_5"] = round(pl["MBps_wall"] / max(swl["MBps_wall"], 1e-9), 2)
                         if "MBps_wall" in sw14l:
                             pl["speedup_vs_libzstd_1_4"] = round(pl["MBps_wall"] / max(sw14l["MBps_wall"], 1e-9), 2)
-                    # the batch front-end at that level (its defaults: 2 MiB claims at levels 1-4, uniform 4 MiB claims at the chain levels), one
+                    # the batch front-end at that level (its defaults: 2 MiB claims at levels 1-4, uniform claims of 4 MiB / at most 64 chunks at the chain levels), one
                     # 512 MiB buffer (level 12: 256 MiB of the web-log corpus in 32 KiB chunks, BASELINE config 4's shape) — a pass over 128 MiB
                     # takes 6 ms at level 3 and is all ramp and tail —, median pass of about 1.5 s
                     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:

@@ -61,7 +61,7 @@ int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
     if (level < 1 || level > 12 || !out) return -1;
     memset(out, 0, sizeof(*out));
     (void)blockSize; /* the profile does not depend on the block size (the kernel's LDS footprint is fixed) */
-    /* levels 1-2: 6400 + no long table = 81.6 KB of LDS, two blocks per CU; levels 3-4: a bigger
+    /* levels 1-2: 8192 entries, no long table = 72.6 KB of LDS, two blocks per CU; levels 3-4: a bigger
      * table plus a second table keyed by 8 bytes (the double-fast idea of zstd's levels 3-4), one block per CU;
      * levels >= 5: exact hash chains (zstd: greedy / lazy / lazy2 / btlazy2 over a 4-byte hash), where the size
      * of the head table hardly matters (a collision costs one chain step): 5888 entries, two blocks per CU */

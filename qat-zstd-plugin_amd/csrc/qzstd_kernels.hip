@@ -2510,7 +2510,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX) return fail_msg("qzstd_hip_find_sequences: block larger than 128 KiB");
     if (qzstd_hip_profile_for_level(level, maxBlockLen, &a.prof))
         return fail_msg("qzstd_hip_find_sequences: level outside 1..12 (optionally | QZSTD_HIP_LEVEL_REPCODES)");
-    if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 128 || a.prof.capLen < 32 ||
+    if (a.prof.tileLog != kTileLog || a.prof.extLog < 8 || a.prof.extLog > 15 || a.prof.capLen > 48 || a.prof.capLen < 32 || /* (the kernels measure candidates up to 48 bytes: the 16-byte head and one step of 32) */
         a.prof.minMatch < 4 || a.prof.hashBytes < 4 || a.prof.hashBytes > 8 || a.prof.repWin > 16 || a.prof.chainDepth > 64 ||
         a.prof.lazy > 4 || (a.prof.subTileLog != 0u && a.prof.subTileLog != 6u) || (a.prof.segLog != 0u && (a.prof.segLog < kTileLog || a.prof.segLog > 17u)) ||
         (a.prof.chainDepth && (a.prof.subTileLog != 6u || a.prof.longSize || a.prof.nearTab)) || (a.prof.longSize && a.prof.subTileLog))

@@ -268,7 +268,7 @@ static pthread_mutex_t qzOrphanMu = PTHREAD_MUTEX_INITIALIZER;
 typedef struct {
     int slotHint;
     unsigned int failOffloadCnt;
-    /* look-ahead batches served to later callbacks (QZSTD_hintSource): two, so that the GPU can
+    /* announced batches served to later callbacks (QZSTD_hintSource): so that the GPU can
      * work on the next buffer while libzstd entropy-codes the current one on this thread */
     QZSTD_Hint_T hint[QZ_HINTS]; /* announced by the caller, a ring of four */
     int hintNext;                /* the ring slot the next announcement tries first */
@@ -1033,7 +1033,7 @@ static void qzPartFinish(QZSTD_Hint_T *h, QZSTD_Part_T *pt)
         if (w != 0 && h->nStuck < QZ_HINT_PARTS) h->stuckSlot[h->nStuck++] = pt->slot; /* ... and the kernel may still use h's buffers */
         qzReleaseSlot(pt->slot);
         pt->st = w == 0 ? 2 : 3;
-        if (w != 0) QZ_LOG(1, "look-ahead batch failed: %s\n", qzstd_hip_last_error());
+        if (w != 0) QZ_LOG(1, "announced batch failed: %s\n", qzstd_hip_last_error());
     } else {
         pt->st = 3;
     }
@@ -1603,7 +1603,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
     return rc;
 }
 
-/* ---------------------------------------------------------------- look-ahead ----- */
+/* ---------------------------------------------------------------- announcements -- */
 
 /* grow-only buffers: returns the (possibly new) pointer, NULL on failure */
 static void *qzGrowHostC(void *old, size_t *cap, size_t need, int dev, int coherent)
@@ -1753,7 +1753,7 @@ static int qzLaunchPart(QZSTD_Session_T *s, QZSTD_Hint_T *h, QZSTD_Part_T *pt, s
     return 0;
 fail:
     for (b = b0; b < b1; b++) h->hCount[b] = QZSTD_HIP_NSEQ_ERROR; /* never launched: nothing will publish these */
-    QZ_LOG(1, "look-ahead not taken: %s\n", qzstd_hip_last_error());
+    QZ_LOG(1, "announcement not queued: %s\n", qzstd_hip_last_error());
     qzReleaseSlot(i);
     return -1;
 }
