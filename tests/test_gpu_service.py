@@ -167,12 +167,13 @@ z, plug = B.Zstd(), B.Plugin()
 assert plug.lib.QZSTD_startQatDevice() == 0
 data = K.by_name("system", 32 * 131072, seed=23)
 buf = (C.c_char * len(data)).from_buffer_copy(data)
-stop = time.time() + 2.0
 out = {}
 def run(level, announce):
     st = plug.lib.QZSTD_createSeqProdState()
     zc = z.cctx(level, producer=plug.producer_addr, state=st, fallback=False, validate=True)
     n = 0
+    z.compress2(zc, data[:131072])  # (the first call pays the device layer's start-up, the service's first launch: not part of the two seconds)
+    stop = time.time() + 2.0
     while time.time() < stop:
         if announce: plug.lib.QZSTD_hintSource(st, buf, len(data), 131072, level)
         for c in range(32):
