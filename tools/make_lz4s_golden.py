@@ -258,7 +258,12 @@ def main():
                             "the case's seed / size / level — serialised as LZ4s by serialise_lz4s() and decoded by the same reference decoder: "
                             "expect is what the reference's code makes of this match-finder's real output",
            "oracle_vectors": run_reference(make_oracle_streams())}
-    text = json.dumps(doc, indent=1) + "\n"
+    # one vector per line (the expected lists of the oracle vectors hold hundreds of triples each: indent=1 made a 17 000-line file of them)
+    head = {k: v for k, v in doc.items() if k not in ("vectors", "oracle_vectors")}
+    text = "{\n" + "".join(" %s: %s,\n" % (json.dumps(k), json.dumps(v)) for k, v in head.items())
+    text += ' "vectors": [\n' + ",\n".join("  " + json.dumps(v) for v in doc["vectors"]) + "\n ],\n"
+    text += ' "oracle_vectors": [\n' + ",\n".join("  " + json.dumps(v) for v in doc["oracle_vectors"]) + "\n ]\n}\n"
+    assert json.loads(text) == doc
     if "--check" in sys.argv:
         same = open(OUT).read() == text
         print("lz4s_ref_vectors.json %s what the reference's decoder produces now" % ("equals" if same else "DIFFERS FROM"))
