@@ -1615,8 +1615,11 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* (the next step starts with these values anyway) */
                 dC[5] += 1;
 #endif
+                /* a best that fills the cap cannot be beaten: that position's walk ends here (round 5) — it used to ride along with nothing to do
+                 * until the wave's last lane had run out of links, keeping the loop alive and its next entry in flight */
+                const bool full = cl != 0u && cl >= cap;
 #pragma unroll
-                for (uint32_t j = 0; j < kEL; j++) E[j] = N[j];
+                for (uint32_t j = 0; j < kEL; j++) E[j] = full ? 0u : N[j];
                 QZ_CLAP(4)
             }
         } else {
