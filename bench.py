@@ -99,6 +99,17 @@ def load_corpus(name: str, size: int) -> tuple[bytes, str]:
     return (raw * reps)[:size], "synthetic:%s(seed=%d,%d B) repeated" % (name, seed, unit)
 
 
+def corpus_unit_bytes(name: str, size: int) -> int:
+    """bytes of the unit load_corpus() repeats to `size` (so that a sample can hold whole units: round-5 verdict, weak 2 — software level 1
+    is 9.5 % faster on the whole system-corpus unit than on its first 32 MiB)"""
+    if os.path.isfile(name):
+        return min(size, os.path.getsize(name))
+    if name == "system":
+        real = sum(len(p) for _, p in K.system_corpus_parts())
+        return min(size, real) if real >= 4 * K.MiB else size
+    return min(size, 64 * K.MiB)
+
+
 SLIM_LINE_MAX = 4096  # the driver parses the LAST stdout line; round 4's 20 KB line came back as parsed = null
 
 
@@ -109,7 +120,8 @@ def _short(x, n):
 
 def slim_line(out: dict, details_file: str | None) -> dict:
     """The measurement of record: ONE short JSON line (the shape of the reference's one-line report, test/benchmark.c:374-382) with the
-    contract's keys and nothing else; every side leg lives in the details file the line names.  Raises when the line would not fit."""
+    contract's keys and little else; every side leg lives in the details file the line names.  A line that would not fit loses its optional
+    keys one by one (round-5 ADVICE: never end a finished run without its line); the contract's keys always fit."""
     cfg, rf, cb = out.get("config", {}), out.get("roofline", {}), out.get("cpu_baseline")
     line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                     "vs_baseline", "dtype")}
@@ -127,15 +139,45 @@ def slim_line(out: dict, details_file: str | None) -> dict:
                                                "algorithmic_bytes_per_launch", "launches_timed")}
     line["roofline"]["launch_workload"] = _short(rf.get("launch_workload", ""), 160)
     if cb:
-        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")}
-        line["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 360)
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "same_bytes_as_value", "sw_ratio_on_sample",
+                                                       "sw_ratio_on_value_bytes") if k in cb}
+        line["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 420)
     else:
         line["cpu_baseline"] = None  # (--no-cpu, or N > 1: the CPU legs run on rank 0 at N = 1 only)
     line["vs_cpu_baseline"] = out.get("vs_cpu_baseline")
+    # round-5 verdict: the median pass of `value` and what UNCHANGED callers get (nothing announced: the reference's `benchmark -m1 -tN`
+    # shape, /root/reference/test/benchmark.c:261-267) belong in the line of record, not only in the details
+    line["value_median_pass"] = (out.get("e2e") or {}).get("MBps_median_pass_this_rank")
+    line["compressed_size_vs_software_same_bytes"] = out.get("compressed_size_vs_software_same_bytes")
+    uc = out.get("unchanged_callers") or {}
+    if "value" in uc:
+        line["unchanged_callers"] = {"MBps": uc.get("value"), "threads": uc.get("threads"), "latency_us_p50": uc.get("latency_us_p50"),
+                                     "vs_cpu_baseline": uc.get("vs_cpu_baseline"), "frac_of_replay_ceiling": uc.get("frac_of_replay_ceiling"),
+                                     "producer_errors": (uc.get("producer_errors") or {}).get("total"),
+                                     "one_thread_MBps": (uc.get("one_thread") or {}).get("plain_MBps"),
+                                     "one_thread_vs_software": (uc.get("one_thread") or {}).get("plain_vs_software_1_5"),
+                                     "what": "plain ZSTD_compress2 callers, plugin registered, nothing announced (benchmark -m1 -tN)"}
+    bc = out.get("box_ceilings") or {}
+    if "h2d" in bc:
+        line["box_ceilings_GBps"] = {"h2d": bc["h2d"].get("GBps_median"), "d2h": bc["d2h"].get("GBps_median"),
+                                     "both_sum": (bc.get("both_directions_at_once") or {}).get("GBps_sum_median"),
+                                     "d2d_hbm_traffic": (bc.get("d2d_copy_1GiB") or {}).get("GBps_hbm_traffic_median"),
+                                     "pcie": (bc.get("pcie_link_this_gpu") or {}).get("speed"), "width": (bc.get("pcie_link_this_gpu") or {}).get("width")}
     line["details_file"] = details_file
-    n = len(json.dumps(line))
-    if n >= SLIM_LINE_MAX:
-        raise AssertionError("bench line is %d bytes (limit %d): move keys to the details file" % (n, SLIM_LINE_MAX))
+    # too long after all: the optional keys go first, in this order; the contract's keys stay whatever happens
+    def drop(*path):
+        d = line
+        for k in path[:-1]:
+            d = d.get(k) if isinstance(d.get(k), dict) else {}
+        d.pop(path[-1], None)
+    for path in (("box_ceilings_GBps",), ("config", "cpu_binding_rank0"), ("roofline", "launch_workload"), ("unchanged_callers", "what"),
+                 ("cpu_baseline", "sample"), ("config", "libzstd_build"), ("config", "parallelism"), ("unchanged_callers",)):
+        if len(json.dumps(line)) < SLIM_LINE_MAX:
+            break
+        drop(*path)
+    if len(json.dumps(line)) >= SLIM_LINE_MAX:
+        line["config"] = {"workload": _short(cfg.get("workload", ""), 120)}
+        line["data"] = _short(line["data"], 40)
     return line
 
 
@@ -759,6 +801,23 @@ def main():
     wall, per_pass, e2e_info = e2e_steps(front, prm, e2e_buf, block, a.steps, a.warmup, torch.cuda.synchronize,
                                          (dist.barrier if world > 1 else (lambda: None)))
     wall = S.reduce_max_seconds(wall, dist if world > 1 else None, None)  # gloo: a CPU tensor
+    # ---- the software path over THE SAME BYTES, the same chunking, the same thread pool (round-5 verdict: cpu_baseline was timed on the first
+    # 32 MiB of the corpus while `value` ran over all of it): QZSTD_frontCompress with useProducer = 0 — ZSTD_compress2 per chunk, plugin
+    # unregistered, libzstd's own match-finder — over e2e_buf, once with as many threads as usable cores and once with `value`'s thread count
+    sw_same = None
+    if rank == 0 and world == 1 and not a.no_cpu:
+        sw_same = []
+        for t in sorted({max(1, min(int(host_cpu_budget()[1]), 128)), e2e_threads}):
+            try:
+                prm0 = B.FrontParams(t, level & 0xFF, block, 2 << 20, 1 if (level & 0x100) else 0, 0)
+                w0, per0, inf0 = e2e_steps(front, prm0, e2e_buf, block, max(5, min(a.steps, 12)), 1, (lambda: None), (lambda: None))
+                srt0 = sorted(per0)
+                sw_same.append({"threads": t, "MBps_median_pass": round(len(e2e_buf) / srt0[len(srt0) // 2] / 1e6, 1),
+                                "MBps_mean": round(len(e2e_buf) * len(per0) / sum(per0) / 1e6, 1), "MBps_best_pass": round(len(e2e_buf) / srt0[0] / 1e6, 1),
+                                "passes": len(per0), "csize": inf0["csize"], "ratio": round(len(e2e_buf) / max(inf0["csize"], 1), 4),
+                                "roundtrip_sampled": inf0["roundtrip_sampled"]})
+            except Exception as e:  # noqa: BLE001 - the bench line must still be printed
+                sw_same.append({"threads": t, "error": repr(e)[:200]})
     L.QZSTD_stopQatDevice()  # (the front-end started the device layer; the side legs below run in child processes or start it again)
 
     if rank == 0:
@@ -849,9 +908,17 @@ def main():
                            "note": "a cgroup CPU quota caps what threads can add: past usable_cores, more threads only hide latency"}
             build_tools()
             out["pcie_pipeline"] = pcie_pipeline_leg(plug, shard, block, level, local)
+            try:  # the box's own ceilings, raw runtime copies: PCIe H2D / D2H / both at once, HBM D2D — what pcie_pipeline is up against
+                import box_ceilings
+                out["box_ceilings"] = box_ceilings.measure(256, 3, 5, local)
+            except Exception as e:  # noqa: BLE001
+                out["box_ceilings"] = {"error": repr(e)[:200]}
             out["cpu_oracle_port"] = cpu_oracle_leg(shard, block, level, min(a.cpu_seconds, 6.0))
             # one sample file for every tool run (per-thread buffer, as the reference's benchmark reads one file per run)
-            sample = shard[:min(len(shard), 256 * block)]
+            # (round 6: whole corpus UNITS, not the first 32 MiB — the batch `value` runs over is this unit repeated, and software level 1 is
+            # 9.5 % faster on the whole unit than on its head; rounded up to whole chunks)
+            unit = corpus_unit_bytes(a.corpus, size)
+            sample = shard[:min(len(shard), -(-unit // block) * block)]
             with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
                 f.write(sample)
                 fname = f.name
@@ -865,15 +932,32 @@ def main():
             sw14 = measured(lambda l: c_benchmark(fname, block, level, base_t, mode=0, loops=l, tool="benchmark_sw", passes=True), tgt)
             out["cpu_libzstd_1_5"] = sw
             out["cpu_libzstd_1_4"] = sw14
-            best_sw = max([x for x in (sw, sw14) if "value" in x], key=lambda x: x["value"], default=None)
-            if best_sw:
-                other = sw if best_sw is sw14 else sw14
-                out["cpu_baseline"] = {"value": best_sw["value"], "min": best_sw["min"], "max": best_sw["max"], "unit": "MB/s", "cores": base_t, "kind": "reference",
-                                       "sample": "libzstd %s own match-finder, plugin unregistered (the reference's software path, test/benchmark.c -m0 shape): "
-                                                 "%d threads x %d MiB x %d passes (%.1f s of continuous load), one frame per %d KiB chunk, wall clock, median pass; "
-                                                 "the same with libzstd %s: %s MB/s"
-                                                 % (best_sw["libzstd"], base_t, len(sample) >> 20, best_sw["passes"], best_sw["continuous_load_s"], block >> 10,
-                                                    other.get("libzstd"), other.get("value"))}
+            out["cpu_libzstd_same_bytes_as_value"] = sw_same
+            # cpu_baseline = the FASTEST software figure of this run (the conservative denominator), over the bytes `value` ran over:
+            #   - QZSTD_frontCompress with useProducer = 0 over the very buffer of the timed region (same chunks, same pool), median pass;
+            #   - the benchmark tool's -m0 (the reference's software path, test/benchmark.c shape) over whole corpus units, 1.5.x and 1.4.x.
+            # sw_ratio_on_sample / sw_ratio_on_value_bytes show that the tool's sample compresses like the timed buffer (round-5 verdict: within 1 %).
+            same_ok = [x for x in (sw_same or []) if "MBps_median_pass" in x]
+            cands = [dict(value=x["MBps_median_pass"], cores=x["threads"], ratio=x["ratio"], same=True,
+                          what="QZSTD_frontCompress with useProducer = 0 (ZSTD_compress2 per %d KiB chunk, plugin unregistered, libzstd %s own match-finder) over the "
+                               "SAME %d MiB buffer as `value`, %d threads, median of %d passes" % (block >> 10, B.Zstd().version(), len(e2e_buf) >> 20, x["threads"], x["passes"]))
+                     for x in same_ok]
+            cands += [dict(value=x["value"], cores=base_t, ratio=x.get("ratio"), same=False,
+                           what="libzstd %s own match-finder, plugin unregistered (the reference's software path, test/benchmark.c -m0 shape): %d threads x %d MiB "
+                                "(whole corpus units: the batch of `value` is this unit repeated) x %d passes (%.1f s of continuous load), one frame per %d KiB chunk, median pass"
+                                % (x["libzstd"], base_t, len(sample) >> 20, x["passes"], x["continuous_load_s"], block >> 10))
+                      for x in (sw, sw14) if "value" in x]
+            if cands:
+                best = max(cands, key=lambda c: c["value"])
+                rest = "; ".join("%s MB/s: %s" % (c["value"], c["what"][:60]) for c in cands if c is not best)
+                out["cpu_baseline"] = {"value": best["value"], "unit": "MB/s", "cores": best["cores"], "kind": "reference",
+                                       "same_bytes_as_value": bool(best["same"]),
+                                       "sw_ratio_on_sample": sw.get("ratio"), "sw_ratio_on_value_bytes": same_ok[0]["ratio"] if same_ok else None,
+                                       "sample": best["what"] + " — the fastest of this run's software figures; the others: " + rest,
+                                       "candidates": [{k: c[k] for k in ("value", "cores", "ratio", "same", "what")} for c in cands]}
+            if same_ok and e2e_info.get("csize"):
+                # the north star's 2 % criterion on the very bytes of `value`: frames of the timed region vs software frames of the same chunks
+                out["compressed_size_vs_software_same_bytes"] = round(e2e_info["csize"] / same_ok[0]["csize"], 4)
 
             def served(r):
                 """a leg only counts as the GPU's when no producer callback fell back to libzstd's own match-finder"""
@@ -929,6 +1013,8 @@ def main():
                                     "plain_vs_software_1_5": round(one["plain"]["MBps_wall"] / max(one["software"]["MBps_wall"], 1e-9), 3),
                                     "passes": one["plain"].get("passes"), "how": "median pass of ~2 s of passes over a 32 MiB buffer, per leg",
                                     "producer_errors": one["plain"].get("producer_errors")}
+            if "value" in plain and (out.get("cpu_baseline") or {}).get("value"):
+                uc["vs_cpu_baseline"] = round(plain["value"] / out["cpu_baseline"]["value"], 3)
             out["unchanged_callers"] = uc
             if "value" in front:
                 v = front["value"]

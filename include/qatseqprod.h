@@ -114,7 +114,8 @@ void QZSTD_freeSeqProdState(void *sequenceProducerState);
 int QZSTD_hintSource(void *sequenceProducerState, const void *src, size_t srcSize,
                      size_t blockSize, int compressionLevel);
 
-/* The same with flags (additive, round 4).  QZSTD_HINT_STABLE: the caller holds [src, src + srcSize) unchanged until the
+/* The same with flags (additive, round 4).  QZSTD_HINT_STABLE — NOT VERIFIED PER BLOCK, ONLY SAMPLED (1 block in 16): a caller that
+ * breaks the promise below may get up to 15 blocks of stale sequences before the library notices.  The caller holds [src, src + srcSize) unchanged until the
  * callbacks of these blocks have come — what a compress call's const source promises anyway, here promised from the
  * announcement on — and the per-callback memcmp against the staged copy is skipped (6-8 us of every 128 KiB callback; the
  * batch front-end, include/qzstd_frontend.h, announces this way: its source is the const argument of one call).  Blocks are
@@ -130,9 +131,11 @@ int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcS
 
 /* Lifetime of an announcement — bounded, whatever the caller does: it ends when the callback of its last block has come; when a
  * callback finds its bytes changed (verified announcements); when a callback asks a STABLE announcement for a block a second time
- * (a buffer that is being used again); when one of its blocks could not be served (a STABLE one ends there, a verified
- * one only if that was its last block); when a newer announcement names addresses it covers; after 16 callbacks in a row it could not
- * serve; at QZSTD_dropHints(); with its state.  A state keeps at most four; callbacks look at the newest first.
+ * (a buffer that is being used again); when its LAST block could not be served (any other block that cannot be served — too many
+ * sequences for the result area, a failed launch — just takes the per-block path); when a newer announcement names addresses it covers
+ * (a STABLE one ends at once, a verified one stops serving by address and lives on for by-content look-ups: streaming callers that refill
+ * and re-announce one buffer); after 16 callbacks in a row it could not serve; at QZSTD_dropHints(); with its state.  A state keeps at
+ * most four; callbacks look at the newest first.
  *
  * QZSTD_dropHints(state): every announcement of the state ends now (launches in flight are waited for).  Call it when the job
  * the announcements belonged to is over — in particular before a buffer announced with QZSTD_HINT_STABLE is rewritten or freed

@@ -52,7 +52,7 @@ static inline uint32_t qzo_rd32(const uint8_t *p)
  * (:1132-1137); here the level picks the search profile.  Table sizes follow the
  * kernel's LDS budget: block bytes + table + 8 KiB <= 160 KiB.
  * MUST match qzstd_hip_profile_for_level() in qat-zstd-plugin_amd/csrc/qzstd_profile.c
- * (tests/test_profiles.py compares the two tables field by field).
+ * (tests/test_host_cpu.py: test_profile_tables_agree compares the two tables field by field).
  */
 int qzo_profile_for_level(int level, size_t blockSize, qzo_profile_t *out)
 {

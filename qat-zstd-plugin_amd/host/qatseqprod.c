@@ -249,6 +249,7 @@ typedef struct {
                                       * runtime's look-up takes its global lock: ~0.5 ms per call with 16 announcing threads) */
     size_t hSrcCap, hSeqsCap, hCountCap, hDescCap; /* bytes */
     int nStuck, stuckSlot[QZ_HINT_PARTS]; /* slots whose wait timed out: a kernel may still read and write the buffers above */
+    int noAddr; /* a newer announcement names (some of) these addresses: this one no longer serves by address, only by verified content */
 } QZSTD_Hint_T;
 
 /* Pinned buffers of an announcement that a timed-out kernel may still read (hSrc, hDesc) and write (hSeqs, hCount): the
@@ -1459,7 +1460,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
             k = order[oi];
             if (h->st == 0) continue; /* (dropped further up in this loop) */
             if (h->level != compressionLevel) continue;
-            if (p >= h->base && p + srcSize <= h->base + h->size) { /* by address: the callback names announced memory */
+            if (!h->noAddr && p >= h->base && p + srcSize <= h->base + h->size) { /* by address: the callback names announced memory */
                 rel = (size_t)(p - h->base);
                 b = rel / h->block;
                 byAddr = 1;
@@ -1567,10 +1568,12 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                     return out;
                 }
             }
-            /* announced but not served (a failed or timed-out part, a block with too many sequences): the per-block path takes this
-             * block.  A STABLE announcement ends here (its announcer's promise covers "until the callbacks have come": this one has,
-             * and the rest is not worth an unbounded promise); a verified one lives on for its other blocks unless this was the last */
-            if (byAddr && (h->stable || rel + srcSize >= h->size)) qzHintDrop(h);
+            /* announced but not served (a failed or timed-out part, a block with too many sequences): the per-block path takes THIS
+             * block; the announcement lives on for its other blocks unless this was the last one.  (Round 5 ended a STABLE announcement
+             * here, waiting for every launch still in flight: one dense block — more sequences than the result pitch holds — then cost
+             * the rest of a 2-4 MiB claim its announcement, a cliff on short-match data (round-5 ADVICE).  Its life is bounded without
+             * that: QZSTD_dropHints at the end of the announcer's job, the asked-twice rule above, the overlap rule of QZSTD_hintSourceEx.) */
+            if (byAddr && rel + srcSize >= h->size) qzHintDrop(h);
             else if (byAddr && e > h->servedUpTo) h->servedUpTo = e;
             break;
         }
@@ -1578,7 +1581,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
          * are dropped, so that they do not serve stale positions */
         for (k = 0; k < QZ_HINTS; k++) {
             QZSTD_Hint_T *h = &s->hint[k];
-            if (h->st != 0 && h->touched && ++h->misses > QZ_HINT_STALE_MISSES) {
+            if (h->st != 0 && (h->touched || h->noAddr) && ++h->misses > QZ_HINT_STALE_MISSES) {
                 QZ_LOG(2, "announcement %d: abandoned by the caller; dropped\n", k);
                 qzHintDrop(h);
             }
@@ -1861,9 +1864,10 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
 }
 
 /* Lifetime of an announcement (round-4 ADVICE): it ends when the callback of its last block has come, when a callback finds its bytes
- * changed (verified announcements) or asks for a block a second time (STABLE ones), when one of its blocks could not be
- * served, when a new announcement names addresses it covers, after 16 callbacks in a row that it could not serve, at
- * QZSTD_dropHints(), and with its state.  At most four are alive per state. */
+ * changed (verified announcements) or asks for a block a second time (STABLE ones), when its LAST block could not be served,
+ * when a new announcement names addresses it covers (STABLE: at once; verified: it stops serving by address and lives on for
+ * by-content look-ups), after 16 callbacks in a row that it could not serve, at QZSTD_dropHints(), and with its state.  At most
+ * four are alive per state. */
 int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcSize, size_t blockSize,
                        int compressionLevel, unsigned int flags)
 {
@@ -1881,7 +1885,14 @@ int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcS
      * caller is announcing now */
     for (k = 0; k < QZ_HINTS; k++) {
         QZSTD_Hint_T *o = &s->hint[k];
-        if (o->st != 0 && (const unsigned char *)src < o->base + o->size && o->base < (const unsigned char *)src + srcSize) qzHintDrop(o);
+        if (o->st == 0 || !((const unsigned char *)src < o->base + o->size && o->base < (const unsigned char *)src + srcSize)) continue;
+        /* A STABLE one goes (nothing but its announcer's word vouches for its bytes).  A verified one only stops serving BY ADDRESS: a
+         * streaming caller that refills and announces the same input buffer again (ZSTD_compressStream2, the zstd CLI) is served by
+         * content out of libzstd's window — every such block is compared with the staged copy — and still needs the tail blocks of the
+         * older announcement; dropping it also meant a synchronous wait for its launches on every announcement (round-5 ADVICE).  It
+         * ends as every announcement does: consumed, stale after 16 misses, pushed out by the fourth newer one, QZSTD_dropHints. */
+        if (o->stable || o->nb > QZ_CONTENT_LOOKUP_BLOCKS || !o->keys) qzHintDrop(o);
+        else o->noAddr = 1;
     }
     /* an empty place of the ring first (starting where the last announcement left off); only when all four are alive the oldest goes */
     for (k = 0; k < QZ_HINTS && !h; k++)
@@ -1899,6 +1910,7 @@ int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcS
         return -1;
     }
     h->stable = (flags & QZSTD_HINT_STABLE) != 0;
+    h->noAddr = 0;
     s->hintCalls++;
     if (s->hintCalls == 8) /* the event log's timers: steady state only (the first announcements allocate pinned buffers and create streams) */
         s->hintStageNs = s->hintQueueNs = s->hintWaitNs = s->hintCopyCallNs = s->hintLaunchCallNs = s->hintPrepNs = s->hintDropNs = 0;

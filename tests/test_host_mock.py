@@ -398,6 +398,42 @@ def test_dense_block_is_redone_alone(mock, zstd, oracle):
     assert got == oracle_frames(zstd, oracle, data, 131072, 1)
 
 
+def test_dense_block_does_not_end_its_announcement(mock, zstd, oracle):
+    """round-5 ADVICE: a STABLE announcement used to be dropped WHOLE at the first block it could not serve — one dense block (more
+    sequences than the result pitch) in a claim and the rest of the claim went through the per-block path, after a synchronous wait for
+    every launch in flight.  Now only that block takes the per-block path; the announcement serves the blocks behind it.  A verified
+    announcement over addresses a newer one names keeps serving by CONTENT (streaming callers refill and re-announce one buffer)."""
+    import random
+    rng = random.Random(7)
+    words = [bytes(rng.randrange(97, 123) for _ in range(5)) for _ in range(200)]
+    dense = b"".join(rng.choice(words) + bytes([rng.randrange(256)]) for _ in range(131072 // 6 + 1))[:131072]
+    assert oracle.find(oracle.profile(1, 131072), dense, cap=B.sequence_bound(131072))[0] > 16384
+    plain = K.by_name("system", 7 * 131072)
+    data = plain[:2 * 131072] + dense + plain[2 * 131072:]  # 8 blocks, the third one dense
+    want = oracle_frames(zstd, oracle, data, 131072, 1)
+    for stable in (1, 0):
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        st = mock.lib.QZSTD_createSeqProdState()
+        assert mock.lib.QZSTD_hintSourceEx(st, buf, len(data), 131072, 1, stable) == 0
+        got = frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), 131072, 1)
+        stats = stats_of(mock, st)
+        mock.lib.QZSTD_freeSeqProdState(st)
+        assert got == want
+        assert stats[0] == 7 and stats[1] == 1, (stable, stats)  # seven blocks from the announcement, the dense one alone
+    # a verified announcement whose addresses are announced again: by content from then on, not dropped
+    data2 = K.by_name("text", 4 * 131072, seed=11)
+    buf = (C.c_char * len(data2)).from_buffer_copy(data2)
+    other = (C.c_char * len(data2)).from_buffer_copy(data2)  # the same bytes elsewhere (libzstd's window, for a streaming caller)
+    st = mock.lib.QZSTD_createSeqProdState()
+    assert mock.lib.QZSTD_hintSource(st, buf, len(data2), 131072, 1) == 0
+    assert mock.lib.QZSTD_hintSource(st, C.byref(buf, 131072), 2 * 131072, 131072, 1) == 0  # overlaps the first
+    got = frames_of(zstd, mock.producer_addr, st, C.addressof(other), len(data2), 131072, 1)
+    stats = stats_of(mock, st)
+    mock.lib.QZSTD_freeSeqProdState(st)
+    assert got == oracle_frames(zstd, oracle, data2, 131072, 1)
+    assert stats[0] == 4 and stats[1] == 0, stats  # all four by content: the older announcement was still there for blocks 0 and 3
+
+
 def test_batch_front_end_over_the_mock(mock, zstd, oracle):
     """include/qzstd_frontend.h: a pool of CCtx threads fed from one chunk cursor, two claims kept
     announced ahead; frames are the oracle's, every block comes from an announcement"""

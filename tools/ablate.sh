@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel time of the default bench workload under the profiling build's ablation switches (GPU box).
 # usage: tools/ablate.sh "<level>" "<bits> <bits> ..."   (needs `make debug`; QZSTD_HIP_ABLATE bits: csrc/qzstd_kernels.hip)
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 LV=${1:-1}; shift
 for A in ${1:-0}; do
   echo -n "level $LV ablate $A: "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # BASELINE config 3 / 4 shapes end to end on a GPU box (C benchmark tool): level 6 on 32 MiB of Zipf text in 128 KiB
 # chunks, level 12 on 32 MiB of web-log lines in 32 KiB chunks; software zstd beside the plugin.
-cd /root/repo
+cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 python - <<'PY'
 import sys; sys.path.insert(0,'tools')
 import qz_corpus as K

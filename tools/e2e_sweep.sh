@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-to-end sweep of the C benchmark tool on the GPU box: software vs plugin (unchanged callers, announcements,
 # opt-in transparent look-ahead) over thread counts.  Usage: tools/e2e_sweep.sh [MiB per thread, default 16] [level, default 1] [chunk]
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 MB=${1:-16}; L=${2:-1}; C=${3:-131072}
 cd $R
 ZL=$(python - <<'PY'

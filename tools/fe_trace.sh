@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: kernel trace of the batch front-end — how long the announcements' launches take and how many run at a time
-cd /root/repo; export TMPDIR=/tmp
+cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp
 python - <<PY
 import sys; sys.path.insert(0, "tools"); import qz_corpus as K
 open("/tmp/fe.bin","wb").write(K.system_corpus(512 << 20)[0])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Quick kernel check on the GPU box: parity tests + kernel ms at the bench shapes.  usage: tools/kbench.sh [levels...]
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -x -q -m gpu 2>&1 | tail -2
 for LV in ${@:-1 3}; do

@@ -1,4 +1,4 @@
-cd ${GRAFT_REPO_ROOT:-/root/repo}
+cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 python - <<PY
 import sys; sys.path.insert(0, "tools"); import qz_corpus as K
 open("/tmp/e2e.bin","wb").write(K.by_name("system", 64 << 20))

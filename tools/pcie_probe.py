@@ -1,7 +1,8 @@
 import os, sys, json
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import importlib.util
-spec = importlib.util.spec_from_file_location("qz_bench", "/root/repo/bench.py"); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+spec = importlib.util.spec_from_file_location("qz_bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 import qz_bind as B
 plug = B.Plugin()
 data, _ = bench.load_corpus("system", 131072 * 8192)

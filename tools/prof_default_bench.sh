@@ -2,7 +2,7 @@
 # GPU box: rocprofv3 --kernel-trace of the DEFAULT bench command's timed path (bench.py --no-cpu: the roofline launches + the end-to-end leg),
 # the match-finder's launches grouped by grid size: the 8192-workgroup launches are the `roofline` block's, the small ones the front-end's
 # announcements (same kernel name, so `--stats` alone would average the two kinds together).
-cd ${GRAFT_REPO_ROOT:-/root/repo}; R=$PWD; export TMPDIR=/tmp
+cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; R=$PWD; export TMPDIR=/tmp
 rm -rf /tmp/dbt; mkdir -p /tmp/dbt
 (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dbt -o db -- python $R/bench.py --no-cpu > /tmp/dbt/run.log 2>&1)
 python - <<PY

@@ -3,7 +3,7 @@
 # usage: tools/prof_mem.sh <tag> <shape of tools/ktime.py>
 set -u
 TAG=$1; SHAPE=${2:-6:131072:2048:system}
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/mem_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -4,7 +4,7 @@
 # usage: tools/prof_pmc.sh <tag> [bench args...]
 set -u
 TAG=$1; shift
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -3,7 +3,7 @@
 # usage: tools/prof_stats.sh <tag>     -> gpurun_out/stats_<tag>/  (copy the summary into profiles/)
 set -u
 TAG=$1; shift
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/stats_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

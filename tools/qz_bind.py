@@ -91,10 +91,30 @@ def slow_libzstd() -> str:
         try:
             lib = C.CDLL(c)
             if hasattr(lib, "ZSTD_registerSequenceProducer"):
-                return c
+                # ctypes.util.find_library() gives a bare soname ("libzstd.so.1"): the Makefiles pass the result to gcc as a FILE and derive an
+                # rpath from its directory, so what leaves here is always the absolute path of the file the loader mapped (round-5 ADVICE, medium)
+                return c if os.path.isabs(c) else _mapped_path(c)
         except OSError:
             continue
     raise OSError("no libzstd >= 1.5.4 (ZSTD_registerSequenceProducer) found; set $ZSTDLIB")
+
+
+def _mapped_path(soname: str) -> str:
+    """absolute path of the already-dlopen()ed library the loader resolved `soname` to (from /proc/self/maps); raises OSError when it
+    cannot be told — a bare soname must never reach a link line as a file name"""
+    base = os.path.basename(soname)
+    stem = base.split(".so")[0]
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {ln.split(None, 5)[5].strip() for ln in f if ln.count("/") and len(ln.split(None, 5)) == 6}
+    except OSError:
+        paths = set()
+    hits = sorted(p for p in paths if os.path.basename(p) == base) or \
+        sorted(p for p in paths if os.path.basename(p).startswith(stem + ".so") and os.path.realpath(p) in {os.path.realpath(q) for q in paths})
+    for p in hits:
+        if os.path.isfile(p):
+            return p
+    raise OSError("cannot resolve %s to a path" % soname)
 
 
 def find_libzstd() -> str:
@@ -321,6 +341,10 @@ class Plugin:
         L.QZSTD_createSeqProdState.restype = C.c_void_p
         L.QZSTD_freeSeqProdState.argtypes = [C.c_void_p]
         L.QZSTD_hintSource.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        if hasattr(L, "QZSTD_hintSourceEx"):
+            L.QZSTD_hintSourceEx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint]
+            L.QZSTD_dropHints.argtypes = [C.c_void_p]
+            L.QZSTD_dropHints.restype = None
         L.QZSTD_hintStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong * 4)]
         L.QZSTD_hintStats.restype = None
         L.QZSTD_failStats.argtypes = [C.c_void_p, C.POINTER(C.c_ulong * 8)]

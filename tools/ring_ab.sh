@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on the GPU box: parity + kernel ms per level for library variants.  usage: gpurun -- bash tools/ring_ab.sh "<so> <so> ..." "<levels>"
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R
 for SO in $1; do
   echo "=== $SO"
   QZ_PLUGIN_SO=$R/qat-zstd-plugin_amd/lib/$SO timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -x -q -m gpu 2>&1 | tail -1
