@@ -99,6 +99,18 @@ constexpr uint32_t kEL = QZSTD_HIP_CHAIN_ENTRY_LINKS; /* links per chain entry: 
 constexpr uint32_t kEQ = QZSTD_HIP_CHAIN_ENTRY_LINKS / 4u; /* 16-byte words between consecutive entries (= per entry, outside the experiment) */
 static_assert(kEL == 4u || kEL == 8u, "chain entries hold four or eight links");
 constexpr uint32_t kLdsBase = 16u; /* first LDS byte the kernel uses (csrc/qzstd_profile.c: QZ_LDS_CTRL covers it) */
+/* Tiles between the matchers and the emission of a tile = tiles of parse words and emission records kept in LDS (csrc/qzstd_profile.c: QZ_PARSE_LAG
+ * must agree).  2 = the parse wave in lock-step with the matchers: THE PRODUCT at every level.  QZ_PARSE_LAG = 3 or 4 builds the round-6 experiment
+ * for levels 1-4 (the round-5 verdict's "take the serial parse off the barrier-critical path"): a DECOUPLED parse wave that parses whatever tile is
+ * ready, window by window, and joins the matchers' barriers when they are all waiting at one — bit-exact, and 14 % SLOWER (13.6 vs 11.9 ms per GiB
+ * at level 1; profiles/r06_ab_decoupled_parse_wave.txt says why: running without pauses, the parse wave's serial chain takes 5 200 cycles per tile
+ * and IS the tile's time, where the lock-step one took 4 600 and idled a quarter of the time). */
+#ifndef QZ_PARSE_LAG
+#define QZ_PARSE_LAG 2
+#endif
+constexpr uint32_t kParseLag = QZ_PARSE_LAG;
+static_assert(kParseLag >= 2u && kParseLag <= 4u, "2 = the lock-step parse wave of rounds 1-5 at every level");
+constexpr uint32_t kCtlArrive = 4u; /* control word: barriers the matcher waves have reached, summed over the eight waves (a HINT for the parse wave) */
 
 struct LaunchArgs {
     const uint8_t *src;
@@ -263,6 +275,18 @@ __device__ __forceinline__ uint32_t head_cmp(const uint32_t (&oa)[4], const uint
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t x = oa[i] ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
+        B = umin(B, first_diff_bit(x) | (32u * (uint32_t)i));
+    }
+    return B >> 3;
+}
+
+/* first mismatching byte (0..32) of 32 bytes already byte-aligned in `pa` and the candidate's nine dwords, already requested */
+__device__ __forceinline__ __attribute__((unused)) uint32_t tail_cmp(const uint32_t (&pa)[8], const uint32_t (&Q)[9], uint32_t qs)
+{
+    uint32_t B = 256u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t x = pa[i] ^ __builtin_amdgcn_alignbyte(Q[i + 1], Q[i], qs);
         B = umin(B, first_diff_bit(x) | (32u * (uint32_t)i));
     }
     return B >> 3;
@@ -815,6 +839,26 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     const qzstd_hip_profile_t pf = args.prof;
     const uint32_t nh = n >= pf.hashBytes ? n - pf.hashBytes + 1u : 0u; /* hashable positions */
     const uint32_t nTiles = (nh + kTile - 1u) >> kTileLog;
+    /* tiles in flight between matching and emission (kParseLag): the decoupled parse wave of levels 1-4; lock-step (2) where the parse wave also
+     * inserts for the matchers (CHAIN) or walks repeat offsets (REP) */
+    constexpr uint32_t kLagT = (CHAIN || REP) ? 2u : kParseLag;
+    constexpr bool kDecoupled = kLagT > 2u;
+#ifndef QZ_TILE_SHIFT
+#define QZ_TILE_SHIFT 1 /* A/B builds: 0 = lengths, start flags and parse words of a tile all inside its own second interval, as in rounds 1-5 */
+#endif
+    /* Round 6: with the parse wave decoupled, a tile's 32-byte extensions ("tails"), lazy start flags and parse words move to the FIRST interval of
+     * the NEXT iteration: what a matcher wave does between two barriers is a chain of dependent LDS round trips (own bytes -> hash -> table read;
+     * near-table read -> candidate heads -> tails -> flag permute -> parse words: ~4 + ~6.5 per iteration before), and the wave's time between
+     * barriers IS that chain (r06_level1_wave_timing_before.txt: interval 2 takes 2 300 cycles on an otherwise idle SIMD for ~230 vector
+     * instructions).  Shifted, the tails' source bytes are requested together with the next tile's own bytes (one round trip instead of three), the
+     * position's own side of the tails comes from that same request one iteration earlier (13 dwords instead of 5: no request at all), and the flag
+     * permute overlaps the table read.  Same values, same order of table operations: bit-exact. */
+    constexpr bool kShift = kDecoupled && QZ_TILE_SHIFT != 0;
+    /* (offset, length) of the own position in earlier tiles, kept for the emission: [i] = of tile it - 1 - i once the iteration has shifted them — at the
+     * end of interval 2, or (kShift) in interval 1 after the emission, which then finds its tile one place earlier */
+    constexpr uint32_t kEmitIdx = kShift ? kLagT - 2u : kLagT - 1u;
+    /* what the parse wave and the late emission read from the ring has to be there still: sources up to kNear back of a tile kLagT tiles behind the matchers */
+    static_assert(kNear + kLagT * kTile + 4u <= kRing - kLook, "the ring no longer holds a near source when its tile is parsed / emitted");
     /* below the chain levels the tables are powers of two (csrc/qzstd_profile.c; the launcher refuses anything else): slot = mix >> shift */
     const uint32_t tabShift = (uint32_t)__builtin_clz(pf.tableSize) + 1u, longShift = pf.longSize ? (uint32_t)__builtin_clz(pf.longSize) + 1u : 31u;
     /* segment mode (qzstd_hip_block_t.parseFrom): tiles before the segment are only inserted into the tables */
@@ -839,9 +883,9 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     uint32_t *tbl = reinterpret_cast<uint32_t *>(smemI + kRing + kMirror);
     uint32_t *tblL = tbl + pf.tableSize;               /* [longSize]    8-byte-key table (levels >= 3)    */
     uint32_t *nearTab = tblL + pf.longSize;
-    uint32_t *srec = nearTab + kTile;                  /* [2][kWin][8]  emission records                  */
-    uint32_t *pv = srec + 2u * kWin * kSrecWords;      /* [2][kPvStride] per-position parse words         */
-    uint32_t *turnCtr = pv + 2u * kPvStride;           /* whose turn it is to update the tables (TURNS)   */
+    uint32_t *srec = nearTab + kTile;                  /* [kLagT][kWin][8]  emission records              */
+    uint32_t *pv = srec + kLagT * kWin * kSrecWords;   /* [kLagT][kPvStride] per-position parse words     */
+    uint32_t *turnCtr = pv + kLagT * kPvStride;        /* control: [0] whose turn it is to update the tables (TURNS), [2] a verdict, [kCtlArrive] */
     uint32_t *P1odd = turnCtr + 16u;                   /* [kTile] (CHAIN) predecessors of the odd tiles' positions (the even tiles': nearTab's words) */
     const uint4 *g128 = reinterpret_cast<const uint4 *>(gsrc);
     Src src;
@@ -880,7 +924,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     for (uint32_t i = tid; i < pf.tableSize + pf.longSize; i += kThreads) tbl[i] = 0u; /* both tables */
     if (!(CHAIN && itBegin != 0u)) { /* (the chain levels' history pass borrows these words first) */
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
-        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
+        for (uint32_t i = tid; i < kLagT * kWin * kSrecWords + kLagT * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
     }
     const bool sharedHist = CHAIN && hsh.flags != nullptr && hsh.nItems > 1u && pf.tableSize <= kSvcTabStride;
     if (itBegin != 0u || sharedHist) __syncthreads(); /* the cleared tables, before the first insert */
@@ -1035,7 +1079,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         if (tid == 0u) __hip_atomic_store(&hsh.flags[k], hsh.epoch, QZ_RLX_AGENT);
         if (!wait_for(hsh.flags)) return QZSTD_HIP_NSEQ_ERROR;
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
-        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
+        for (uint32_t i = tid; i < kLagT * kWin * kSrecWords + kLagT * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
     } else if (CHAIN && itBegin != 0u) {
         /* Chain levels, segment item: the history [0, parseFrom) has to be INSERTED AND LINKED, exactly (every position's
          * predecessor in its slot), but not walked.  Going through the tile loop for that costs one exposed HBM round trip per tile
@@ -1170,7 +1214,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         }
         __syncthreads();
         for (uint32_t i = tid; i < kTile; i += kThreads) nearTab[i] = 0xFFFFFFFFu;
-        for (uint32_t i = tid; i < 2u * kWin * kSrecWords + 2u * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
+        for (uint32_t i = tid; i < kLagT * kWin * kSrecWords + kLagT * kPvStride + 16u; i += kThreads) srec[i] = 0u; /* srec, pv, control */
     }
     {
         const uint32_t hiMaskH = pf.hashBytes >= 8 ? 0xFFFFFFFFu : ((1u << (8u * (pf.hashBytes - 4u))) - 1u);
@@ -1218,7 +1262,10 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
-        if (!QZ_ABLATED(32u)) __builtin_amdgcn_s_setprio(3); /* the serial critical path: win issue arbitration on its SIMD */
+#ifndef QZ_PARSE_PRIO
+#define QZ_PARSE_PRIO 3 /* the priority of the DECOUPLED parse wave (A/B builds); the lock-step one is the serial critical path: 3 */
+#endif
+        if (!QZ_ABLATED(32u)) __builtin_amdgcn_s_setprio(kDecoupled ? QZ_PARSE_PRIO : 3); /* win issue arbitration on its SIMD */
 #ifndef QZ_PARSE_SPLIT
 #define QZ_PARSE_SPLIT 3 /* windows parsed in interval 1 (the short one), the rest in interval 2 (A/B builds) */
 #endif
@@ -1230,12 +1277,83 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #define QZ_PLAP(acc)
 #endif
         uint32_t nseqEnd, anchorEnd;
-        if (REP) {
+        if constexpr (kDecoupled) {
+            /* Levels 1-4 (round 6): THE DECOUPLED PARSE WAVE.  Rounds 1-5 ran the parse wave in lock-step with the matchers — windows 0-2 of tile
+             * it-1 in interval 1, windows 3-7 in interval 2 — so every interval took max(slowest matcher wave, the parse wave's serial chain) and the
+             * round-5 measurements named exactly that as what a tile waits for.  s_barrier knows no "arrive without waiting" on gfx950, so the parse
+             * wave has to execute every barrier of the matchers' loop — but WHEN is its own business as long as
+             *   (a) it parses tile k only after B2 of iteration k (the tile's parse words are complete),
+             *   (b) it lets B2 of iteration j go only once tile j + 1 - kLagT is parsed (iteration j + 1 emits that tile and, in its second
+             *       interval, overwrites the parse words of tile j + 1 - kLagT's ring slot).
+             * Between those bounds it works through the tiles window by window and, after every window, looks at a counter the matcher waves bump
+             * before each of their barriers: when all eight are waiting and (b) allows, it joins the barrier at once (a hint, not a
+             * synchronisation: a stale value only costs time).  With nothing to parse it simply waits at the next barrier.  The matchers thus
+             * wait for the parse only when it is kLagT - 1 tiles behind, not twice per tile. */
+            ParseState st = { blk.parseFrom, blk.parseFrom, 0u };
+            uint32_t bar = 0u; /* barriers of the matchers' loop executed so far: B1 of iteration j = 2 (j - itBegin), B2 = that + 1 */
+            const uint32_t nBar = 2u * (nTiles + kLagT - itBegin);
+            const uint32_t *arriveP = turnCtr + kCtlArrive;
+#ifdef QZ_DEBUG_DUMP
+            u64 pYield = 0, pHeld = 0;
+#endif
+            for (uint32_t k = itBegin; k < nTiles && !QZ_ABLATED(1u); k++) {
+                QZ_PLAP(pI1)
+                /* (a): the tile's parse words are complete after B2 of its own iteration — after B1 of the next one when the flags are written there (kShift).
+                 * Ahead of the matchers there is nothing to do but wait with them */
+                while (bar < (kShift ? 2u * (k + 1u - itBegin) + 1u : 2u * (k - itBegin) + 2u)) { QZ_BARRIER_LDS(); bar++; }
+                QZ_PLAP(pW1)
+                const uint32_t *pvT = pv + (k % kLagT) * kPvStride;
+                uint32_t word[kWin];
+#pragma unroll
+                for (uint32_t w = 0; w < kWin; w++) word[w] = pvT[64u * w + lane];
+#pragma unroll
+                for (uint32_t w = 0; w < kWin; w++) asm volatile("" : "+v"(word[w])); /* all eight requested here: ONE LDS wait per tile */
+                ParseRecs r = { 0u, 0u, 0u, 0u, 0u, 0u };
+                const uint32_t base = k << kTileLog;
+                auto yield = [&](uint32_t seenV) {
+                    const uint32_t seen = rdfirst(seenV);
+                    if (seen >= (uint32_t)kMatchWaves * (bar + 1u)) { /* every matcher wave is waiting at barrier `bar` */
+                        if (!(bar & 1u) || k + kLagT >= itBegin + (bar >> 1) + 2u) { QZ_BARRIER_LDS(); bar++;
+#ifdef QZ_DEBUG_DUMP
+                            pYield++;
+#endif
+                        }
+#ifdef QZ_DEBUG_DUMP
+                        else pHeld++;
+#endif
+                    }
+                };
+#ifndef QZ_HINT_EVERY
+#define QZ_HINT_EVERY 1 /* windows between two looks at the matchers' counter (A/B builds) */
+#endif
+#define QZ_PW(W) { if (((W) + 1u) % QZ_HINT_EVERY == 0u) { \
+                       const uint32_t seenV = __hip_atomic_load(arriveP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                       parse_window<W>(pf, src, word[W], base, n, lane, st, r); yield(seenV); \
+                   } else parse_window<W>(pf, src, word[W], base, n, lane, st, r); }
+                QZ_PW(0) QZ_PW(1) QZ_PW(2) QZ_PW(3) QZ_PW(4) QZ_PW(5) QZ_PW(6)
+                parse_window<7>(pf, src, word[7], base, n, lane, st, r); /* (the records first, then the barrier — next iteration's loop head, or below) */
+#undef QZ_PW
+                if (lane < kWin) {
+                    uint32_t *so = srec + ((k % kLagT) * kWin + lane) * kSrecWords;
+                    *reinterpret_cast<uint4 *>(so) = make_uint4(r.r0, r.r1, r.r2, r.r3);
+                    so[4] = r.r4;
+                    so[5] = r.r5;
+                }
+            }
+            QZ_PLAP(pI1)
+            while (bar < nBar) { QZ_BARRIER_LDS(); bar++; }
+            QZ_PLAP(pW1)
+#ifdef QZ_DEBUG_DUMP
+            pI2 = pYield; pW2 = pHeld;
+#endif
+            nseqEnd = st.nseq;
+            anchorEnd = st.anchor;
+        } else if (REP) {
             RepState st = { blk.parseFrom, blk.parseFrom, 0u, 0u, 0u, 0u, pf.segLog ? blk.parseFrom >> pf.segLog : 0u };
             for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u, base = k << kTileLog;
-                uint32_t *pvT = pv + (k & 1u) * kPvStride, *srecT = srec + (k & 1u) * kWin * kSrecWords;
+                uint32_t *pvT = pv + (k % kLagT) * kPvStride, *srecT = srec + (k % kLagT) * kWin * kSrecWords;
                 if (work) {
                     st.tileSeq = st.nseq;
                     if (lane == 0u) srecT[0] = st.nseq; /* the records carry indices relative to this */
@@ -1259,7 +1377,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u;
                 if (work && !(CHAIN && QZ_CHAIN_SHIFT))
-                    parse_tile<0, kSplit>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
+                    parse_tile<0, kSplit>(pf, src, pv + (k % kLagT) * kPvStride, srec + (k % kLagT) * kWin * kSrecWords,
                                           k << kTileLog, n, lane, st);
                 if (CHAIN && it == itBegin && it < nTiles) chain_insert_tile(pf, src, tbl, (it & 1u) ? P1odd : nearTab, it << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI1)
@@ -1267,9 +1385,9 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 QZ_PLAP(pW1)
                 if (work) {
                     if (CHAIN && QZ_CHAIN_SHIFT)
-                        parse_tile<0, kWin>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords, k << kTileLog, n, lane, st);
+                        parse_tile<0, kWin>(pf, src, pv + (k % kLagT) * kPvStride, srec + (k % kLagT) * kWin * kSrecWords, k << kTileLog, n, lane, st);
                     else
-                        parse_tile<kSplit, kWin>(pf, src, pv + (k & 1u) * kPvStride, srec + (k & 1u) * kWin * kSrecWords,
+                        parse_tile<kSplit, kWin>(pf, src, pv + (k % kLagT) * kPvStride, srec + (k % kLagT) * kWin * kSrecWords,
                                                  k << kTileLog, n, lane, st);
                 }
                 if (CHAIN && it + 1u < nTiles) chain_insert_tile(pf, src, tbl, ((it + 1u) & 1u) ? P1odd : nearTab, (it + 1u) << kTileLog, n, nh, lane, args.orderedLds != 0u);
@@ -1292,6 +1410,10 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     }
 
     /* ---------------- the 8 matcher waves ---------------- */
+#ifdef QZ_MATCH_PRIO_HI /* A/B: the issue arbiter prefers the OLDER waves of a SIMD — waves 4-7 of a workgroup reach every barrier last (r06_level1_wave_timing_before.txt);
+                         * a raised priority for them evens that out */
+    if (wave >= 4u) __builtin_amdgcn_s_setprio(QZ_MATCH_PRIO_HI);
+#endif
     /* Chain entries: of the positions before the item (its history) in chainB; of the item's own positions in ownB — the same array
      * on the launch paths, an array of its own where the items of a request share chainB (HistShare): there the entries of an
      * item's range are stored by the item AFTER it, written through, and nobody else may leave half-written lines of them in an
@@ -1309,7 +1431,9 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     const uint32_t nTilesMax = QZSTD_HIP_BLOCK_MAX >> kTileLog;
 
     /* (offset, jump length) of this thread's position in tiles it-1 and it-2 */
-    uint32_t offA = 0, lenA = 0, offB = 0, lenB = 0;
+    uint32_t offH[kLagT], lenH[kLagT]; /* [i] = of tile it - 1 - i */
+#pragma unroll
+    for (uint32_t i = 0; i < kLagT; i++) offH[i] = lenH[i] = 0u;
     uint32_t rp = ring_dw((itBegin << kTileLog) + tid) << 2 | (tid & 3u); /* ring offset of the own position, advanced by one tile per iteration */
 #ifdef QZ_DEBUG_DUMP
     u64 dI1 = 0, dW1 = 0, dI2 = 0, dW2 = 0, tP = __builtin_amdgcn_s_memtime();
@@ -1366,9 +1490,16 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             nx = capped ? kNxCapped : nx;
             /* REP: the hash gain (0 = no usable candidate; 4 len + 32 - bits(offset) < 1024) | offset << 10; bit 31 stays clear */
             const uint32_t gRep = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
-            pv[(tileIdx & 1u) * kPvStride + tid] = REP ? (gRep | (off << 10)) : pack_pos(nx, ns, capped ? off : cl);
+            pv[(tileIdx % kLagT) * kPvStride + tid] = REP ? (gRep | (off << 10)) : pack_pos(nx, ns, capped ? off : cl);
     };
-    for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
+    /* kShift: what interval 2 of an iteration leaves for interval 1 of the next — the candidates' offsets and head lengths (0 = none), which of
+     * them matched all 16 bytes of the head and go on ("need"), the cap, and the 36 bytes behind the position's head (dwords 4-12 of `own`) */
+    uint32_t cOff1 = 0, cOff2 = 0, cOff3 = 0, cL1 = 0, cL2 = 0, cL3 = 0, cCap = 0;
+    bool cNeed1 = false, cNeed2 = false, cNeed3 = false, cFlags = false;
+    uint32_t cP[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) cP[i] = 0u;
+    for (uint32_t it = itBegin; it < nTiles + kLagT; it++) {
         const uint32_t t0 = it << kTileLog;
         const uint32_t p = t0 + tid; /* own position in tile it */
         const uint32_t stamp = (nTilesMax - 1u - (it & (nTilesMax - 1u))) << stampShift;
@@ -1381,8 +1512,30 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         /* ================= interval 1 ================= */
         /* the position's own first 20 bytes (5 aligned dwords): issued first so that their LDS latency
          * hides behind the emission below; used by the hash now and by the candidate compare later */
-        uint32_t own[5];
-        load_dw_r<5>(src, p, rp, false, own);
+#ifndef QZ_SHIFT_CARRY_P
+#define QZ_SHIFT_CARRY_P 0 /* A/B: 1 = the position's own side of its tails is requested WITH its head (13 dwords instead of 5) and carried in registers to the next
+                            * iteration (no request there; 88 VGPRs: the second workgroup no longer fits next to the first on every SIMD); 0 = requested again
+                            * with the candidates' tails */
+#endif
+        constexpr bool kCarryP = kShift && QZ_SHIFT_CARRY_P != 0;
+        constexpr int kOwn = kCarryP ? 13 : 5;
+        uint32_t own[kOwn];
+        load_dw_r<kOwn>(src, p, rp, false, own);
+        /* kShift: the tails of tile it-1 — the 32 bytes behind the head of every candidate that matched its whole head — requested NOW, together with
+         * the own bytes of tile it: one round trip for both (the candidates' ring offsets follow from the carried offsets) */
+        uint32_t TQ1[9], TQ2[9], TQ3[9], TP[9];
+        if constexpr (kShift) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) asm volatile("" : "=v"(TQ1[i]), "=v"(TQ2[i]), "=v"(TQ3[i]), "=v"(TP[i])); /* only the requesting lanes ever read them: "written" without an instruction */
+            const uint32_t rpP16 = ring_back(rp, kTile - 16u); /* ring offset of (the position in tile it-1) + 16 */
+            if constexpr (kCarryP) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) TP[i] = cP[i];
+            } else if (cNeed1 || cNeed2 || (HAS_LONG && cNeed3)) load_dw_r<9>(src, p - kTile + 16u, rpP16, false, TP);
+            if (cNeed1) load_dw_r<9>(src, p - kTile + 16u - cOff1, ring_back(rpP16, cOff1), cOff1 > src.nearLimit, TQ1);
+            if (HAS_LONG && cNeed3) load_dw_r<9>(src, p - kTile + 16u - cOff3, ring_back(rpP16, cOff3), cOff3 > src.nearLimit, TQ3);
+            if (cNeed2) load_dw_r<9>(src, p - kTile + 16u - cOff2, ring_back(rpP16, cOff2), false, TQ2);
+        }
         /* refill: the 512 bytes that enter the look-ahead window this iteration (HBM -> registers now,
          * registers -> ring after the barrier; the ring slots they replace left everyone's reach
          * three tiles ago) */
@@ -1392,10 +1545,10 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         const uint32_t fpos = t0 + kLook + (tid - 64u) * 16u; /* iteration it stages [t0 + kLook, t0 + kLook + kTile) */
         const bool refill = wave == 1u && it >= 1u && lane < kTile / 16u && fpos < nPad;
         if (refill) fresh = g128[fpos >> 4];
-        if (it >= 2u + firstTile && !QZ_ABLATED(8u)) /* emit(it-2): needs the parse of tile it-2 (done in interval 2 of it-1) */
-            emit_window<REP>(pf, src, srec + ((it & 1u) * kWin + wave) * kSrecWords, pv + (it & 1u) * kPvStride + 64u * wave,
-                             offB, lenB, t0 - 2u * kTile + 64u * wave, ring_back(rp, 2u * kTile), lane, out, blk.seqCap,
-                             REP ? srec[(it & 1u) * kWin * kSrecWords] : 0u, blk.mark);
+        if (it >= kLagT + firstTile && !QZ_ABLATED(8u)) /* emit(it - kLagT): needs the parse of that tile (lock-step: done in interval 2 of it-1; decoupled: before the parse wave let B2 of it-1 go) */
+            emit_window<REP>(pf, src, srec + ((it % kLagT) * kWin + wave) * kSrecWords, pv + (it % kLagT) * kPvStride + 64u * wave,
+                             offH[kEmitIdx], lenH[kEmitIdx], t0 - kLagT * kTile + 64u * wave, ring_back(rp, kLagT * kTile), lane, out, blk.seqCap,
+                             REP ? srec[(it % kLagT) * kWin * kSrecWords] : 0u, blk.mark);
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
         const bool validL = HAS_LONG && valid && p + 8u <= segE;
         uint32_t oa[4]; /* the position's first 16 bytes, byte-aligned: hashed now, compared against every candidate later */
@@ -1419,6 +1572,30 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 if (!TURNS) oldL = tblL[slotL];
             }
         }
+        if constexpr (kShift) {
+            /* tile it-1: lengths beyond the head, the choice between the candidates, start flags, parse words — while the table read of tile it is in flight */
+            uint32_t clP = 0u, offP = 0u;
+            if (cFlags) { /* uniform */
+                uint32_t l1 = cL1, l2 = cL2, l3 = cL3;
+                if (cNeed1 || cNeed2 || cNeed3) {
+                    uint32_t pa[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) pa[i] = __builtin_amdgcn_alignbyte(TP[i + 1], TP[i], p & 3u); /* (tile it-1's position has the same alignment) */
+                    if (cNeed1) l1 = 16u + tail_cmp(pa, TQ1, (p - cOff1) & 3u);
+                    if (HAS_LONG && cNeed3) l3 = 16u + tail_cmp(pa, TQ3, (p - cOff3) & 3u);
+                    if (cNeed2) l2 = 16u + tail_cmp(pa, TQ2, (p - cOff2) & 3u);
+                }
+                l1 = umin(l1, cCap); l2 = umin(l2, cCap); l3 = umin(l3, cCap);
+                if (l1 >= 4u) { clP = l1; offP = cOff1; }
+                if (l3 >= 4u && l3 > clP) { clP = l3; offP = cOff3; }   /* 8-byte table: only if strictly longer */
+                if (l2 >= 4u && l2 >= clP) { clP = l2; offP = cOff2; }  /* same tile: ties go to the nearer source */
+                if (!QZ_ABLATED(4u)) write_flags(it - 1u, clP, offP);
+            }
+#pragma unroll
+            for (uint32_t i = kLagT - 1u; i > 0u; i--) { offH[i] = offH[i - 1u]; lenH[i] = lenH[i - 1u]; }
+            offH[0] = offP;
+            lenH[0] = clP;
+        }
         uint32_t pre[kEL];
 #pragma unroll
         for (uint32_t j = 0; j < kEL; j++) pre[j] = 0u;
@@ -1428,7 +1605,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             old = valid ? ((it & 1u) ? P1odd : nearTab)[tid] : 0u;
             if (old != 0u && (old >> kTagBits) - 1u < t0) entryOf((old >> kTagBits) - 1u, pre);
         }
-        if (CHAIN && QZ_CHAIN_SHIFT && it > itBegin && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(4u)) write_flags(it - 1u, lenA, offA);
+        if (CHAIN && QZ_CHAIN_SHIFT && it > itBegin && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(4u)) write_flags(it - 1u, lenH[0], offH[0]);
+        if (kDecoupled && lane == 0u) (void)__hip_atomic_fetch_add(turnCtr + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* "at B1": the parse wave's hint */
         QZ_LAP(dI1)
 #ifdef QZ_B1_LDS_ONLY /* A/B: the barrier between the intervals orders LDS traffic only — nothing in global memory crosses it (the chain entries of the
                        * previous tile were drained at B2, the refill's load and the predecessor's entry are waited for where they are used) */
@@ -1465,8 +1643,16 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             ring128[o >> 4] = fresh;
             if (o < kMirror) ring128[(kRing + o) >> 4] = fresh;
         }
-        offB = offA; lenB = lenA;
         uint32_t cl = 0, off = 0; /* capped candidate length, offset */
+        if constexpr (kShift) { /* what this interval leaves for interval 1 of the next iteration (set below where the position has candidates) */
+            cOff1 = cOff2 = cOff3 = cL1 = cL2 = cL3 = cCap = 0u;
+            cNeed1 = cNeed2 = cNeed3 = false;
+            cFlags = it < nTiles && !history;
+            if constexpr (kCarryP) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) cP[i] = own[kOwn - 9 + i];
+            }
+        }
         if (CHAIN) {
             /* Levels >= 5: exact hash chains (oracle: qzo_candidates_chain): every position gets its exact predecessor in
              * its slot, and walks chainDepth links from there.
@@ -1675,6 +1861,13 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
              * cap of 48) shares the position's own side — fetched and byte-aligned once — between the candidates */
             bool need1 = l1 == 16u && cap > 16u, need2 = l2 == 16u && cap > 16u, need3 = HAS_LONG && l3 == 16u && cap > 16u;
             if (QZ_ABLATED(128u)) need1 = need2 = need3 = false; /* profiling: what the extension past 16 bytes costs */
+            if (kShift) { /* the rest of this tile's lengths in interval 1 of the next iteration */
+                cOff1 = q1 != kNone ? p - q1 : 0u; cOff2 = q2 != kNone ? p - q2 : 0u; cOff3 = q3 != kNone ? p - q3 : 0u;
+                cL1 = l1; cL2 = l2; cL3 = l3;
+                cNeed1 = need1; cNeed2 = need2; cNeed3 = need3;
+                cCap = cap;
+                need1 = need2 = need3 = false;
+            }
             if (need1 || need2 || need3) {
                 const uint32_t rp16 = ring_fwd(rp, 16u);
                 uint32_t P[9], pa[8];
@@ -1695,17 +1888,24 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 else if (which == 3) { l3 = L + l; need3 = more; }
                 else { l2 = L + l; need2 = more; }
             }
+            if (!kShift) {
             l1 = umin(l1, cap); l2 = umin(l2, cap); l3 = umin(l3, cap);
             if (l1 >= 4u) { cl = l1; off = p - q1; }
             if (l3 >= 4u && l3 > cl) { cl = l3; off = p - q3; }   /* 8-byte table: only if strictly longer */
             if (l2 >= 4u && l2 >= cl) { cl = l2; off = p - q2; }  /* same tile: ties go to the nearer source */
             }
+            }
         }
         }
+        if (!kShift) {
         if (!(CHAIN && QZ_CHAIN_SHIFT) && it < nTiles && !history && !QZ_ABLATED(4u)) write_flags(it, cl, off);
-        offA = off;
-        lenA = cl;
+#pragma unroll
+        for (uint32_t i = kLagT - 1u; i > 0u; i--) { offH[i] = offH[i - 1u]; lenH[i] = lenH[i - 1u]; }
+        offH[0] = off;
+        lenH[0] = cl;
+        }
         rp = ring_fwd(rp, kTile);
+        if (kDecoupled && lane == 0u) (void)__hip_atomic_fetch_add(turnCtr + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* "at B2" */
         QZ_LAP(dI2)
         __syncthreads(); /* B2 */
         QZ_LAP(dW2)

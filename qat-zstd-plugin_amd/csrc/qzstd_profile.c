@@ -103,20 +103,26 @@ size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockL
 #ifndef QZ_RING
 #define QZ_RING 32768u
 #endif
+#ifndef QZ_PARSE_LAG
+#define QZ_PARSE_LAG 2u /* csrc/qzstd_kernels.hip must agree (make variant passes XFLAGS to both); 3 / 4: the decoupled parse wave experiment of round 6 */
+#endif
 #define QZ_RING_BYTES (QZ_RING + 128u) /* ring of recent block bytes + wrap mirror (csrc/qzstd_kernels.hip: kRing) */
 
 /* LDS per workgroup: independent of the block size — 72 560 B at levels 1-2 (two workgroups per CU) */
 size_t qzstd_hip_lds_bytes(int level, uint32_t maxBlockLen)
 {
     qzstd_hip_profile_t p;
-    size_t need;
+    size_t need, lag;
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX || qzstd_hip_profile_for_level(level, maxBlockLen, &p)) return 0;
+    /* tiles between matching and emission (csrc/qzstd_kernels.hip: kLagT): the decoupled parse wave of levels 1-4 keeps QZ_PARSE_LAG tiles of
+     * parse words and emission records; the chain levels and the repeat-aware parse run it in lock-step with the matchers: 2 */
+    lag = (p.chainDepth || p.repWin) ? 2u : QZ_PARSE_LAG;
     need = (size_t)QZ_RING_BYTES
            + 4u * p.tableSize        /* hash table                                    */
            + 4u * p.longSize         /* 8-byte-key table (levels >= 3)                */
            + (4u << p.tileLog)     /* tile-local near table / the current tile's chain links (levels >= 5) */
-           + 2u * ((4u << p.tileLog) + 32u) /* per-position parse words (+ override spill), 2 tiles in flight */
-           + 2u * ((1u << p.tileLog) >> 6) * 32u /* per-window emission records, x2 */
+           + lag * ((4u << p.tileLog) + 32u) /* per-position parse words (+ override spill), `lag` tiles in flight */
+           + lag * ((1u << p.tileLog) >> 6) * 32u /* per-window emission records, as many tiles */
            + (p.chainDepth ? (4u << p.tileLog) : 0u) /* chain levels: slot | tag of the tile's positions, for the insert wave */
            + QZ_LDS_CTRL + QZ_LDS_SVC;
     return need <= QZ_LDS_MAX ? need : 0;
