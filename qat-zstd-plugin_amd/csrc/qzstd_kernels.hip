@@ -60,6 +60,13 @@
 #ifndef QZ_CHAIN_SHIFT
 #define QZ_CHAIN_SHIFT 1 /* chain levels: a tile's start flags are written in the next iteration's first interval (A/B: 0) */
 #endif
+#ifndef QZ_CHAIN_DEFER_EXT
+#define QZ_CHAIN_DEFER_EXT 0 /* chain walk (round 6 A/B, 1): the 32-byte extensions of a step's links in a loop of their own, every lane taking ITS next one — bit-exact, +2 ... +7 % time (profiles/r06_ab_chain_walk.txt); 0 = inside
+                              * every link's own block, as in rounds 3-5) */
+#endif
+#ifndef QZ_CHAIN_HOIST_P
+#define QZ_CHAIN_HOIST_P 0 /* A/B: 1 = the position's own 32 bytes behind its head requested and byte-aligned ONCE per tile, kept in registers over the whole walk */
+#endif
 
 namespace {
 
@@ -1695,6 +1702,15 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             const uint32_t cap = valid ? umin(umin(pf.capLen, 48u), segE - p) : 0u; /* a match never leaves its segment; candidates are measured up to 48 bytes */
             uint32_t walked = 0;
             if (history) E[0] = 0u; /* a tile before the segment (segment mode): inserted and linked, not matched */
+#if QZ_CHAIN_DEFER_EXT && QZ_CHAIN_HOIST_P
+            uint32_t pa[8];
+            {
+                uint32_t P[9];
+                load_dw_r<9>(src, p + 16u, ring_fwd(rp, 16u), false, P);
+#pragma unroll
+                for (int i = 0; i < 8; i++) pa[i] = __builtin_amdgcn_alignbyte(P[i + 1], P[i], p & 3u);
+            }
+#endif
             int bg = 0;
             QZ_CLAP(0)
             while (__ballot(E[0] != 0u)) {
@@ -1783,6 +1799,51 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                             if (m[g]) load_dw_r<5>(src, q[g], rq[g], far[g], Q[g]);
                         }
 #endif
+#if QZ_CHAIN_DEFER_EXT
+                        /* Round 6.  A link's LENGTH depends on nothing but (p, q): only the choice between the links is sequential.  So the step first
+                         * measures the 16-byte heads of all its surviving links, then extends the heads that matched whole — in a loop in which every
+                         * lane takes ITS next such link: as many passes as the busiest lane has (one or two) instead of one 60-instruction block per
+                         * link position that runs whenever ANY lane of the wave needs it (four per step, practically always) —, then chooses in link
+                         * order exactly as before.  A wave's time is its instruction count (profiles/r06_ab_decoupled_parse_wave.txt). */
+                        uint32_t lg[kG], needX = 0u;
+#pragma unroll
+                        for (int g = 0; g < kG; g++) {
+                            lg[g] = 0u;
+                            if (m[g] && cl < cap) {
+                                lg[g] = head_cmp(oa, Q[g], q[g] & 3u);
+                                if (lg[g] == 16u && cap > 16u) needX |= 1u << g;
+                            }
+                        }
+                        if (__ballot(needX != 0u)) {
+#if !QZ_CHAIN_HOIST_P
+                            /* the position's own 32 bytes behind the head: requested and byte-aligned once per step (they were per link) */
+                            uint32_t P[9], pa[8];
+                            load_dw_r<9>(src, p + 16u, ring_fwd(rp, 16u), false, P);
+#pragma unroll
+                            for (int i = 0; i < 8; i++) pa[i] = __builtin_amdgcn_alignbyte(P[i + 1], P[i], p & 3u);
+#endif
+                            do {
+                                if (needX != 0u) {
+                                    const uint32_t gx = first_diff_bit(needX); /* this lane's next link to extend */
+                                    needX &= needX - 1u;
+                                    uint32_t qx = q[0];
+#pragma unroll
+                                    for (int g = 1; g < kG; g++) qx = gx == (uint32_t)g ? q[g] : qx;
+                                    const uint32_t t = tail_len(src, pa, qx + 16u, ring_back(ring_fwd(rp, 16u), p - qx), p - qx > src.nearLimit);
+#pragma unroll
+                                    for (int g = 0; g < kG; g++) lg[g] = gx == (uint32_t)g ? 16u + t : lg[g];
+                                }
+                            } while (__ballot(needX != 0u));
+                        }
+#pragma unroll
+                        for (int g = 0; g < kG; g++) {
+                            if (m[g] && cl < cap) { /* (a best that fills the cap cannot be beaten: the sequential walk would not have looked) */
+                                const uint32_t l = umin(lg[g], cap);
+                                const int gn = (int)(4u * l) - (int)(31u - (uint32_t)__builtin_clz(p - q[g] + 1u));
+                                if (l >= 4u && (cl == 0u || gn > bg)) { cl = l; off = p - q[g]; bg = gn; }
+                            }
+                        }
+#else
 #pragma unroll
                         for (int g = 0; g < kG; g++) {
                             if (m[g] && cl < cap) { /* (a best that fills the cap cannot be beaten: the sequential walk would not have looked) */
@@ -1793,6 +1854,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                                 if (l >= 4u && (cl == 0u || gn > bg)) { cl = l; off = p - q[g]; bg = gn; }
                             }
                         }
+#endif
                     }
                     walked += cnt;
                 }
