@@ -64,6 +64,22 @@
 #define QZ_CHAIN_DEFER_EXT 0 /* chain walk (round 6 A/B, 1): the 32-byte extensions of a step's links in a loop of their own, every lane taking ITS next one — bit-exact, +2 ... +7 % time (profiles/r06_ab_chain_walk.txt); 0 = inside
                               * every link's own block, as in rounds 3-5) */
 #endif
+/* Round 6: "progress-inverse priority".  The issue arbiter serves the OLDER waves of a SIMD first, so waves 4-7 of a workgroup reach every barrier last
+ * and run the end of every interval alone, with nobody to hide their latencies behind (profiles/r06_level1_wave_timing_before.txt).  A matcher wave of the
+ * tile levels therefore starts an interval at priority 2 and lowers it as it gets on (1 after the first part, 0 after the second): whoever is behind
+ * wins the arbitration; the parse wave stays above them at 3.  Measured (profiles/r06_ab_small_steps.txt): level 1 11.91 -> 11.78 ms per GiB (-1.1 %),
+ * level 3 10.47 -> 10.31 (-1.6 %); 2 = the same with priorities 1, 0, 0: half of that; a fixed raised priority for waves 4-7: nothing.  0 = off (A/B). */
+#ifndef QZ_PROGRESS_PRIO
+#define QZ_PROGRESS_PRIO 1
+#endif
+#define QZ_PRIO(n) do { if (QZ_PROGRESS_PRIO && !CHAIN) __builtin_amdgcn_s_setprio((n) >= QZ_PROGRESS_PRIO ? (n) + 1 - QZ_PROGRESS_PRIO : 0); } while (0) /* 1: 2,1,0   2: 1,0,0 */
+/* A/B (round 6): the emission's common path trimmed — the "a capped match was extended" flag rides in bit 31 of the record's sequence base (no second LDS
+ * request + scalar test per window), the own chosen bit is tested without a 64-bit shift by the lane (a quarter-rate instruction).  Fewer instructions,
+ * bit-exact — and +2.8 % time at level 1 (12.25 vs 11.91 ms per GiB), +1.4 % at level 3: NOT the product (profiles/r06_ab_small_steps.txt). */
+#ifndef QZ_EMIT_TRIM
+#define QZ_EMIT_TRIM 0
+#endif
+constexpr uint32_t kExtFlag = 0x80000000u; /* QZ_EMIT_TRIM: set in ParseRecs.r3 (the window's first sequence index) when r4 / r5 hold extended lengths */
 #ifndef QZ_CHAIN_HOIST_P
 #define QZ_CHAIN_HOIST_P 0 /* A/B: 1 = the position's own 32 bytes behind its head requested and byte-aligned ONCE per tile, kept in registers over the whole walk */
 #endif
@@ -461,7 +477,7 @@ __device__ __forceinline__ void parse_window(const qzstd_hip_profile_t &pf, cons
     r.r0 = wrlane<W>(r.r0, (uint32_t)chosen);
     r.r1 = wrlane<W>(r.r1, (uint32_t)(chosen >> 32));
     r.r2 = wrlane<W>(r.r2, anchorIn);
-    r.r3 = wrlane<W>(r.r3, seqBase);
+    r.r3 = wrlane<W>(r.r3, (QZ_EMIT_TRIM && ext0) ? (seqBase | kExtFlag) : seqBase);
     if (ext0) { /* rare */
         r.r4 = wrlane<W>(r.r4, ext0);
         r.r5 = wrlane<W>(r.r5, ext1);
@@ -663,14 +679,18 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
         const uint4 rec = *reinterpret_cast<const uint4 *>(srec);
         const u64 chosen = (u64)rec.x | ((u64)rec.y << 32);
         if (!chosen) return;
-        const uint32_t anchorIn = rec.z, seqBase = rec.w;
-        const uint32_t ext0 = rdfirst(srec[4]); /* uniform: a scalar branch skips the (rare) extended matches */
-        if (ext0) {
-            const uint32_t ext1 = srec[5];
-            if ((ext0 >> 24) == lane) len = ext0 & 0xFFFFFFu; /* extended by the parse wave */
-            if (ext1 && (ext1 >> 24) == lane) len = ext1 & 0xFFFFFFu;
+        const uint32_t anchorIn = rec.z, seqBase = QZ_EMIT_TRIM ? rec.w & ~kExtFlag : rec.w;
+        const bool hasExt = QZ_EMIT_TRIM ? (rdfirst(rec.w) & kExtFlag) != 0u : true; /* uniform: a scalar branch skips the (rare) extended matches */
+        if (hasExt) {
+            const uint32_t ext0 = rdfirst(srec[4]);
+            if (ext0) {
+                const uint32_t ext1 = srec[5];
+                if ((ext0 >> 24) == lane) len = ext0 & 0xFFFFFFu; /* extended by the parse wave */
+                if (ext1 && (ext1 >> 24) == lane) len = ext1 & 0xFFFFFFu;
+            }
         }
-        ch = (chosen >> lane) & 1ull;
+        if (QZ_EMIT_TRIM) ch = (((lane & 32u) ? rec.y : rec.x) >> (lane & 31u)) & 1u; /* (a 64-bit shift by the lane is a quarter-rate instruction) */
+        else ch = (chosen >> lane) & 1ull;
         const u64 lower = chosen & below(lane);
         const uint32_t myEnd = w0 + lane + len;
         const int jprev = lower ? 63 - __builtin_clzll(lower) : 0;
@@ -1517,6 +1537,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         const bool history = it < firstTile; /* uniform: a tile before the segment (segment mode): inserted, not matched */
 
         /* ================= interval 1 ================= */
+        QZ_PRIO(2);
         /* the position's own first 20 bytes (5 aligned dwords): issued first so that their LDS latency
          * hides behind the emission below; used by the hash now and by the candidate compare later */
 #ifndef QZ_SHIFT_CARRY_P
@@ -1556,6 +1577,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             emit_window<REP>(pf, src, srec + ((it % kLagT) * kWin + wave) * kSrecWords, pv + (it % kLagT) * kPvStride + 64u * wave,
                              offH[kEmitIdx], lenH[kEmitIdx], t0 - kLagT * kTile + 64u * wave, ring_back(rp, kLagT * kTile), lane, out, blk.seqCap,
                              REP ? srec[(it % kLagT) * kWin * kSrecWords] : 0u, blk.mark);
+        QZ_PRIO(1); /* (interval 1: the emission is behind) */
         uint32_t slot = 0, nslot = 0, slotL = 0, oldL = 0, tagL = 0;
         const bool validL = HAS_LONG && valid && p + 8u <= segE;
         uint32_t oa[4]; /* the position's first 16 bytes, byte-aligned: hashed now, compared against every candidate later */
@@ -1624,6 +1646,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         QZ_LAP(dW1)
 
         /* ================= interval 2 ================= */
+        QZ_PRIO(2);
 #if defined(QZ_PAD_VALU) || defined(QZ_PAD_SALU) || defined(QZ_PAD_LDS)
         /* calibration builds only (make variant XFLAGS=-DQZ_PAD_VALU=64 ...): what ONE more instruction of a kind costs per matcher wave
          * and tile — the slope says which issue resource binds the kernel */
@@ -1930,6 +1953,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 cCap = cap;
                 need1 = need2 = need3 = false;
             }
+            QZ_PRIO(1); /* (the heads are behind) */
             if (need1 || need2 || need3) {
                 const uint32_t rp16 = ring_fwd(rp, 16u);
                 uint32_t P[9], pa[8];
@@ -1950,6 +1974,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 else if (which == 3) { l3 = L + l; need3 = more; }
                 else { l2 = L + l; need2 = more; }
             }
+            QZ_PRIO(0); /* (the tails are behind) */
             if (!kShift) {
             l1 = umin(l1, cap); l2 = umin(l2, cap); l3 = umin(l3, cap);
             if (l1 >= 4u) { cl = l1; off = p - q1; }

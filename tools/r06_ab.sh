@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R; TAG=$1; SHAPES=$2; shift 2
 O=$R/gpurun_out/$TAG; mkdir -p $O
-(timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py ${EXTRA_TESTS:-} -x -q -m gpu 2>&1 | tail -60) > $O/parity.txt
+(QZ_PLUGIN_SO=${PARITY_SO:+$R/qat-zstd-plugin_amd/lib/libqatseqprod_$PARITY_SO.so} timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py ${EXTRA_TESTS:-} -x -q -m gpu 2>&1 | tail -60) > $O/parity.txt
 for V in "$@"; do
   SO=$R/qat-zstd-plugin_amd/lib/libqatseqprod_$V.so; [ "$V" = default ] && SO=$R/qat-zstd-plugin_amd/lib/libqatseqprod.so
   for rep in 1 2; do
