@@ -418,6 +418,7 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
     "host double-buffered pinned H2D/D2H overlapping compute", at the level of the C ABI).  GB/s of input per GPU."""
     L = plug.lib
     pitch = 16384  # result entries per block (the product's QZ_HINT_PITCH)
+    packed = os.environ.get("QZ_BENCH_PCIE_PACKED", "1") != "0"  # PACKED result entries, as the product's announcements ask for since round 6
     nb = min(len(shard) // block, 4096)
     nchunks = nb // chunk_blocks
     if nchunks < depth:
@@ -443,7 +444,8 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
             assert all(ln.values()), plug.err()
             desc = (B.HipBlock * chunk_blocks).from_address(ln["h_desc"])
             for i in range(chunk_blocks):
-                desc[i].srcOff, desc[i].seqOff, desc[i].srcLen, desc[i].seqCap = i * block, i * pitch, block, pitch
+                desc[i].srcOff, desc[i].seqOff, desc[i].srcLen, desc[i].seqCap = i * block, (i * (pitch // 2) if packed else i * pitch), block, pitch
+                desc[i].mark = (B.MARK_COMPACT | 1) if packed else 0  # (as the product's announcements: 8-byte entries over PCIe)
             ln["dv"] = [L.qzstd_hip_host_device_ptr(C.c_void_p(ln[k])) for k in ("h_seqs", "h_cnt", "h_desc")]
             work = L.qzstd_hip_workspace_bytes(level, chunk_blocks, block)
             ln["work"] = work
@@ -494,7 +496,7 @@ def pcie_pipeline_leg(plug, shard: bytes, block: int, level: int, device: int, c
         return {"GBps_input_per_gpu": round(nbytes * passes / tot / 1e9, 2), "GBps_best_pass": round(nbytes / best / 1e9, 2),
                 "bytes_per_pass": nbytes, "chunk_blocks": chunk_blocks, "chunks_in_flight": depth, "passes": passes,
                 "t_begin": t_begin, "t_end": time.perf_counter(), "device": device,
-                "result_bytes_per_pass": 16 * seqs, "dense_blocks_over_pitch": errs,
+                "result_bytes_per_pass": (8 if packed else 16) * seqs, "result_entry_bytes": 8 if packed else 16, "dense_blocks_over_pitch": errs,
                 "what": "pinned host -> device memory (%s) -> kernel -> counts + sequences written by the kernel into pinned host memory; "
                         "%d chunks of %d blocks in flight on separate streams" % ("copy kernel" if copy_kernel else "hipMemcpyAsync", depth, chunk_blocks)}
     except AssertionError as e:

@@ -658,6 +658,16 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
     }
 }
 
+/* One result entry: a ZSTD_Sequence with the item's mark in its fourth word — or, for result areas in pinned host memory (qzstd_hip.h:
+ * QZSTD_HIP_MARK_COMPACT), the same three numbers and a 12-bit tag packed into ONE 8-byte store: half the bytes the kernel pushes over PCIe */
+__device__ __forceinline__ void store_entry(uint4 *out, uint32_t idx, uint32_t off, uint32_t lit, uint32_t ml, uint32_t mark)
+{
+    if (mark & QZSTD_HIP_MARK_COMPACT) /* uniform: one flag per work item */
+        reinterpret_cast<u64 *>(out)[idx] = QZSTD_HIP_PACK(off, lit, ml, mark & 0xFFFu);
+    else
+        out[idx] = make_uint4(off, lit, ml, mark);
+}
+
 /* emission of one window's chosen matches by the wave that owns the window */
 template <bool REP>
 __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const Src &src, const uint32_t *srec,
@@ -715,7 +725,7 @@ __device__ __forceinline__ void emit_window(const qzstd_hip_profile_t &pf, const
             const uint32_t x = pb ^ qb;
             b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
         }
-        if (idx < seqCap) out[idx] = make_uint4(off, lit - b, len + b, mark); /* ONE 16-byte store: entry and mark arrive together */
+        if (idx < seqCap) store_entry(out, idx, off, lit - b, len + b, mark); /* ONE store: entry and mark arrive together */
     }
 }
 
@@ -1426,12 +1436,12 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             anchorEnd = st.anchor;
         }
 #ifdef QZ_DEBUG_DUMP
-        if (lane == 0) out[blk.seqCap - 2u] = make_uint4((uint32_t)pI1, (uint32_t)pW1, (uint32_t)pI2, (uint32_t)pW2);
-        if (lane == 0) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID: where the wave runs */
+        if (lane == 0 && !(blk.mark & QZSTD_HIP_MARK_COMPACT)) out[blk.seqCap - 2u] = make_uint4((uint32_t)pI1, (uint32_t)pW1, (uint32_t)pI2, (uint32_t)pW2);
+        if (lane == 0 && !(blk.mark & QZSTD_HIP_MARK_COMPACT)) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID: where the wave runs */
 #endif
         /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
         uint32_t count = nseqEnd + 1u;
-        if (lane == 0 && nseqEnd < blk.seqCap) out[nseqEnd] = make_uint4(0u, n - anchorEnd, 0u, blk.mark);
+        if (lane == 0 && nseqEnd < blk.seqCap) store_entry(out, nseqEnd, 0u, n - anchorEnd, 0u, blk.mark);
         if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
         return count;
     }
@@ -1736,7 +1746,17 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #endif
             int bg = 0;
             QZ_CLAP(0)
+#ifndef QZ_CHAIN_PROGRESS_PRIO
+#define QZ_CHAIN_PROGRESS_PRIO 0 /* A/B: the walking waves' priority falls with the steps they have done (2 for the first two, 1 for the next two, then 0) */
+#endif
+            uint32_t stepsDone = 0u;
+            if (QZ_CHAIN_PROGRESS_PRIO) __builtin_amdgcn_s_setprio(2);
             while (__ballot(E[0] != 0u)) {
+                if (QZ_CHAIN_PROGRESS_PRIO) {
+                    if (stepsDone == 2u * QZ_CHAIN_PROGRESS_PRIO) __builtin_amdgcn_s_setprio(1);
+                    else if (stepsDone == 4u * QZ_CHAIN_PROGRESS_PRIO) __builtin_amdgcn_s_setprio(0);
+                    stepsDone++;
+                }
                 uint32_t N[kEL];
 #pragma unroll
                 for (uint32_t j = 0; j < kEL; j++) N[j] = 0u;
@@ -1893,6 +1913,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 for (uint32_t j = 0; j < kEL; j++) E[j] = full ? 0u : N[j];
                 QZ_CLAP(4)
             }
+            if (QZ_CHAIN_PROGRESS_PRIO) __builtin_amdgcn_s_setprio(0);
         } else {
         if (TURNS) {
             /* level 2 and levels >= 5 update the tables per 64 positions, in position order: the matcher waves take turns
@@ -1994,10 +2015,16 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         rp = ring_fwd(rp, kTile);
         if (kDecoupled && lane == 0u) (void)__hip_atomic_fetch_add(turnCtr + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* "at B2" */
         QZ_LAP(dI2)
+#ifdef QZ_B2_LDS_ONLY /* A/B: below the chain levels no wave reads what another wave wrote to global memory — the barrier need not wait for the result stores
+                       * (to PINNED HOST memory in the product paths) either; the chain levels keep the full barrier: chain entries */
+        if (CHAIN) __syncthreads(); else QZ_BARRIER_LDS(); /* B2 */
+#else
         __syncthreads(); /* B2 */
+#endif
         QZ_LAP(dW2)
     }
 #ifdef QZ_DEBUG_DUMP
+    if (blk.mark & QZSTD_HIP_MARK_COMPACT) return 0u; /* (the cycle counts are dumped behind 16-byte entries only) */
     if (lane == 0) out[blk.seqCap - 3u - wave] = make_uint4((uint32_t)dI1, (uint32_t)dW1, (uint32_t)dI2, (uint32_t)dW2);
     if (lane == 0) out[blk.seqCap - 24u - 2u * wave] = make_uint4((uint32_t)(dC[0] >> 4), (uint32_t)(dC[1] >> 4), (uint32_t)(dC[2] >> 4), (uint32_t)(dC[3] >> 4));
     if (lane == 0) out[blk.seqCap - 25u - 2u * wave] = make_uint4((uint32_t)(dC[4] >> 4), (uint32_t)dC[5], 0u, 0u);

@@ -195,6 +195,7 @@ typedef struct {
                                     * oversubscribe the cores, and a caller that waits for the GPU should give its core away at once */
     int hintFlags;                 /* QZSTD_HIP_HINT_FLAGS (default 1): an announcement's launch is complete when its blocks' count words are in (0: when
                                     * the runtime says its stream is idle) */
+    int hintCompact;               /* QZSTD_HIP_HINT_COMPACT (default 1): announcements' result entries are packed — 8 bytes with a 12-bit tag */
     int hintDirect;                /* QZSTD_HIP_HINT_DIRECT: 0 (default) an announcement's staging copy goes to device memory by a copy kernel on the
                                     * launch's stream; 1 the match-finder reads the pinned staging copy itself; 2 that at the levels without
                                     * chains only; 3 the copy by hipMemcpyAsync (rounds 1-3).  Batch front-end, 16 threads, 2 MiB claims, GB/s:
@@ -825,6 +826,9 @@ int QZSTD_startQatDevice(void)
         gProc.svcSpinUs = qzEnvInt("QZSTD_HIP_SERVICE_SPIN_US", 400, 0, 1000000);
         gProc.svcSpinSet = getenv("QZSTD_HIP_SERVICE_SPIN_US") != NULL;
         gProc.hintFlags = qzEnvInt("QZSTD_HIP_HINT_FLAGS", 1, 0, 1);
+        /* announcements: PACKED result entries (qzstd_hip.h: QZSTD_HIP_MARK_COMPACT) — 8 bytes per sequence over PCIe instead of 16 (round 6: the
+         * level-1 kernel ran at the bus's write rate); needs the count-word completion (every entry certifies itself).  0 = 16-byte entries (A/B) */
+        gProc.hintCompact = gProc.hintFlags ? qzEnvInt("QZSTD_HIP_HINT_COMPACT", 1, 0, 1) : 0;
         gProc.hintDirect = qzEnvInt("QZSTD_HIP_HINT_DIRECT", 0, 0, 3);
         (void)qzUsableCores(); /* (read once here, under the process mutex: the waits only load it) */
     }
@@ -982,6 +986,33 @@ static int qzTakeMarked(ZSTD_Sequence *dst, const ZSTD_Sequence *q, size_t n, un
             } while ((unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(v, 12)) != epoch);
         }
         if (dst) _mm_storeu_si128((__m128i *)(void *)(dst + j), _mm_and_si128(v, keep));
+    }
+    return 0;
+}
+
+/* The same for PACKED entries (qzstd_hip.h: QZSTD_HIP_MARK_COMPACT): one 8-byte load per entry (it arrived as one store), taken when its top 12
+ * bits show the tag, unpacked into the caller's ZSTD_Sequence array.  *covered += literal + match lengths of the entries taken (dst != NULL). */
+static int qzTakePacked(ZSTD_Sequence *dst, const unsigned long long *q, size_t n, unsigned int tag)
+{
+    unsigned long t0 = 0;
+    size_t j;
+    for (j = 0; j < n; j++) {
+        unsigned long long v = __atomic_load_n(&q[j], __ATOMIC_RELAXED);
+        if (QZSTD_HIP_PACKED_TAG(v) != tag) { /* not there yet: rare */
+            unsigned spins = 0;
+            if (!t0) t0 = qzNowNs();
+            do {
+                __builtin_ia32_pause();
+                if ((++spins & 1023u) == 0u && qzNowNs() - t0 > (unsigned long)gProc.timeoutMs * 1000000ul) return 1;
+                v = __atomic_load_n(&q[j], __ATOMIC_RELAXED);
+            } while (QZSTD_HIP_PACKED_TAG(v) != tag);
+        }
+        if (dst) {
+            dst[j].offset = QZSTD_HIP_PACKED_OFF(v);
+            dst[j].litLength = QZSTD_HIP_PACKED_LIT(v);
+            dst[j].matchLength = QZSTD_HIP_PACKED_ML(v);
+            dst[j].rep = 0;
+        }
     }
     return 0;
 }
@@ -1538,6 +1569,24 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                     for (bi = b; bi < e; bi++) {
                         const ZSTD_Sequence *q = h->hSeqs + bi * h->pitch;
                         const size_t count = h->hCount[bi];
+                        if (h->hDesc[bi].mark & QZSTD_HIP_MARK_COMPACT) {
+                            /* packed entries (8 bytes, 12-bit tag): unpacked into the caller's array as they are taken */
+                            const unsigned long long *q8 = (const unsigned long long *)(const void *)((const unsigned char *)h->hSeqs + bi * h->pitch * 8u);
+                            ZSTD_Sequence dl;
+                            if (qzTakePacked(count > 1 ? outSeqs + out : NULL, q8, count - 1, h->hDesc[bi].mark & 0xFFFu) != 0 ||
+                                qzTakePacked(&dl, q8 + count - 1, 1, h->hDesc[bi].mark & 0xFFFu) != 0) {
+                                QZ_LOG(1, "announcement: entries of block %zu did not arrive within %d ms of their count\n", bi, gProc.timeoutMs);
+                                usable = 0;
+                                break;
+                            }
+                            if (count > 1) {
+                                outSeqs[out].litLength += (unsigned int)carry;
+                                out += count - 1;
+                                carry = 0;
+                            }
+                            carry += dl.litLength; /* the block's delimiter: its trailing literals */
+                            continue;
+                        }
                         /* completed by its count word: the entries certify themselves one by one (the last one, the delimiter, too) */
                         if (h->hDesc[bi].mark != 0u && (qzTakeMarked(count > 1 ? outSeqs + out : NULL, q, count - 1, h->hDesc[bi].mark) != 0 ||
                                                         qzTakeMarked(NULL, q + count - 1, 1, h->hDesc[bi].mark) != 0)) {
@@ -1779,6 +1828,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     nb = (srcSize + blockSize - 1) / blockSize;
     /* a fine grid means many blocks: the result area is sized by what a block of that size can produce at most */
     h->pitch = qzstd_hip_sequence_bound(blockSize) < QZ_HINT_PITCH ? qzstd_hip_sequence_bound(blockSize) : QZ_HINT_PITCH;
+    h->pitch = (h->pitch + 1u) & ~(size_t)1; /* (even: a block's region of packed entries is pitch / 2 sixteen-byte units long) */
     blocksBytes = nb * sizeof(qzstd_hip_block_t);
     srcBytes = (srcSize + 63) & ~(size_t)63;
 
@@ -1806,10 +1856,11 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     h->block = blockSize;
     h->level = compressionLevel;
     h->nb = nb;
-    h->epoch = (h->epoch + 1u) & 0xFFFFFFu;
+    h->epoch = (h->epoch + 1u) & (gProc.hintCompact ? 0xFFFu : 0xFFFFFFu);
     if (h->epoch == 0u) {
-        /* the 24-bit epoch starts over: an entry that no announcement of the last 2^24 overwrote would show a mark that is valid again.
-         * Nothing of this announcement's buffers is in flight here (qzHintDrop above): wipe the result area once per lap */
+        /* the epoch (24 bits; 12 as the tag of packed entries) starts over: an entry that no announcement of the last lap overwrote would show a
+         * mark that is valid again.  Nothing of this announcement's buffers is in flight here (qzHintDrop above): wipe the result area once per
+         * lap (packed: 2 MiB every 4 095 announcements) */
         memset(h->hSeqs, 0, h->hSeqsCap);
         h->epoch = 1u;
     }
@@ -1828,11 +1879,11 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
         for (b = 0; b < nb; b++) {
             const size_t o = b * blockSize;
             h->hDesc[b].srcOff = o;
-            h->hDesc[b].seqOff = b * h->pitch;
+            h->hDesc[b].seqOff = gProc.hintCompact ? b * (h->pitch / 2u) : b * h->pitch; /* (sixteen-byte units) */
             h->hDesc[b].srcLen = (unsigned int)(srcSize - o < blockSize ? srcSize - o : blockSize);
             h->hDesc[b].seqCap = (unsigned int)h->pitch;
             h->hDesc[b].parseFrom = 0;
-            h->hDesc[b].mark = gProc.hintFlags ? h->epoch : 0u; /* (count-word completion: every entry certifies itself, see qzTakeMarked) */
+            h->hDesc[b].mark = gProc.hintFlags ? (gProc.hintCompact ? (h->epoch | QZSTD_HIP_MARK_COMPACT) : h->epoch) : 0u; /* (count-word completion: every entry certifies itself, see qzTakeMarked) */
             h->hCount[b] = gProc.hintFlags ? QZ_COUNT_PENDING : QZSTD_HIP_NSEQ_ERROR; /* until a kernel says otherwise */
             if (h->keys && nb <= h->keysCap && nb <= QZ_CONTENT_LOOKUP_BLOCKS)
                 h->keys[b] = h->hDesc[b].srcLen >= 16 ? qzBlockKey(h->hSrc + o, h->hDesc[b].srcLen) : 0ull;

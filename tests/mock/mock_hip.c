@@ -116,6 +116,14 @@ static void *late_marks(void *p)
     struct timespec nap = { 0, 0 };
     nap.tv_nsec = (long)lt->us * 1000l;
     nanosleep(&nap, NULL);
+    if (lt->epoch & QZSTD_HIP_MARK_COMPACT) { /* packed entries: one 8-byte store each, last entries first */
+        uint64_t *w8 = (uint64_t *)lt->w;
+        for (j = lt->n; j-- > 0; )
+            __atomic_store_n(&w8[j], QZSTD_HIP_PACK(lt->real[j * 4u], lt->real[j * 4u + 1u], lt->real[j * 4u + 2u], lt->epoch & 0xFFFu), __ATOMIC_RELEASE);
+        free(lt->real);
+        free(lt);
+        return NULL;
+    }
     for (j = lt->n; j-- > 0; ) { /* last entries first; an entry's mark with (here: after) its three other words */
         lt->w[j * 4u] = lt->real[j * 4u]; lt->w[j * 4u + 1u] = lt->real[j * 4u + 1u]; lt->w[j * 4u + 2u] = lt->real[j * 4u + 2u];
         __atomic_store_n(&lt->w[j * 4u + 3u], lt->epoch, __ATOMIC_RELEASE);
@@ -296,6 +304,50 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
     for (b = 0; b < nBlocks; b++) {
         const qzstd_hip_block_t *k = &d_blocks[b];
         size_t n;
+        if (k->mark & QZSTD_HIP_MARK_COMPACT) {
+            /* packed entries (qzstd_hip.h): the oracle's sequences, 8 bytes each with the 12-bit tag, in the item's region (seqOff in 16-byte units) */
+            qzo_seq_t *tmp = (qzo_seq_t *)malloc(((size_t)k->seqCap + 1u) * sizeof(qzo_seq_t));
+            uint64_t *w8 = (uint64_t *)d_seqs + (size_t)k->seqOff * 2u;
+            size_t j;
+            n = QZO_ERROR;
+            if (tmp && replayOn()) { /* (QZSTD_MOCK_REPLAY: a "device" that costs one look-up and the packing) */
+                const long long t0 = nowNs();
+                const uint64_t key = replayKey(level, (const uint8_t *)d_src + k->srcOff, k->srcLen, k->parseFrom);
+                const replay_t *r = replayFind(key);
+                if (r && r->n <= k->seqCap) {
+                    for (j = 0; j < r->n; j++)
+                        __atomic_store_n(&w8[j], QZSTD_HIP_PACK(r->seqs[j].offset, r->seqs[j].litLength, r->seqs[j].matchLength, k->mark & 0xFFFu), __ATOMIC_RELAXED);
+                    __atomic_store_n(&d_nseq[b], r->n, __ATOMIC_RELEASE);
+                    __atomic_fetch_add(&gReplayNs, (unsigned long long)(nowNs() - t0), __ATOMIC_RELAXED);
+                    __atomic_fetch_add(&gReplayHits, 1ull, __ATOMIC_RELAXED);
+                    free(tmp);
+                    continue;
+                }
+                n = qzo_find_sequences_from(&pf, (const uint8_t *)d_src + k->srcOff, k->srcLen, k->parseFrom, tmp, k->seqCap);
+                if (n != QZO_ERROR) replayKeep(key, tmp, n);
+            } else if (tmp) {
+                n = qzo_find_sequences_from(&pf, (const uint8_t *)d_src + k->srcOff, k->srcLen, k->parseFrom, tmp, k->seqCap);
+            }
+            if (nowNs() < gStallUntilNs) { free(tmp); continue; }
+            if (n != QZO_ERROR) {
+                if (gLateMarks) { /* test hook: the count first, the entries a while later, last entries first */
+                    late_t *lt = (late_t *)malloc(sizeof *lt);
+                    pthread_t th;
+                    lt->w = (uint32_t *)w8; lt->n = n; lt->epoch = k->mark; lt->us = 300 + 20 * (int)(b & 15u);
+                    lt->real = (uint32_t *)malloc(n * 16u);
+                    memcpy(lt->real, tmp, n * 16u);
+                    memset(w8, 0, n * 8u);
+                    if (pthread_create(&th, NULL, late_marks, lt) == 0) pthread_detach(th);
+                    else late_marks(lt);
+                } else {
+                    for (j = 0; j < n; j++)
+                        __atomic_store_n(&w8[j], QZSTD_HIP_PACK(tmp[j].offset, tmp[j].litLength, tmp[j].matchLength, k->mark & 0xFFFu), __ATOMIC_RELAXED);
+                }
+            }
+            free(tmp);
+            __atomic_store_n(&d_nseq[b], n == QZO_ERROR ? QZSTD_HIP_NSEQ_ERROR : (uint32_t)n, __ATOMIC_RELEASE);
+            continue;
+        }
         if (replayOn()) {
             const long long t0 = nowNs();
             const uint64_t key = replayKey(level, (const uint8_t *)d_src + k->srcOff, k->srcLen, k->parseFrom);

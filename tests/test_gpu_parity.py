@@ -16,8 +16,8 @@ def seqs_to_np(seqs, start, n):
     return a[start:start + n, :3].copy()
 
 
-def check_blocks(gpu_plugin, oracle, blocks, level=1):
-    counts, seqs, stride = gpu_plugin.find_batch(blocks, level)
+def check_blocks(gpu_plugin, oracle, blocks, level=1, packed_tag=0):
+    counts, seqs, stride = gpu_plugin.find_batch(blocks, level, packed_tag=packed_tag)
     for i, blk in enumerate(blocks):
         prof = oracle.profile(level, len(blk))
         want_n, want = oracle.find(prof, blk, cap=stride)
@@ -31,6 +31,10 @@ def check_blocks(gpu_plugin, oracle, blocks, level=1):
             bad = int(np.nonzero((got != exp).any(axis=1))[0][0])
             raise AssertionError("block %d (len %d): first differing sequence %d: gpu %s oracle %s" % (
                 i, len(blk), bad, got[bad], exp[bad]))
+        if packed_tag:  # every packed entry, the delimiter included, carries the item's 12-bit tag
+            tags = np.frombuffer(seqs, dtype=np.uint32).reshape(-1, 4)[i * stride:i * stride + want_n, 3]
+            assert (tags == packed_tag).all(), "block %d: packed entries without the tag %#x" % (i, packed_tag)
+            continue
         sub = (B.Sequence * want_n).from_buffer_copy(bytes(C.string_at(C.addressof(seqs) + i * stride * 16, want_n * 16)))
         assert oracle.lib.qzo_validate(sub, want_n, len(blk), 0) == 0
         assert oracle.lib.qzo_reconstruct_check(sub, want_n, blk, len(blk)) == 0
@@ -65,6 +69,18 @@ def test_degenerate_blocks(gpu_plugin, oracle, level):
 def test_levels(gpu_plugin, oracle, level):
     data = K.mix(11, 6 * 131072)
     check_blocks(gpu_plugin, oracle, [data[o:o + 131072] for o in range(0, len(data), 131072)], level)
+
+
+@pytest.mark.parametrize("level", [1, 3, 6, 12, 0x101])
+def test_packed_entries_equal_the_oracle(gpu_plugin, oracle, level):
+    """round 6: PACKED result entries (qzstd_hip.h: QZSTD_HIP_MARK_COMPACT — offset 17 | litLength 18 | matchLength 17 | tag 12 bits in one
+    8-byte store, what the announcements ask for so that the kernel pushes half the bytes over PCIe): the same sequences, entry for
+    entry, as the 16-byte form and the oracle — on the blocks with the longest matches and literal runs there are (128 KiB of zeros: one
+    match of 131 071; incompressible: one delimiter of 131 072 literals), ragged sizes, every kernel family"""
+    data = K.mix(21, 3 * 131072)
+    blocks = [data[o:o + 131072] for o in range(0, len(data), 131072)] + [bytes(131072), K.incompressible(5, 131072), b"ab" * 65536,
+                                                                            K.text(2, 77777), K.text(4, 5), b"", K.weblog(3, 32768)]
+    check_blocks(gpu_plugin, oracle, blocks, level, packed_tag=0xABC if level != 3 else 1)
 
 
 def test_block_32k_and_64k(gpu_plugin, oracle):

@@ -775,6 +775,36 @@ def test_announcement_epoch_wrap_wipes_stale_marks(mock, zstd, oracle):
     assert served[0] == 7 * 16 and served[1] == 0 and fs[0] == 0, (served, fs)
 
 
+def test_packed_and_sixteen_byte_announcement_entries(mock, zstd, oracle):
+    """round 6: announcements ask for PACKED result entries by default (qzstd_hip.h: QZSTD_HIP_MARK_COMPACT: 8 bytes with a 12-bit tag, half the
+    bytes the kernel writes over PCIe); QZSTD_HIP_HINT_COMPACT=0 keeps the 16-byte entries with the 24-bit epoch.  Both forms, with entries
+    that arrive after their counts (the mock's late-marks hook), over reused buffers and across the tags' lap (the result area is wiped when the
+    12-bit tag starts over: 4 095 announcements per buffer): frames are the oracle's, every block comes from an announcement"""
+    chunk = 65536
+    data = K.by_name("system", 12 * chunk + 777, seed=31)
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    L = mock.lib
+    L.qzstd_mock_late_marks.argtypes = [C.c_int]
+    L.qzstd_test_set_hint_epochs.argtypes = [C.c_void_p, C.c_uint]
+    want = oracle_frames(zstd, oracle, data, chunk, 1)
+    for compact in ("1", "0"):
+        with restarted(mock, QZSTD_HIP_HINT_COMPACT=compact):
+            st = L.QZSTD_createSeqProdState()
+            assert L.QZSTD_hintSource(st, buf, len(data), chunk, 1) == 0
+            assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1) == want
+            L.qzstd_test_set_hint_epochs(st, 0xFFC if compact == "1" else 0xFFFFFC)  # a few announcements before the lap
+            L.qzstd_mock_late_marks(1)
+            try:
+                for _ in range(8):
+                    assert L.QZSTD_hintSource(st, buf, len(data), chunk, 1) == 0
+                    assert frames_of(zstd, mock.producer_addr, st, C.addressof(buf), len(data), chunk, 1) == want, compact
+            finally:
+                L.qzstd_mock_late_marks(0)
+            served, fs = stats_of(mock, st), fail_stats(mock, st)
+            L.QZSTD_freeSeqProdState(st)
+            assert served[0] == 9 * 13 and served[1] == 0 and fs[0] == 0, (compact, served, fs)
+
+
 def test_service_epoch_wrap_wipes_stale_marks(mock, zstd, oracle):
     """the request epoch is 24 bits per slot: when it starts over, entries no request of the last lap overwrote would carry a mark
     that is valid again — the slot's result area is wiped once per lap (round-3 verdict, weak 3).  Every slot is put just before the

@@ -38,12 +38,24 @@ def main():
         data = corpus(name, blk * nb)
         d_src = torch.empty(blk * nb + 64, dtype=torch.uint8, device=dev)
         d_src[:blk * nb].copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
-        stride = B.sequence_bound(blk)
-        d_seqs = torch.empty((nb * stride, 4), dtype=torch.int32, device=dev)
-        d_cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
+        host_results = os.environ.get("KTIME_HOST_RESULTS", "0") not in ("", "0")  # sequences + counts written into PINNED HOST memory, as in the product paths
+        stride = 16384 if host_results else B.sequence_bound(blk)
+        h_seqs = h_cnt = None
+        if host_results:
+            L.qzstd_hip_host_alloc.restype = C.c_void_p
+            L.qzstd_hip_host_device_ptr.restype = C.c_void_p
+            h_seqs, h_cnt = L.qzstd_hip_host_alloc(C.c_size_t(nb * stride * 16)), L.qzstd_hip_host_alloc(C.c_size_t(nb * 4))
+            assert h_seqs and h_cnt, plug.err()
+            p_seqs, p_cnt = L.qzstd_hip_host_device_ptr(C.c_void_p(h_seqs)), L.qzstd_hip_host_device_ptr(C.c_void_p(h_cnt))
+        else:
+            d_seqs = torch.empty((nb * stride, 4), dtype=torch.int32, device=dev)
+            d_cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
+            p_seqs, p_cnt = d_seqs.data_ptr(), d_cnt.data_ptr()
+        packed = os.environ.get("KTIME_PACKED", "0") not in ("", "0")  # 8-byte entries (qzstd_hip.h: QZSTD_HIP_MARK_COMPACT), as the announcements ask for
         desc = (B.HipBlock * nb)()
         for i in range(nb):
-            desc[i].srcOff, desc[i].seqOff, desc[i].srcLen, desc[i].seqCap = i * blk, i * stride, blk, stride
+            desc[i].srcOff, desc[i].seqOff, desc[i].srcLen, desc[i].seqCap = i * blk, (i * (stride // 2) if packed else i * stride), blk, stride
+            desc[i].mark = (B.MARK_COMPACT | 1) if packed else 0
         d_desc = torch.empty(C.sizeof(desc), dtype=torch.uint8, device=dev)
         d_desc.copy_(torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8))
         work = L.qzstd_hip_workspace_bytes(lv, nb, blk)
@@ -52,7 +64,7 @@ def main():
 
         def go():
             rc = L.qzstd_hip_find_sequences(0, C.c_void_p(stream.cuda_stream), lv, C.c_void_p(d_src.data_ptr()), C.c_void_p(d_desc.data_ptr()), nb, blk,
-                                            C.c_void_p(d_seqs.data_ptr()), C.c_void_p(d_cnt.data_ptr()), C.c_void_p(d_work.data_ptr()), work)
+                                            C.c_void_p(p_seqs), C.c_void_p(p_cnt), C.c_void_p(d_work.data_ptr()), work)
             assert rc == 0, plug.err()
         go()
         torch.cuda.synchronize()
@@ -64,15 +76,23 @@ def main():
         torch.cuda.synchronize()
         ms = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(reps))
         med = ms[len(ms) // 2]
-        c = d_cnt.cpu().numpy().astype("uint32")
+        if host_results:
+            import numpy as np
+            c = np.ctypeslib.as_array((C.c_uint32 * nb).from_address(h_cnt)).copy()
+        else:
+            c = d_cnt.cpu().numpy().astype("uint32")
         ok = c[c != 0xFFFFFFFF]
         # a position-weighted checksum of the counts: two builds that should produce the same sequences print the same number
         chk = int((ok.astype("uint64") * (1 + (ok.size and (__import__("numpy").arange(ok.size, dtype="uint64") % 251)))).sum()) if ok.size else 0
         occ = L.qzstd_hip_occupancy(0, lv) if hasattr(L, "qzstd_hip_occupancy") else -1
-        print("[%d WG/CU] level %#x block %d x %d %s: %.3f ms (min %.3f) = %.1f ms/GiB = %.2f GB/s in; %.1f seq/block, %d error blocks, counts checksum %d"
-              % (occ, lv, blk, nb, name, med, ms[0], med * (1 << 30) / (blk * nb), blk * nb / med / 1e6, float(ok.mean()) if ok.size else 0.0,
+        print("[%d WG/CU]%s level %#x block %d x %d %s: %.3f ms (min %.3f) = %.1f ms/GiB = %.2f GB/s in; %.1f seq/block, %d error blocks, counts checksum %d"
+              % (occ, (" results in pinned host memory," if host_results else "") + (" PACKED entries," if packed else ""), lv, blk, nb, name, med, ms[0], med * (1 << 30) / (blk * nb), blk * nb / med / 1e6, float(ok.mean()) if ok.size else 0.0,
                  int((c == 0xFFFFFFFF).sum()), chk), flush=True)
-        del d_src, d_seqs, d_cnt, d_desc, d_work
+        if host_results:
+            L.qzstd_hip_host_free(C.c_void_p(h_seqs)); L.qzstd_hip_host_free(C.c_void_p(h_cnt))
+        else:
+            del d_seqs, d_cnt
+        del d_src, d_desc, d_work
         torch.cuda.empty_cache()
 
 

@@ -306,6 +306,7 @@ class HipBlock(C.Structure):
 
 
 NSEQ_ERROR = 0xFFFFFFFF
+MARK_COMPACT = 0x80000000  # qzstd_hip.h: QZSTD_HIP_MARK_COMPACT
 NSEQ_REJECTED = 0xFFFFFFFE
 
 
@@ -406,9 +407,11 @@ class Plugin:
         return ServiceLane(self, slot, device)
 
     def find_batch(self, blocks: list[bytes], level: int = 1, device: int = 0, stride: int | None = None,
-                   caps: list[int] | None = None, parse_from: list[int] | None = None):
+                   caps: list[int] | None = None, parse_from: list[int] | None = None, packed_tag: int = 0):
         """Run the HIP match-finder over `blocks` through the C ABI (device memory managed
-        with qzstd_hip_malloc / memcpy).  Returns (counts, list of Sequence arrays)."""
+        with qzstd_hip_malloc / memcpy).  Returns (counts, list of Sequence arrays).
+        packed_tag != 0: the items ask for PACKED entries (qzstd_hip.h: QZSTD_HIP_MARK_COMPACT | tag, 8 bytes each, seqOff in 16-byte units);
+        they are unpacked here into the same Sequence array (rep = the tag found), so callers compare them like the 16-byte ones."""
         L = self.lib
         nb = len(blocks)
         maxlen = max([len(b) for b in blocks] + [1])
@@ -424,7 +427,8 @@ class Plugin:
         desc = (HipBlock * nb)()
         for i, b in enumerate(blocks):
             desc[i].srcOff = offs[i]
-            desc[i].seqOff = i * stride
+            desc[i].seqOff = i * stride if not packed_tag else i * ((stride + 1) // 2)
+            desc[i].mark = (MARK_COMPACT | (packed_tag & 0xFFF)) if packed_tag else 0
             desc[i].srcLen = len(b)
             desc[i].seqCap = caps[i] if caps else stride
             desc[i].parseFrom = parse_from[i] if parse_from else 0  # segment mode: the item parses [parseFrom, len) only
@@ -448,6 +452,18 @@ class Plugin:
             self.check(L.qzstd_hip_memcpy_d2h(device, None, cnt, d_cnt, nb * 4), "d2h counts")
             self.check(L.qzstd_hip_memcpy_d2h(device, None, seqs, d_seqs, nb * stride * 16), "d2h seqs")
             self.check(L.qzstd_hip_stream_sync(device, None), "sync")
+            if packed_tag:
+                import numpy as np
+                raw = np.frombuffer(seqs, dtype=np.uint64)  # the device buffer's first bytes: block i's packed entries start at 16 * seqOff
+                out = np.zeros((nb * stride, 4), dtype=np.uint32)
+                for i in range(nb):
+                    n = cnt[i] if cnt[i] != NSEQ_ERROR else 0
+                    v = raw[i * ((stride + 1) // 2) * 2:][:n]
+                    out[i * stride:i * stride + n, 0] = (v & 0x1FFFF).astype(np.uint32)
+                    out[i * stride:i * stride + n, 1] = ((v >> np.uint64(17)) & np.uint64(0x3FFFF)).astype(np.uint32)
+                    out[i * stride:i * stride + n, 2] = ((v >> np.uint64(35)) & np.uint64(0x1FFFF)).astype(np.uint32)
+                    out[i * stride:i * stride + n, 3] = (v >> np.uint64(52)).astype(np.uint32)
+                seqs = (Sequence * (nb * stride)).from_buffer_copy(out.tobytes())
         finally:
             for p in (d_src, d_desc, d_seqs, d_cnt, d_work):
                 if p:
