@@ -865,16 +865,28 @@ def main():
         if not a.no_cpu and world == 1 and level == 1 and block == 131072:
             # the other BASELINE levels through the same entry point, resident input, HIP events (side keys, not the metric):
             # config 3's level 6 on 128 KiB blocks, config 4's level 12 on 32 KiB web-log blocks
-            def side_kernel(lv, blk, nblk, src_bytes):
+            def side_kernel(lv, blk, nblk, src_bytes, host_results=0):
+                """host_results: 0 = results in device memory (as the roofline block); 16 / 8 = counts + sequences written by the kernel into PINNED HOST
+                memory, as in the product paths, 16-byte entries / PACKED 8-byte entries (what the announcements ask for since round 6)"""
+                h_seqs = h_cnt = None
                 try:
                     t_src = torch.empty(nblk * blk + 64, dtype=torch.uint8, device=dev)
                     t_src[:nblk * blk].copy_(torch.frombuffer(bytearray(src_bytes[:nblk * blk]), dtype=torch.uint8))
-                    st2 = B.sequence_bound(blk)
-                    t_seqs = torch.empty((nblk * st2, 4), dtype=torch.int32, device=dev)
-                    t_cnt = torch.zeros(nblk, dtype=torch.int32, device=dev)
+                    st2 = 16384 if host_results else B.sequence_bound(blk)
+                    if host_results:
+                        L.qzstd_hip_host_alloc.restype = C.c_void_p
+                        L.qzstd_hip_host_device_ptr.restype = C.c_void_p
+                        h_seqs, h_cnt = L.qzstd_hip_host_alloc(C.c_size_t(nblk * st2 * host_results)), L.qzstd_hip_host_alloc(C.c_size_t(nblk * 4))
+                        assert h_seqs and h_cnt, plug.err()
+                        p_seqs, p_cnt = L.qzstd_hip_host_device_ptr(C.c_void_p(h_seqs)), L.qzstd_hip_host_device_ptr(C.c_void_p(h_cnt))
+                    else:
+                        t_seqs = torch.empty((nblk * st2, 4), dtype=torch.int32, device=dev)
+                        t_cnt = torch.zeros(nblk, dtype=torch.int32, device=dev)
+                        p_seqs, p_cnt = t_seqs.data_ptr(), t_cnt.data_ptr()
                     dsc = (B.HipBlock * nblk)()
                     for i in range(nblk):
-                        dsc[i].srcOff, dsc[i].seqOff, dsc[i].srcLen, dsc[i].seqCap = i * blk, i * st2, blk, st2
+                        dsc[i].srcOff, dsc[i].seqOff, dsc[i].srcLen, dsc[i].seqCap = i * blk, (i * (st2 // 2) if host_results == 8 else i * st2), blk, st2
+                        dsc[i].mark = (B.MARK_COMPACT | 1) if host_results == 8 else 0
                     t_desc = torch.empty(C.sizeof(dsc), dtype=torch.uint8, device=dev)
                     t_desc.copy_(torch.frombuffer(bytearray(bytes(dsc)), dtype=torch.uint8))
                     wk = L.qzstd_hip_workspace_bytes(lv, nblk, blk)
@@ -883,8 +895,8 @@ def main():
 
                     def go():
                         rc2 = L.qzstd_hip_find_sequences(local, C.c_void_p(stream.cuda_stream), lv, C.c_void_p(t_src.data_ptr()),
-                                                         C.c_void_p(t_desc.data_ptr()), nblk, blk, C.c_void_p(t_seqs.data_ptr()),
-                                                         C.c_void_p(t_cnt.data_ptr()), C.c_void_p(t_work.data_ptr()), wk)
+                                                         C.c_void_p(t_desc.data_ptr()), nblk, blk, C.c_void_p(p_seqs),
+                                                         C.c_void_p(p_cnt), C.c_void_p(t_work.data_ptr()), wk)
                         if rc2 != 0:
                             raise RuntimeError(plug.err())
                     go()
@@ -895,14 +907,28 @@ def main():
                     e1.record(stream)
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / 3
-                    c2 = t_cnt.cpu().numpy().astype("uint32")
-                    return {"level": lv, "block_bytes": blk, "blocks": nblk, "kernel_ms": round(ms, 3),
+                    if host_results:
+                        import numpy as np
+                        c2 = np.ctypeslib.as_array((C.c_uint32 * nblk).from_address(h_cnt)).copy()
+                    else:
+                        c2 = t_cnt.cpu().numpy().astype("uint32")
+                    return {"level": lv, "block_bytes": blk, "blocks": nblk, "kernel_ms": round(ms, 3), "results": {0: "device memory", 16: "pinned host memory, 16-byte entries", 8: "pinned host memory, PACKED 8-byte entries"}[host_results],
                             "input_GBps": round(nblk * blk / (ms * 1e-3) / 1e9, 2), "ms_per_GiB": round(ms * (1 << 30) / (nblk * blk), 1),
                             "sequences_per_block": round(float(c2[c2 != 0xFFFFFFFF].mean()), 1), "error_blocks": int((c2 == 0xFFFFFFFF).sum())}
                 except Exception as e:  # noqa: BLE001
                     return {"error": repr(e)[:200]}
+                finally:
+                    if h_seqs:
+                        L.qzstd_hip_host_free(C.c_void_p(h_seqs))
+                    if h_cnt:
+                        L.qzstd_hip_host_free(C.c_void_p(h_cnt))
             out["kernel_other_levels"] = {"config3_level6_128KiB": side_kernel(6, 131072, 2048, shard),
                                           "config4_level12_32KiB_weblog": side_kernel(12, 32768, 8192, K.weblog(4, 64 * K.MiB) * 4)}
+            # the metric's kernel as the PRODUCT runs it: counts + sequences written straight into pinned host memory (round 6: with 16-byte entries it
+            # ran at the bus's write rate; the announcements ask for packed entries since)
+            out["kernel_results_over_pcie_level1"] = {"device_memory": side_kernel(level, block, 2048, shard),
+                                                      "pinned_host_16_byte_entries": side_kernel(level, block, 2048, shard, 16),
+                                                      "pinned_host_packed_entries": side_kernel(level, block, 2048, shard, 8)}
         if not a.no_cpu and world == 1:  # CPU legs on rank 0 at N=1 only (bench contract)
             import tempfile
             ncpu, quota = host_cpu_budget()

@@ -196,6 +196,7 @@ typedef struct {
     int hintFlags;                 /* QZSTD_HIP_HINT_FLAGS (default 1): an announcement's launch is complete when its blocks' count words are in (0: when
                                     * the runtime says its stream is idle) */
     int hintCompact;               /* QZSTD_HIP_HINT_COMPACT (default 1): announcements' result entries are packed — 8 bytes with a 12-bit tag */
+    int stageNt;                   /* QZSTD_HIP_STAGE_NT (default 1): announcements are staged with streaming stores (qzStageCopy) */
     int hintDirect;                /* QZSTD_HIP_HINT_DIRECT: 0 (default) an announcement's staging copy goes to device memory by a copy kernel on the
                                     * launch's stream; 1 the match-finder reads the pinned staging copy itself; 2 that at the levels without
                                     * chains only; 3 the copy by hipMemcpyAsync (rounds 1-3).  Batch front-end, 16 threads, 2 MiB claims, GB/s:
@@ -829,6 +830,7 @@ int QZSTD_startQatDevice(void)
         /* announcements: PACKED result entries (qzstd_hip.h: QZSTD_HIP_MARK_COMPACT) — 8 bytes per sequence over PCIe instead of 16 (round 6: the
          * level-1 kernel ran at the bus's write rate); needs the count-word completion (every entry certifies itself).  0 = 16-byte entries (A/B) */
         gProc.hintCompact = gProc.hintFlags ? qzEnvInt("QZSTD_HIP_HINT_COMPACT", 1, 0, 1) : 0;
+        gProc.stageNt = qzEnvInt("QZSTD_HIP_STAGE_NT", 1, 0, 1);
         gProc.hintDirect = qzEnvInt("QZSTD_HIP_HINT_DIRECT", 0, 0, 3);
         (void)qzUsableCores(); /* (read once here, under the process mutex: the waits only load it) */
     }
@@ -994,24 +996,40 @@ static int qzTakeMarked(ZSTD_Sequence *dst, const ZSTD_Sequence *q, size_t n, un
  * bits show the tag, unpacked into the caller's ZSTD_Sequence array.  *covered += literal + match lengths of the entries taken (dst != NULL). */
 static int qzTakePacked(ZSTD_Sequence *dst, const unsigned long long *q, size_t n, unsigned int tag)
 {
+    const __m128i m17 = _mm_set_epi32(0, 0x1FFFF, 0, 0x1FFFF), m18 = _mm_set_epi32(0, 0x3FFFF, 0, 0x3FFFF);
     unsigned long t0 = 0;
-    size_t j;
-    for (j = 0; j < n; j++) {
-        unsigned long long v = __atomic_load_n(&q[j], __ATOMIC_RELAXED);
-        if (QZSTD_HIP_PACKED_TAG(v) != tag) { /* not there yet: rare */
-            unsigned spins = 0;
-            if (!t0) t0 = qzNowNs();
-            do {
-                __builtin_ia32_pause();
-                if ((++spins & 1023u) == 0u && qzNowNs() - t0 > (unsigned long)gProc.timeoutMs * 1000000ul) return 1;
-                v = __atomic_load_n(&q[j], __ATOMIC_RELAXED);
-            } while (QZSTD_HIP_PACKED_TAG(v) != tag);
+    size_t j = 0;
+    while (j < n) {
+        if (dst && j + 2 <= n) { /* two entries per step: the usual case, both there */
+            const __m128i v = _mm_loadu_si128((const __m128i *)(const void *)(q + j));
+            const __m128i t = _mm_srli_epi64(v, 52);
+            if ((unsigned int)_mm_cvtsi128_si32(t) == tag && (unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(t, 8)) == tag) {
+                const __m128i ol = _mm_or_si128(_mm_and_si128(v, m17), _mm_slli_epi64(_mm_and_si128(_mm_srli_epi64(v, 17), m18), 32)); /* off0 lit0 off1 lit1 */
+                const __m128i ml = _mm_and_si128(_mm_srli_epi64(v, 35), m17);                                                          /* ml0  0    ml1  0    */
+                _mm_storeu_si128((__m128i *)(void *)(dst + j), _mm_unpacklo_epi64(ol, ml));
+                _mm_storeu_si128((__m128i *)(void *)(dst + j + 1), _mm_unpackhi_epi64(ol, ml));
+                j += 2;
+                continue;
+            }
         }
-        if (dst) {
-            dst[j].offset = QZSTD_HIP_PACKED_OFF(v);
-            dst[j].litLength = QZSTD_HIP_PACKED_LIT(v);
-            dst[j].matchLength = QZSTD_HIP_PACKED_ML(v);
-            dst[j].rep = 0;
+        {
+            unsigned long long v = __atomic_load_n(&q[j], __ATOMIC_RELAXED);
+            if (QZSTD_HIP_PACKED_TAG(v) != tag) { /* not there yet: rare */
+                unsigned spins = 0;
+                if (!t0) t0 = qzNowNs();
+                do {
+                    __builtin_ia32_pause();
+                    if ((++spins & 1023u) == 0u && qzNowNs() - t0 > (unsigned long)gProc.timeoutMs * 1000000ul) return 1;
+                    v = __atomic_load_n(&q[j], __ATOMIC_RELAXED);
+                } while (QZSTD_HIP_PACKED_TAG(v) != tag);
+            }
+            if (dst) {
+                dst[j].offset = QZSTD_HIP_PACKED_OFF(v);
+                dst[j].litLength = QZSTD_HIP_PACKED_LIT(v);
+                dst[j].matchLength = QZSTD_HIP_PACKED_ML(v);
+                dst[j].rep = 0;
+            }
+            j++;
         }
     }
     return 0;
@@ -1657,6 +1675,26 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
 
 /* ---------------------------------------------------------------- announcements -- */
 
+/* The staging copy of an announcement (reference: the memcpy into DMA memory, :1222-1227): caller's bytes -> pinned buffer the GPU reads over the
+ * bus.  For a STABLE announcement nobody on the host reads the copy again soon (a sampled memcmp at most), so it goes out with STREAMING stores: no
+ * read-for-ownership of the destination lines and no 2 MiB of a thread's cache spent on bytes only the GPU wants — with 16 threads staging at
+ * once the copies share the socket's memory bandwidth, a third of which the ordinary stores' line fills took.  QZSTD_HIP_STAGE_NT=0: memcpy. */
+static void qzStageCopy(unsigned char *dst, const unsigned char *src, size_t n)
+{
+    size_t i = 0;
+    if (!gProc.stageNt || n < 4096 || ((uintptr_t)dst & 15u)) { memcpy(dst, src, n); return; }
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(const void *)(src + i)), b = _mm_loadu_si128((const __m128i *)(const void *)(src + i + 16)),
+                      c = _mm_loadu_si128((const __m128i *)(const void *)(src + i + 32)), d = _mm_loadu_si128((const __m128i *)(const void *)(src + i + 48));
+        _mm_stream_si128((__m128i *)(void *)(dst + i), a);
+        _mm_stream_si128((__m128i *)(void *)(dst + i + 16), b);
+        _mm_stream_si128((__m128i *)(void *)(dst + i + 32), c);
+        _mm_stream_si128((__m128i *)(void *)(dst + i + 48), d);
+    }
+    _mm_sfence(); /* streaming stores are weakly ordered: before anything that tells the GPU the bytes are there */
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+
 /* grow-only buffers: returns the (possibly new) pointer, NULL on failure */
 static void *qzGrowHostC(void *old, size_t *cap, size_t need, int dev, int coherent)
 {
@@ -1815,7 +1853,7 @@ fail:
  * src/qatseqprod.c:601-630), each on its own slot and stream; the results land in the announcement's pinned buffers.
  * Returns the bytes announced, 0 if none. */
 static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, size_t srcSize, size_t blockSize,
-                         int compressionLevel)
+                         int compressionLevel, int stable)
 {
     size_t nb, blocksBytes, srcBytes;
     unsigned long tq, tp;
@@ -1848,7 +1886,10 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     s->hintPrepNs += qzNowNs() - tp;
 
     tq = qzNowNs();
-    memcpy(h->hSrc, src, srcSize); /* pinned staging (reference: the staging memcpy, :1222-1227) */
+    /* pinned staging (reference: the staging memcpy, :1222-1227).  Streaming stores where the host will not read the copy back: a verified
+     * announcement compares every callback's block with it (measured with the copy streamed out: -2 ... -4 %), a STABLE one only samples (+1.5 %) */
+    if (stable) qzStageCopy(h->hSrc, (const unsigned char *)src, srcSize);
+    else memcpy(h->hSrc, src, srcSize);
     s->hintStageNs += qzNowNs() - tq;
     tq = qzNowNs();
     h->base = (const unsigned char *)src;
@@ -1954,7 +1995,7 @@ int QZSTD_hintSourceEx(void *sequenceProducerState, const void *src, size_t srcS
             if ((int)(s->hint[k].seq - h->seq) < 0) h = &s->hint[k];
     }
     s->hintNext = (int)((h - s->hint) + 1) % QZ_HINTS;
-    if (qzAnnounce(s, h, src, srcSize, blockSize, compressionLevel) == 0) return -1;
+    if (qzAnnounce(s, h, src, srcSize, blockSize, compressionLevel, (flags & QZSTD_HINT_STABLE) != 0) == 0) return -1;
     for (k = 0; k < h->nParts; k++) inflight += h->part[k].st == 1;
     if (!inflight) { /* nothing could be queued */
         qzHintDrop(h);
