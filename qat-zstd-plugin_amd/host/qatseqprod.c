@@ -1000,8 +1000,9 @@ static int qzTakePacked(ZSTD_Sequence *dst, const unsigned long long *q, size_t 
     unsigned long t0 = 0;
     size_t j = 0;
     while (j < n) {
-        if (dst && j + 2 <= n) { /* two entries per step: the usual case, both there */
-            const __m128i v = _mm_loadu_si128((const __m128i *)(const void *)(q + j));
+        if (dst && j + 2 <= n && !((uintptr_t)(q + j) & 15u)) { /* two entries per step: the usual case, both there (an ALIGNED 16-byte load: each
+                                                                  * 8-byte half is one of the kernel's stores, never torn) */
+            const __m128i v = _mm_load_si128((const __m128i *)(const void *)(q + j));
             const __m128i t = _mm_srli_epi64(v, 52);
             if ((unsigned int)_mm_cvtsi128_si32(t) == tag && (unsigned int)_mm_cvtsi128_si32(_mm_srli_si128(t, 8)) == tag) {
                 const __m128i ol = _mm_or_si128(_mm_and_si128(v, m17), _mm_slli_epi64(_mm_and_si128(_mm_srli_epi64(v, 17), m18), 32)); /* off0 lit0 off1 lit1 */
