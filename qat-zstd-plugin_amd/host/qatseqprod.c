@@ -1586,7 +1586,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                 }
                 if (usable && total < outSeqsCapacity - 1) {
                     for (bi = b; bi < e; bi++) {
-                        const ZSTD_Sequence *q = h->hSeqs + bi * h->pitch;
+                        const ZSTD_Sequence *q;
                         const size_t count = h->hCount[bi];
                         if (h->hDesc[bi].mark & QZSTD_HIP_MARK_COMPACT) {
                             /* packed entries (8 bytes, 12-bit tag): unpacked into the caller's array as they are taken */
@@ -1606,6 +1606,7 @@ size_t qatSequenceProducer(void *sequenceProducerState, ZSTD_Sequence *outSeqs, 
                             carry += dl.litLength; /* the block's delimiter: its trailing literals */
                             continue;
                         }
+                        q = h->hSeqs + bi * h->pitch;
                         /* completed by its count word: the entries certify themselves one by one (the last one, the delimiter, too) */
                         if (h->hDesc[bi].mark != 0u && (qzTakeMarked(count > 1 ? outSeqs + out : NULL, q, count - 1, h->hDesc[bi].mark) != 0 ||
                                                         qzTakeMarked(NULL, q + count - 1, 1, h->hDesc[bi].mark) != 0)) {
@@ -1877,7 +1878,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     h->hSrc = (unsigned char *)qzGrowHost(h->hSrc, &h->hSrcCap, srcBytes, firstDev);
     h->hDesc = (qzstd_hip_block_t *)qzGrowHost(h->hDesc, &h->hDescCap, blocksBytes, firstDev);
     h->hCount = (unsigned int *)qzGrowHostC(h->hCount, &h->hCountCap, nb * sizeof(unsigned int), firstDev, gProc.hintFlags);
-    h->hSeqs = (ZSTD_Sequence *)qzGrowHostC(h->hSeqs, &h->hSeqsCap, nb * h->pitch * sizeof(ZSTD_Sequence), firstDev, gProc.hintFlags);
+    h->hSeqs = (ZSTD_Sequence *)qzGrowHostC(h->hSeqs, &h->hSeqsCap, nb * h->pitch * (gProc.hintCompact ? 8u : sizeof(ZSTD_Sequence)), firstDev, gProc.hintFlags); /* (packed entries: 8 bytes) */
     if (!h->hSrc || !h->hDesc || !h->hCount || !h->hSeqs) return 0;
     if (h->dvOf[0] != h->hDesc || !h->dvDesc) { h->dvDesc = qzstd_hip_host_device_ptr(h->hDesc); h->dvOf[0] = h->hDesc; }
     if (h->dvOf[1] != h->hCount || !h->dvCount) { h->dvCount = qzstd_hip_host_device_ptr(h->hCount); h->dvOf[1] = h->hCount; }
