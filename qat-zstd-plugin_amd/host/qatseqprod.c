@@ -252,6 +252,8 @@ typedef struct {
     size_t hSrcCap, hSeqsCap, hCountCap, hDescCap; /* bytes */
     int nStuck, stuckSlot[QZ_HINT_PARTS]; /* slots whose wait timed out: a kernel may still read and write the buffers above */
     int noAddr; /* a newer announcement names (some of) these addresses: this one no longer serves by address, only by verified content */
+    int packedLast; /* the form of the entries the result area held last (1 packed, 0 sixteen-byte): a change of form (the device layer restarted with
+                     * another QZSTD_HIP_HINT_COMPACT) wipes it, as a lap of the epochs does */
 } QZSTD_Hint_T;
 
 /* Pinned buffers of an announcement that a timed-out kernel may still read (hSrc, hDesc) and write (hSeqs, hCount): the
@@ -1900,6 +1902,7 @@ static size_t qzAnnounce(QZSTD_Session_T *s, QZSTD_Hint_T *h, const void *src, s
     h->level = compressionLevel;
     h->nb = nb;
     h->epoch = (h->epoch + 1u) & (gProc.hintCompact ? 0xFFFu : 0xFFFFFFu);
+    if (h->packedLast != gProc.hintCompact) { h->epoch = 0u; h->packedLast = gProc.hintCompact; } /* (entries of the other form mean nothing as marks) */
     if (h->epoch == 0u) {
         /* the epoch (24 bits; 12 as the tag of packed entries) starts over: an entry that no announcement of the last lap overwrote would show a
          * mark that is valid again.  Nothing of this announcement's buffers is in flight here (qzHintDrop above): wipe the result area once per
