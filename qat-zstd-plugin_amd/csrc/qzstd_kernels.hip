@@ -57,6 +57,13 @@
 
 #include "qzstd_hip.h"
 
+#ifndef QZ_REP_DEFER
+#define QZ_REP_DEFER 1 /* the launch kernels of the repeat-aware parse BELOW THE CHAIN LEVELS (level 1-4 | REPCODES) parse AFTER their tile loop, eight segments at a
+                        * time (qz_item: DEFER): 65.0 -> 23.5 ms per GiB at level 1 | REPCODES, 125.9 -> 40.4 at level 3 | REPCODES, bit-exact.  A/B: 0 = in the loop,
+                        * one wave, as the resident service's items do; 2 = deferred at the chain levels too — measured SLOWER there (level 12: 185.8 -> 192.1 ms
+                        * per GiB, config 4's shape 105.7 -> 107.8): the chain walk takes longer than the parse wave's serial chain, which the lock-step loop
+                        * hides completely, so deferring it only adds the parse's own time */
+#endif
 #ifndef QZ_CHAIN_SHIFT
 #define QZ_CHAIN_SHIFT 1 /* chain levels: a tile's start flags are written in the next iteration's first interval (A/B: 0) */
 #endif
@@ -343,10 +350,9 @@ __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint3
 
 /* cooperative forward extension of a match that hit the candidate cap: 64 lanes x 16 bytes
  * (1 KiB) per step, never past `lim` */
-__device__ __forceinline__ uint32_t extend_match(const Src &s, uint32_t p, uint32_t off, uint32_t L, uint32_t lim,
-                                                 uint32_t lane)
+__device__ __forceinline__ uint32_t extend_match_from(const Src &s, uint32_t p, uint32_t off, uint32_t L, uint32_t lim,
+                                                      uint32_t lane, const bool far /* uniform: the whole match has one offset */)
 {
-    const bool far = off > s.nearLimit; /* uniform: the whole match has one offset */
     for (;;) {
         const uint32_t a = p + L + 16u * lane;
         uint32_t ok = 0; /* bytes of this lane's 16 that match and lie below lim */
@@ -370,6 +376,11 @@ __device__ __forceinline__ uint32_t extend_match(const Src &s, uint32_t p, uint3
         }
         L += 1024u;
     }
+}
+
+__device__ __forceinline__ uint32_t extend_match(const Src &s, uint32_t p, uint32_t off, uint32_t L, uint32_t lim, uint32_t lane)
+{
+    return extend_match_from(s, p, off, L, lim, lane, off > s.nearLimit);
 }
 
 /* parse-wave state, uniform across the wave */
@@ -546,12 +557,21 @@ __device__ __forceinline__ uint32_t ring_byte(const Src &s, uint32_t x, bool far
 /* equality bitmap of the 64 bytes from `cur` against the bytes `rp` back (0 when rp == 0): bit b = byte cur+b matches.
  * General form (any offset, sources beyond the ring's reach come from HBM); the parse loop below only uses it when one of
  * the repeats is farther back than the ring holds */
-__device__ __forceinline__ u64 rep_bitmap(const Src &src, uint32_t cur, uint32_t rp, uint32_t n, uint32_t lane)
+__device__ __forceinline__ u64 rep_bitmap(const Src &src, uint32_t cur, uint32_t rp, uint32_t n, uint32_t lane, uint32_t ringFrom = 0u)
 {
     const uint32_t bpos = cur + lane;
     bool eq = false;
-    if (rp != 0u && bpos < n) eq = ring_byte(src, bpos, false) == ring_byte(src, bpos - rp, rp > src.nearLimit);
+    /* ringFrom: the deferred parse (below) reads a ring that holds [ringFrom, ringFrom + kRing) — a source is far when it lies before that */
+    if (rp != 0u && bpos < n) eq = ring_byte(src, bpos, false) == ring_byte(src, bpos - rp, rp > src.nearLimit || bpos - rp < ringFrom);
     return __ballot(eq);
+}
+
+/* The deferred repeat-aware parse (qz_item<..., DEFER>): one record per chosen match, 60 bits — position (17) | offset (17) << 17 | length (13: a match
+ * never leaves its 4 KiB segment) << 34 | literals since the previous match of the SEGMENT (13) << 47 — written over the segment's own parse words in
+ * device memory: record k lands on the words of the segment's positions 2k and 2k + 1, behind the cursor (a match is at least three bytes long). */
+__device__ __forceinline__ u64 rep_record(uint32_t q, uint32_t off, uint32_t L, uint32_t lit)
+{
+    return (u64)q | ((u64)off << 17) | ((u64)L << 34) | ((u64)lit << 47);
 }
 
 /* scalar x mod kRing for x < 3 * kRing (kept in SGPRs by the parse wave) */
@@ -565,10 +585,14 @@ __device__ __forceinline__ uint32_t ring_off_s(uint32_t a)
  * from the cursor and the bytes one repeat-1 / repeat-2 offset before them — is fetched up front in ONE round trip
  * (addresses depend on the scalars only), the run lengths come from the two ballots with a funnel shift + ffbl, the hash
  * gains were computed by the matcher waves (G in the low 10 bits of the word). */
+template <bool DEF>
 __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, const Src &src, uint32_t *pvT,
                                                uint32_t base, uint32_t limit, uint32_t n, uint32_t nh, uint32_t lane,
-                                               RepState &st)
+                                               RepState &st, const uint32_t ringFrom = 0u, u64 *recG = nullptr)
 {
+    /* DEF: the deferred parse of one segment by one wave (qz_item, after the tile loop): the ring holds [ringFrom, ringFrom + kRing) — the 32 KiB
+     * "quarter" of the block the segment lies in — so a repeat source is near when it lies at or behind ringFrom, whatever its offset; the chosen
+     * matches go out as 8-byte records (rep_record) to recG[st.nseq], st.nseq counting the matches of the segment */
     /* the span lies inside one tile, a tile inside one segment: both are fixed for the call.  No match — a repeat neither —
      * starts in the last hashBytes - 1 positions of a segment (oracle: qzo_parse_rep, startEnd): the cursor a segment leaves
      * there moves on to the next segment's first position */
@@ -590,7 +614,8 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
         uint32_t wd = 0;
         if (lane < V) wd = pvT[st.cur + lane - base]; /* the candidate of the window position: gain | offset << 10 */
         u64 M1, M2;
-        if (st.rep1 <= src.nearLimit && st.rep2 <= src.nearLimit) { /* the usual case: both sources inside the ring */
+        if (DEF ? (st.cur - st.rep1 >= ringFrom && st.cur - st.rep2 >= ringFrom)
+                : (st.rep1 <= src.nearLimit && st.rep2 <= src.nearLimit)) { /* the usual case: both sources inside the ring */
             /* 64 bytes from each of the three ring offsets: what runs over the ring's end is in the mirror (kMirror >= 64) */
             const uint32_t t1 = rc - st.rep1, t2 = rc - st.rep2; /* offsets never reach before the block */
             const uint32_t r1 = t1 & kRingMask, r2 = t2 & kRingMask;
@@ -599,8 +624,8 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
             M1 = st.rep1 ? __ballot(A == B1) & in : 0ull;
             M2 = st.rep2 ? __ballot(A == B2) & in : 0ull;
         } else {
-            M1 = rep_bitmap(src, st.cur, st.rep1, segEnd, lane);
-            M2 = rep_bitmap(src, st.cur, st.rep2, segEnd, lane);
+            M1 = rep_bitmap(src, st.cur, st.rep1, segEnd, lane, ringFrom);
+            M2 = rep_bitmap(src, st.cur, st.rep2, segEnd, lane, ringFrom);
         }
         /* run of ones from bit `lane`, counted up to the cap: lanes < 18 always have 32 bits of look-ahead in the low
          * word of the shifted bitmap (funnel shift), ffbl of an all-ones word gives -1 -> the cap */
@@ -638,10 +663,13 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
             L = rdlane(rl1, ks);
             from = kRepCap;
         }
-        if (L == from) L = extend_match(src, q, off, from, umin(segEnd, ((q >> pf.extLog) + 2u) << pf.extLog), lane);
-        /* record, branch-free: the three parse-word slots at the start of the match (all behind the new cursor,
-         * L >= 3) become {chosen | offset, length | index in tile, literal anchor} for the emitting wave */
-        if (lane == 0u) {
+        if (L == from) L = extend_match_from(src, q, off, from, umin(segEnd, ((q >> pf.extLog) + 2u) << pf.extLog), lane,
+                                             DEF ? q - off < ringFrom : off > src.nearLimit);
+        if (DEF) {
+            if (lane == 0u) recG[st.nseq] = rep_record(q, off, L, q - st.anchor);
+        } else if (lane == 0u) {
+            /* record, branch-free: the three parse-word slots at the start of the match (all behind the new cursor,
+             * L >= 3) become {chosen | offset, length | index in tile, literal anchor} for the emitting wave */
             uint32_t *r = pvT + (q - base);
             r[0] = kChosenBit | off;
             r[1] = L | ((st.nseq - st.tileSeq) << 17);
@@ -861,10 +889,20 @@ constexpr uint32_t kSvcTabStride = 5888u; /* words per published head table (the
  * count including the delimiter or QZSTD_HIP_NSEQ_ERROR (every thread returns that for an item that is refused); the matcher
  * waves return 0.  Both kernels below are thin shells around it: one launch = one item per workgroup
  * (qzstd_find_sequences_kernel), or a resident worker that takes items from a queue (qzstd_service_worker). */
-template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS, bool NEAR>
+template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS, bool NEAR, bool DEFER = false>
 __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_hip_block_t &blk, const uint8_t *gsrc, uint4 *out,
                                             uint4 *chainB, uint32_t *p1B, const HistShare hsh)
 {
+    /* DEFER (round 6, the launch kernels of the repeat-aware parse): THE PARSE IS TAKEN OUT OF THE TILE LOOP.  The repeat-aware parse is a serial
+     * state machine (cursor, two repeat offsets) — in the loop, one wave walks it while eight matcher waves wait 80 % of the time (65 ms per GiB at
+     * level 1 | repcodes against 12 without).  But by definition the parse of a 4 KiB SEGMENT depends on nothing before the segment (no match
+     * crosses a boundary, the repeat offsets are forgotten there: what lets the resident service cut a block into 32 items), and the candidates
+     * do not depend on the parse at all.  So: the tile loop only matches — every position's parse word goes to device memory (p1B: 4 B per
+     * position; the chain levels' dense first-link array, which a launch only uses before the loop) — and AFTERWARDS the block is parsed 32 KiB
+     * "quarter" by quarter: the quarter's bytes are staged in the ring, EIGHT waves parse its eight segments at the same time (parse_rep_span<true>,
+     * a tile of parse words at a time through a private LDS window, 8-byte records back over the words), the segments' counts are summed, and every
+     * wave emits its own segment's records, one lane per sequence.  Same definition (oracle: qzo_parse_rep), same sequences. */
+    static_assert(!DEFER || REP, "only the repeat-aware parse is deferred");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -1391,19 +1429,19 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u, base = k << kTileLog;
                 uint32_t *pvT = pv + (k % kLagT) * kPvStride, *srecT = srec + (k % kLagT) * kWin * kSrecWords;
-                if (work) {
+                if (work && !DEFER) {
                     st.tileSeq = st.nseq;
                     if (lane == 0u) srecT[0] = st.nseq; /* the records carry indices relative to this */
-                    if (!(CHAIN && QZ_CHAIN_SHIFT)) parse_rep_span(pf, src, pvT, base, base + 64u * kSplit, n, nh, lane, st);
+                    if (!(CHAIN && QZ_CHAIN_SHIFT)) parse_rep_span<false>(pf, src, pvT, base, base + 64u * kSplit, n, nh, lane, st);
                 }
                 if (CHAIN && it == itBegin && it < nTiles) chain_insert_tile(pf, src, tbl, (it & 1u) ? P1odd : nearTab, it << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
                 QZ_PLAP(pW1)
-                if (work) parse_rep_span(pf, src, pvT, base, base + kTile, n, nh, lane, st);
+                if (work && !DEFER) parse_rep_span<false>(pf, src, pvT, base, base + kTile, n, nh, lane, st);
                 if (CHAIN && it + 1u < nTiles) chain_insert_tile(pf, src, tbl, ((it + 1u) & 1u) ? P1odd : nearTab, (it + 1u) << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI2)
-                __syncthreads(); /* B2 */
+                if (DEFER && !CHAIN) QZ_BARRIER_LDS(); else __syncthreads(); /* B2 */
                 QZ_PLAP(pW2)
             }
             nseqEnd = st.nseq;
@@ -1439,13 +1477,16 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         if (lane == 0 && !(blk.mark & QZSTD_HIP_MARK_COMPACT)) out[blk.seqCap - 2u] = make_uint4((uint32_t)pI1, (uint32_t)pW1, (uint32_t)pI2, (uint32_t)pW2);
         if (lane == 0 && !(blk.mark & QZSTD_HIP_MARK_COMPACT)) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID: where the wave runs */
 #endif
+        if constexpr (!DEFER) {
         /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
         uint32_t count = nseqEnd + 1u;
         if (lane == 0 && nseqEnd < blk.seqCap) store_entry(out, nseqEnd, 0u, n - anchorEnd, 0u, blk.mark);
         if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
         return count;
+        }
     }
 
+    if (matcher) {
     /* ---------------- the 8 matcher waves ---------------- */
 #ifdef QZ_MATCH_PRIO_HI /* A/B: the issue arbiter prefers the OLDER waves of a SIMD — waves 4-7 of a workgroup reach every barrier last (r06_level1_wave_timing_before.txt);
                          * a raised priority for them evens that out */
@@ -1527,7 +1568,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             nx = capped ? kNxCapped : nx;
             /* REP: the hash gain (0 = no usable candidate; 4 len + 32 - bits(offset) < 1024) | offset << 10; bit 31 stays clear */
             const uint32_t gRep = take ? 4u * cl + 32u - (31u - (uint32_t)__builtin_clz(off + 1u)) : 0u;
-            pv[(tileIdx % kLagT) * kPvStride + tid] = REP ? (gRep | (off << 10)) : pack_pos(nx, ns, capped ? off : cl);
+            if (DEFER) p1B[(tileIdx << kTileLog) + tid] = gRep | (off << 10);
+            else pv[(tileIdx % kLagT) * kPvStride + tid] = REP ? (gRep | (off << 10)) : pack_pos(nx, ns, capped ? off : cl);
     };
     /* kShift: what interval 2 of an iteration leaves for interval 1 of the next — the candidates' offsets and head lengths (0 = none), which of
      * them matched all 16 bytes of the head and go on ("need"), the cap, and the 36 bytes behind the position's head (dwords 4-12 of `own`) */
@@ -1583,7 +1625,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         const uint32_t fpos = t0 + kLook + (tid - 64u) * 16u; /* iteration it stages [t0 + kLook, t0 + kLook + kTile) */
         const bool refill = wave == 1u && it >= 1u && lane < kTile / 16u && fpos < nPad;
         if (refill) fresh = g128[fpos >> 4];
-        if (it >= kLagT + firstTile && !QZ_ABLATED(8u)) /* emit(it - kLagT): needs the parse of that tile (lock-step: done in interval 2 of it-1; decoupled: before the parse wave let B2 of it-1 go) */
+        if (!DEFER && it >= kLagT + firstTile && !QZ_ABLATED(8u)) /* emit(it - kLagT): needs the parse of that tile (lock-step: done in interval 2 of it-1; decoupled: before the parse wave let B2 of it-1 go) */
             emit_window<REP>(pf, src, srec + ((it % kLagT) * kWin + wave) * kSrecWords, pv + (it % kLagT) * kPvStride + 64u * wave,
                              offH[kEmitIdx], lenH[kEmitIdx], t0 - kLagT * kTile + 64u * wave, ring_back(rp, kLagT * kTile), lane, out, blk.seqCap,
                              REP ? srec[(it % kLagT) * kWin * kSrecWords] : 0u, blk.mark);
@@ -2019,18 +2061,115 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                        * (to PINNED HOST memory in the product paths) either; the chain levels keep the full barrier: chain entries */
         if (CHAIN) __syncthreads(); else QZ_BARRIER_LDS(); /* B2 */
 #else
-        __syncthreads(); /* B2 */
+        /* (DEFER below the chain levels: the parse words just stored are read after the loop — the barrier need not wait for them) */
+        if (DEFER && !CHAIN) QZ_BARRIER_LDS(); else __syncthreads(); /* B2 */
 #endif
         QZ_LAP(dW2)
     }
 #ifdef QZ_DEBUG_DUMP
-    if (blk.mark & QZSTD_HIP_MARK_COMPACT) return 0u; /* (the cycle counts are dumped behind 16-byte entries only) */
+    if (!(blk.mark & QZSTD_HIP_MARK_COMPACT)) { /* (the cycle counts are dumped behind 16-byte entries only) */
     if (lane == 0) out[blk.seqCap - 3u - wave] = make_uint4((uint32_t)dI1, (uint32_t)dW1, (uint32_t)dI2, (uint32_t)dW2);
     if (lane == 0) out[blk.seqCap - 24u - 2u * wave] = make_uint4((uint32_t)(dC[0] >> 4), (uint32_t)(dC[1] >> 4), (uint32_t)(dC[2] >> 4), (uint32_t)(dC[3] >> 4));
     if (lane == 0) out[blk.seqCap - 25u - 2u * wave] = make_uint4((uint32_t)(dC[4] >> 4), (uint32_t)dC[5], 0u, 0u);
     if (lane == 0) out[blk.seqCap - 12u - wave] = make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), 0u, 0u, 0u); /* HW_ID */
+    }
 #endif
-    return 0u;
+    if constexpr (!DEFER) return 0u;
+    } /* matcher */
+
+    /* ---------------- DEFER: the parse and the emission, quarter by quarter (all nine waves arrive here) ---------------- */
+    if constexpr (DEFER) {
+        constexpr uint32_t kSegLog = 12u, kSeg = 1u << kSegLog, kSegsPerQ = kRing >> kSegLog; /* the launcher only starts these kernels with profile.segLog == 12 */
+        static_assert(kSegsPerQ == (uint32_t)kMatchWaves, "one wave per segment of a quarter");
+        constexpr uint32_t kNoAnchor = 0xFFFFFFFFu;
+        __syncthreads(); /* every wave's parse words are stored (the loop's last barriers may have ordered LDS only); ring and tables are free */
+        uint32_t *pvW = tbl + wave * kPvStride; /* this wave's window of parse words: one tile (the head table's LDS: 8 x 520 words <= 5888) */
+        uint32_t *ctl = srec;                   /* [0, 8) the segments' counts, [8, 16) the end of their last match (kNoAnchor: none) */
+        const uint32_t firstSeg = blk.parseFrom >> kSegLog, nSegs = (nh + kSeg - 1u) >> kSegLog; /* segments that hold a hashable position */
+        uint32_t total = 0u, anchorCarry = blk.parseFrom; /* sequences emitted so far; where the pending literals start */
+        for (uint32_t Q = firstSeg / kSegsPerQ; Q * kSegsPerQ < nSegs; Q++) {
+            const uint32_t qs = Q * kRing;
+            /* the quarter's bytes into the ring: position x at x mod kRing, as in the tile loop (what a 64-byte read finds behind the ring's end
+             * belongs to the next segment and is masked) */
+            for (uint32_t o = qs + tid * 16u; o < umin(qs + kRing, nPad); o += (uint32_t)kThreads * 16u) {
+                const uint4 v = g128[o >> 4];
+                ring128[(o & kRingMask) >> 4] = v;
+                if ((o & kRingMask) < kMirror) ring128[(kRing + (o & kRingMask)) >> 4] = v; /* (the emission's four bytes before a position may wrap) */
+            }
+            __syncthreads();
+            const uint32_t sg = Q * kSegsPerQ + wave; /* this wave's segment */
+            const uint32_t segStart = sg << kSegLog;
+            u64 *recG = reinterpret_cast<u64 *>(p1B + segStart);
+            if (matcher) {
+                uint32_t cnt = 0u, endA = kNoAnchor;
+                if (sg >= firstSeg && sg < nSegs) {
+                    RepState st = { segStart, segStart, 0u, 0u, 0u, 0u, sg };
+                    const uint32_t tEnd = umin(segStart + kSeg, nTiles << kTileLog);
+                    uint32_t nxt[kWin];
+#pragma unroll
+                    for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[segStart + 64u * j + lane];
+                    for (uint32_t base = segStart; base < tEnd; base += kTile) {
+#pragma unroll
+                        for (uint32_t j = 0; j < kWin; j++) pvW[64u * j + lane] = nxt[j];
+                        if (base + kTile < tEnd) { /* the next tile's words: in flight while this one is parsed */
+#pragma unroll
+                            for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[base + kTile + 64u * j + lane];
+                        }
+                        parse_rep_span<true>(pf, src, pvW, base, base + kTile, n, nh, lane, st, qs, recG);
+                    }
+                    cnt = st.nseq;
+                    if (cnt) endA = st.anchor;
+                }
+                if (lane == 0u) { ctl[wave] = cnt; ctl[kSegsPerQ + wave] = endA; }
+            }
+            __syncthreads(); /* counts in LDS; every wave's records are stored (it reads them back itself) */
+            {
+                const uint32_t cv = lane < 2u * kSegsPerQ ? ctl[lane] : 0u;
+                uint32_t before = 0u, all = 0u, anchorIn = anchorCarry, anchorOut = anchorCarry;
+#pragma unroll
+                for (uint32_t j = 0; j < kSegsPerQ; j++) {
+                    const uint32_t c = rdlane(cv, j), a = rdlane(cv, kSegsPerQ + j);
+                    if (j < wave) { before += c; if (a != kNoAnchor) anchorIn = a; }
+                    all += c;
+                    if (a != kNoAnchor) anchorOut = a;
+                }
+                if (matcher) {
+                    const uint32_t cnt = rdlane(cv, wave);
+                    for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
+                        const uint32_t k = k0 + lane;
+                        if (k < cnt) {
+                            const u64 r = recG[k];
+                            const uint32_t pm = (uint32_t)r & 0x1FFFFu, off = (uint32_t)(r >> 17) & 0x1FFFFu, len = (uint32_t)(r >> 34) & 0x1FFFu;
+                            const uint32_t lit = k ? (uint32_t)(r >> 47) & 0x1FFFu : pm - anchorIn; /* the segment's first match: literals since the last match of any segment before */
+                            const uint32_t q = pm - off;
+                            const uint32_t maxb = umin(umin(umin(pf.backExt, lit), q), pm & (kSeg - 1u));
+                            uint32_t b = 0;
+                            if (maxb) { /* as emit_window: the 4 bytes before the match and before its source, top byte = nearest */
+                                const uint32_t pb = rd32u(src, pm - 4u, false);
+                                uint32_t qb;
+                                if (q < qs + 4u) qb = q >= 4u ? rd32u(src, q - 4u, true) : rd32u(src, 0u, true) << (8u * (4u - q)); /* the source's bytes lie before the quarter */
+                                else qb = rd32u(src, q - 4u, false);
+                                const uint32_t x = pb ^ qb;
+                                b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
+                            }
+                            const uint32_t idx = total + before + k;
+                            if (idx < blk.seqCap) store_entry(out, idx, off, lit - b, len + b, blk.mark);
+                        }
+                    }
+                }
+                total += all;
+                anchorCarry = anchorOut;
+            }
+            __syncthreads(); /* the ring and the control words are rewritten by the next quarter */
+        }
+        if (matcher) return 0u;
+        /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
+        uint32_t count = total + 1u;
+        if (lane == 0 && total < blk.seqCap) store_entry(out, total, 0u, n - anchorCarry, 0u, blk.mark);
+        if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
+        return count;
+    }
+    return 0u; /* (not reached) */
 }
 
 /* one launch, one work item per workgroup (the batch paths) */
@@ -2047,9 +2186,11 @@ template <bool HAS_LONG, bool REP, bool CHAIN, bool TURNS, bool NEAR>
 __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_kernel(LaunchArgs args)
 {
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
-    const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS, NEAR>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
+    /* the launch kernels parse repeat-aware levels AFTER the tile loop (qz_item: DEFER): the parse words go to the dense 4-byte array of the block's
+     * scratch region — behind the chain entries at the chain levels (chainEntries), the whole region below them */
+    const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS, NEAR, REP && (QZ_REP_DEFER > 1 || (QZ_REP_DEFER == 1 && !CHAIN))>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
                                                                 CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr,
-                                                                CHAIN ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
+                                                                (CHAIN || REP) ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
                                                                 HistShare{ nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr, nullptr });
     /* The count is the host's flag when the result area is pinned host memory (announcements: host/qatseqprod.c polls the count words instead
      * of asking the runtime about the stream — a stream query waits for whatever else shares the stream's hardware queue): every wave's result
@@ -2910,7 +3051,13 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         a.chain = static_cast<uint4 *>(d_work);
         a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
         a.chainEntries = (uint32_t)(need / nBlocks / (4u * QZSTD_HIP_CHAIN_ENTRY_LINKS + 4u)) * kEQ;
+    } else if (a.prof.repWin) { /* the deferred repeat-aware parse below the chain levels: one parse word (4 B) per position */
+        const size_t need = qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen);
+        if (!d_work || workBytes < need || need == 0) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
+        a.chain = static_cast<uint4 *>(d_work);
+        a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
     }
+    if (a.prof.repWin && a.prof.segLog != 12u) return fail_msg("qzstd_hip_find_sequences: unsupported profile (the repeat-aware parse of a launch works on 4 KiB segments)");
     a.src = static_cast<const uint8_t *>(d_src);
     a.blocks = d_blocks;
     a.seqs = static_cast<uint4 *>(d_seqs);
