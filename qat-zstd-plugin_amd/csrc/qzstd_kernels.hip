@@ -64,6 +64,9 @@
                         * per GiB, config 4's shape 105.7 -> 107.8): the chain walk takes longer than the parse wave's serial chain, which the lock-step loop
                         * hides completely, so deferring it only adds the parse's own time */
 #endif
+#ifndef QZ_PLAIN_DEFER
+#define QZ_PLAIN_DEFER 1 /* the launch kernels of levels 1-4 defer their plain parse and their emission in the same way (csrc/qzstd_profile.c must agree: the workspace) */
+#endif
 #ifndef QZ_CHAIN_SHIFT
 #define QZ_CHAIN_SHIFT 1 /* chain levels: a tile's start flags are written in the next iteration's first interval (A/B: 0) */
 #endif
@@ -902,7 +905,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
      * "quarter" by quarter: the quarter's bytes are staged in the ring, EIGHT waves parse its eight segments at the same time (parse_rep_span<true>,
      * a tile of parse words at a time through a private LDS window, 8-byte records back over the words), the segments' counts are summed, and every
      * wave emits its own segment's records, one lane per sequence.  Same definition (oracle: qzo_parse_rep), same sequences. */
-    static_assert(!DEFER || REP, "only the repeat-aware parse is deferred");
+    static_assert(!DEFER || !CHAIN || REP, "at the chain levels only the repeat-aware parse can be deferred");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -1451,14 +1454,14 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u;
-                if (work && !(CHAIN && QZ_CHAIN_SHIFT))
+                if (work && !DEFER && !(CHAIN && QZ_CHAIN_SHIFT))
                     parse_tile<0, kSplit>(pf, src, pv + (k % kLagT) * kPvStride, srec + (k % kLagT) * kWin * kSrecWords,
                                           k << kTileLog, n, lane, st);
                 if (CHAIN && it == itBegin && it < nTiles) chain_insert_tile(pf, src, tbl, (it & 1u) ? P1odd : nearTab, it << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
                 QZ_PLAP(pW1)
-                if (work) {
+                if (work && !DEFER) {
                     if (CHAIN && QZ_CHAIN_SHIFT)
                         parse_tile<0, kWin>(pf, src, pv + (k % kLagT) * kPvStride, srec + (k % kLagT) * kWin * kSrecWords, k << kTileLog, n, lane, st);
                     else
@@ -1467,7 +1470,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 }
                 if (CHAIN && it + 1u < nTiles) chain_insert_tile(pf, src, tbl, ((it + 1u) & 1u) ? P1odd : nearTab, (it + 1u) << kTileLog, n, nh, lane, args.orderedLds != 0u);
                 QZ_PLAP(pI2)
-                __syncthreads(); /* B2 */
+                if (DEFER && !CHAIN) QZ_BARRIER_LDS(); else __syncthreads(); /* B2 */
                 QZ_PLAP(pW2)
             }
             nseqEnd = st.nseq;
@@ -1552,6 +1555,11 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 defer3 = pf.lazy >= 3u && lane < 61u && tl3 > cl + 2u; /* three on: longer by more than two */
             }
             const bool start = take && !defer1 && !defer2 && !defer3;
+            if constexpr (DEFER && !REP) {
+                /* the deferred plain parse (after the tile loop) works from the start flag, the capped length and the offset of every position */
+                p1B[(tileIdx << kTileLog) + tid] = off | (cl << 17) | (start ? kChosenBit : 0u);
+                return;
+            }
             const u64 startMask = __ballot(start);
             /* what the parse wave needs, one word per position (see parse_tile) */
             /* ns = the first start at/after this lane: the starts below the lane masked off word by word (a 64-bit shift by the
@@ -2102,25 +2110,82 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             u64 *recG = reinterpret_cast<u64 *>(p1B + segStart);
             if (matcher) {
                 uint32_t cnt = 0u, endA = kNoAnchor;
+#ifndef QZ_DEFER_PRIO
+#define QZ_DEFER_PRIO 0 /* A/B: the priority of the parsing waves (a serial chain each) against the other workgroup's matcher waves on their SIMDs */
+#endif
+                if (QZ_DEFER_PRIO) __builtin_amdgcn_s_setprio(QZ_DEFER_PRIO);
+#ifdef QZ_EXP_NOPARSE /* timing experiment only (no sequences): what the tile loop of a deferring kernel takes without its parse */
+                if (false) {
+#else
                 if (sg >= firstSeg && sg < nSegs) {
-                    RepState st = { segStart, segStart, 0u, 0u, 0u, 0u, sg };
+#endif
                     const uint32_t tEnd = umin(segStart + kSeg, nTiles << kTileLog);
                     uint32_t nxt[kWin];
 #pragma unroll
                     for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[segStart + 64u * j + lane];
-                    for (uint32_t base = segStart; base < tEnd; base += kTile) {
+                    if constexpr (REP) {
+                        RepState st = { segStart, segStart, 0u, 0u, 0u, 0u, sg };
+                        for (uint32_t base = segStart; base < tEnd; base += kTile) {
 #pragma unroll
-                        for (uint32_t j = 0; j < kWin; j++) pvW[64u * j + lane] = nxt[j];
-                        if (base + kTile < tEnd) { /* the next tile's words: in flight while this one is parsed */
+                            for (uint32_t j = 0; j < kWin; j++) pvW[64u * j + lane] = nxt[j];
+                            if (base + kTile < tEnd) { /* the next tile's words: in flight while this one is parsed */
 #pragma unroll
-                            for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[base + kTile + 64u * j + lane];
+                                for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[base + kTile + 64u * j + lane];
+                            }
+                            parse_rep_span<true>(pf, src, pvW, base, base + kTile, n, nh, lane, st, qs, recG);
                         }
-                        parse_rep_span<true>(pf, src, pvW, base, base + kTile, n, nh, lane, st, qs, recG);
+                        cnt = st.nseq;
+                        if (cnt) endA = st.anchor;
+                    } else {
+                        /* The plain (lazy) greedy parse of the segment (oracle: the loop of qzo_find_sequences_from): window by window — lane = position —
+                         * the start flags of a window are one ballot, the chase is scalar (first start at / behind the cursor, jump by its length; a
+                         * candidate that hit the cap is extended when it is taken), and the lanes of the chosen starts store their records
+                         * {position, offset, length} at once, ranked by the chosen lanes below them. */
+                        uint32_t cur = segStart;
+                        for (uint32_t base = segStart; base < tEnd; base += kTile) {
+                            uint32_t wds[kWin];
+#pragma unroll
+                            for (uint32_t j = 0; j < kWin; j++) wds[j] = nxt[j];
+                            if (base + kTile < tEnd) { /* the next tile's words: in flight while this one is parsed */
+#pragma unroll
+                                for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[base + kTile + 64u * j + lane];
+                            }
+#pragma unroll
+                            for (uint32_t w = 0; w < kWin; w++) {
+                                const uint32_t w0 = base + 64u * w;
+                                const u64 sm = __ballot((wds[w] & kChosenBit) != 0u);
+                                uint32_t c = cur - w0; /* the cursor never lies before the window */
+                                if (c < 64u) {
+                                    uint32_t len = (wds[w] >> 17) & 63u;
+                                    u64 chosen = 0ull;
+                                    for (;;) {
+                                        const u64 m = (sm >> c) << c;
+                                        if (!m) { c = 64u; break; } /* no start left in the window: the cursor walks on */
+                                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                                        uint32_t L = rdlane(len, j);
+                                        if (__builtin_expect(L == pf.capLen, 0)) { /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
+                                            const uint32_t pj = w0 + j, offj = rdlane(wds[w], j) & 0x1FFFFu;
+                                            L = extend_match_from(src, pj, offj, pf.capLen, umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog), lane, pj - offj < qs);
+                                            if (lane == j) len = L;
+                                        }
+                                        chosen |= 1ull << j;
+                                        c = j + L;
+                                        endA = w0 + c;
+                                        if (c >= 64u) break;
+                                    }
+                                    cur = w0 + c;
+                                    if (chosen) {
+                                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u));
+                                        if ((chosen >> lane) & 1ull) recG[cnt + rank] = rep_record(w0 + lane, wds[w] & 0x1FFFFu, len, 0u);
+                                        cnt += (uint32_t)__popcll(chosen);
+                                    }
+                                }
+                            }
+                        }
                     }
-                    cnt = st.nseq;
-                    if (cnt) endA = st.anchor;
                 }
                 if (lane == 0u) { ctl[wave] = cnt; ctl[kSegsPerQ + wave] = endA; }
+                if (QZ_DEFER_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads(); /* counts in LDS; every wave's records are stored (it reads them back itself) */
             {
@@ -2140,7 +2205,11 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         if (k < cnt) {
                             const u64 r = recG[k];
                             const uint32_t pm = (uint32_t)r & 0x1FFFFu, off = (uint32_t)(r >> 17) & 0x1FFFFu, len = (uint32_t)(r >> 34) & 0x1FFFu;
-                            const uint32_t lit = k ? (uint32_t)(r >> 47) & 0x1FFFu : pm - anchorIn; /* the segment's first match: literals since the last match of any segment before */
+                            uint32_t lit = pm - anchorIn; /* the segment's first match: literals since the last match of any segment before */
+                            if (k) {
+                                if constexpr (REP) lit = (uint32_t)(r >> 47) & 0x1FFFu;
+                                else { const u64 rb = recG[k - 1u]; lit = pm - (((uint32_t)rb & 0x1FFFFu) + ((uint32_t)(rb >> 34) & 0x1FFFu)); } /* behind the end of the match before */
+                            }
                             const uint32_t q = pm - off;
                             const uint32_t maxb = umin(umin(umin(pf.backExt, lit), q), pm & (kSeg - 1u));
                             uint32_t b = 0;
@@ -2188,9 +2257,10 @@ __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_ke
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     /* the launch kernels parse repeat-aware levels AFTER the tile loop (qz_item: DEFER): the parse words go to the dense 4-byte array of the block's
      * scratch region — behind the chain entries at the chain levels (chainEntries), the whole region below them */
-    const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS, NEAR, REP && (QZ_REP_DEFER > 1 || (QZ_REP_DEFER == 1 && !CHAIN))>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
+    constexpr bool kDefer = CHAIN ? (REP && QZ_REP_DEFER > 1) : (REP ? QZ_REP_DEFER != 0 : QZ_PLAIN_DEFER != 0);
+    const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS, NEAR, kDefer>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
                                                                 CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr,
-                                                                (CHAIN || REP) ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
+                                                                (CHAIN || kDefer) ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
                                                                 HistShare{ nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr, nullptr });
     /* The count is the host's flag when the result area is pinned host memory (announcements: host/qatseqprod.c polls the count words instead
      * of asking the runtime about the stream — a stream query waits for whatever else shares the stream's hardware queue): every wave's result
@@ -3051,13 +3121,13 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         a.chain = static_cast<uint4 *>(d_work);
         a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
         a.chainEntries = (uint32_t)(need / nBlocks / (4u * QZSTD_HIP_CHAIN_ENTRY_LINKS + 4u)) * kEQ;
-    } else if (a.prof.repWin) { /* the deferred repeat-aware parse below the chain levels: one parse word (4 B) per position */
+    } else if (a.prof.repWin ? QZ_REP_DEFER != 0 : QZ_PLAIN_DEFER != 0) { /* the deferred parse below the chain levels: one parse word (4 B) per position */
         const size_t need = qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen);
         if (!d_work || workBytes < need || need == 0) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
         a.chain = static_cast<uint4 *>(d_work);
         a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
     }
-    if (a.prof.repWin && a.prof.segLog != 12u) return fail_msg("qzstd_hip_find_sequences: unsupported profile (the repeat-aware parse of a launch works on 4 KiB segments)");
+    if (a.prof.segLog != 12u) return fail_msg("qzstd_hip_find_sequences: unsupported profile (the deferred parse of a launch works on 4 KiB segments)");
     a.src = static_cast<const uint8_t *>(d_src);
     a.blocks = d_blocks;
     a.seqs = static_cast<uint4 *>(d_seqs);

@@ -92,13 +92,19 @@ size_t qzstd_hip_sequence_bound(size_t srcSize)
 }
 
 /* device scratch of one launch: per position of every work item the chain entry of levels >= 5 (16 B, four links) and — for the
- * history pass of segment items and for the parse words of the repeat-aware levels (10-12), whose parse a launch runs after its tile loop —
- * a dense array of 4 B per position.  Below the chain levels only that array, and only with the repeat-aware parse (level | REPCODES). */
+ * history pass of segment items — a dense array of 4 B per position.  Below the chain levels only that array: the parse words of a launch,
+ * which parses after its tile loop (csrc/qzstd_kernels.hip: DEFER). */
 size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockLen)
 {
     qzstd_hip_profile_t p;
     if (maxBlockLen > QZSTD_HIP_BLOCK_MAX || qzstd_hip_profile_for_level(level, maxBlockLen, &p)) return 0;
-    if (!p.chainDepth) return p.repWin ? (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * 4u : 0;
+#ifndef QZ_PLAIN_DEFER
+#define QZ_PLAIN_DEFER 1 /* csrc/qzstd_kernels.hip must agree */
+#endif
+#ifndef QZ_REP_DEFER
+#define QZ_REP_DEFER 1
+#endif
+    if (!p.chainDepth) return (p.repWin ? QZ_REP_DEFER != 0 : QZ_PLAIN_DEFER != 0) ? (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * 4u : 0;
     return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * (4u * QZSTD_HIP_CHAIN_ENTRY_LINKS + 4u); /* a chain entry of QZSTD_HIP_CHAIN_ENTRY_LINKS links + the first link again, dense */
 }
 

@@ -1238,6 +1238,13 @@ static int qzSetupSlotService(QZSTD_Slot_T *sl)
  * Returns the count, the error code, or QZ_NOT_SERVED (no slot free right now, the level is not served, the service is
  * down or busy with another level): the caller then takes the launch path.
  */
+/* levels >= 5 (exact hash chains): their service requests carry a chain scratch (a launch's scratch is sized by qzstd_hip_workspace_bytes at every level) */
+static int qzIsChainLevel(int level)
+{
+    qzstd_hip_profile_t p;
+    return qzstd_hip_profile_for_level(level, QZSTD_HIP_BLOCK_MAX, &p) == 0 && p.chainDepth != 0;
+}
+
 static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs, size_t outSeqsCapacity, const void *src,
                              size_t srcSize, int level)
 {
@@ -1283,7 +1290,7 @@ static size_t qzServiceBlock(QZSTD_Session_T *s, int dev, ZSTD_Sequence *outSeqs
     rq.seqCapPerItem = (uint32_t)(QZ_SVC_ITEMS_MAX * QZ_SVC_ITEM_CAP / nItems); /* the slot's whole result area, shared out */
     rq.slot = (uint32_t)i; rq.epoch = sl->vEpoch;
     rq.dWork = NULL;
-    if (qzstd_hip_workspace_bytes(level, 1, QZSTD_HIP_BLOCK_MAX) != 0) { /* a chain level: every item links the block before it in its own scratch */
+    if (qzIsChainLevel(level)) { /* every item links the block before it in its own scratch */
         if (!sl->vdWork) sl->vdWork = qzstd_hip_malloc(sl->device, QZSTD_HIP_SVC_WORK_BYTES);
         if (!sl->vdWork) {
             memset(sl->vCount, 0xFF, nItems * sizeof(unsigned int));

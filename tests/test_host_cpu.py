@@ -89,15 +89,15 @@ def test_profile_tables_agree(plugin, oracle, level, block):
     assert plugin.profile(level, block).as_dict() == oracle.profile(level, block).as_dict()
 
 
-def test_workspace_only_for_chain_levels(plugin):
+def test_workspace_per_level(plugin):
     """levels >= 5 keep their hash chains in device memory: per position of every work item a chain entry of four links (16 B)
-    and a dense array of 4 B per position — the first links once more for the history pass of segment items, and the parse words of
-    the repeat-aware levels, whose parse a launch runs after its tile loop; below the chain levels only that array, and only with the
-    repeat-aware parse (level | QZSTD_HIP_LEVEL_REPCODES)"""
+    and a dense array of 4 B per position (the first links once more, for the history pass of segment items); below the chain
+    levels only that array: the parse words of a launch, which parses after its tile loop"""
     W = plugin.lib.qzstd_hip_workspace_bytes
     for level in range(1, 5):
-        assert W(level, 100, 131072) == 0 and plugin.profile(level, 131072).chainDepth == 0
-        assert W(level | 0x100, 100, 131072) == 100 * 131072 * 4 and W(level | 0x100, 3, 1000) == 3 * 1024 * 4
+        assert plugin.profile(level, 131072).chainDepth == 0
+        for lv in (level, level | 0x100):
+            assert W(lv, 100, 131072) == 100 * 131072 * 4 and W(lv, 3, 1000) == 3 * 1024 * 4
         assert plugin.profile(level, 131072).subTileLog == (6 if level == 2 else 0)
     for level in range(5, 13):
         assert plugin.profile(level, 131072).chainDepth in (8, 12, 32, 40, 64) and plugin.profile(level, 131072).subTileLog == 6

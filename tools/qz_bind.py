@@ -499,7 +499,7 @@ class ServiceLane:
             self.cnt[k] = 0
         self.epoch = self.epoch % 0xFFFFFF + 1
         work = None
-        if self.L.qzstd_hip_workspace_bytes(level, 1, self.BLOCK_MAX):
+        if self.plug.profile(level, self.BLOCK_MAX).chainDepth:  # a chain level: the request carries a chain scratch
             if not self.dwork:
                 self.dwork = self.L.qzstd_hip_malloc(self.device, self.BLOCK_MAX * (8 * 4 + 4) + 32 * 5888 * 4)  # QZSTD_HIP_SVC_WORK_BYTES: one scratch per request
                 assert self.dwork, self.plug.err()
