@@ -152,8 +152,10 @@ int qzstd_hip_memcpy2d_d2h(int device, void *stream, void *dst, size_t dpitch, c
  *             (what qatSequenceProducer returns, src/qatseqprod.c:1090,:1323), or
  *             QZSTD_HIP_NSEQ_ERROR when count >= seqCap-1 (src/qatseqprod.c:1318)
  *   d_work    device scratch of at least qzstd_hip_workspace_bytes(level, nBlocks, maxBlockLen)
- *             bytes, private to this launch until it completes (levels >= 6 keep their hash
- *             chains there; may be NULL when that size is 0)
+ *             bytes, private to this launch until it completes: REQUIRED AT EVERY LEVEL since
+ *             round 6 (levels >= 5 keep their hash chains there; below them a launch leaves one
+ *             parse word per position there and parses after its tile loop, eight 4 KiB segments
+ *             at a time: 4 bytes per position)
  *
  * One workgroup per block; block bytes, hash table and parse scratch live in LDS.
  */

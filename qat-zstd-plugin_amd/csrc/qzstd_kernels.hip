@@ -353,8 +353,10 @@ __device__ __forceinline__ uint32_t min_len(const qzstd_hip_profile_t &pf, uint3
 
 /* cooperative forward extension of a match that hit the candidate cap: 64 lanes x 16 bytes
  * (1 KiB) per step, never past `lim` */
+template <bool AFAR = false> /* AFAR: the ring does not hold the match itself either (the deferred plain parse): both sides from device memory */
 __device__ __forceinline__ uint32_t extend_match_from(const Src &s, uint32_t p, uint32_t off, uint32_t L, uint32_t lim,
-                                                      uint32_t lane, const bool far /* uniform: the whole match has one offset */)
+                                                      uint32_t lane, const bool far /* uniform: the whole match has one offset */,
+                                                      const uint32_t lastDw = 0xFFFFFFFFu /* AFAR: the last dword of the block's buffer that may be read */)
 {
     for (;;) {
         const uint32_t a = p + L + 16u * lane;
@@ -362,8 +364,17 @@ __device__ __forceinline__ uint32_t extend_match_from(const Src &s, uint32_t p, 
         if (a < lim) {
             const uint32_t b = a - off, as = a & 3u, bs = b & 3u;
             uint32_t A[5], B[5];
-            load_dw<5>(s, a, false, A);
-            load_dw<5>(s, b, far, B);
+            if constexpr (AFAR) { /* (a dword behind the buffer's end only holds bytes at or behind lim — on the source's side: bytes that face such bytes —
+                                   * and is never counted: clamped.  The ring-based callers only go to device memory for sources far before the block's end) */
+#pragma unroll
+                for (int i = 0; i < 5; i++) { A[i] = s.g[umin((a >> 2) + (uint32_t)i, lastDw)]; B[i] = s.g[umin((b >> 2) + (uint32_t)i, lastDw)]; }
+            } else {
+                load_dw<5>(s, a, false, A);
+                if (far) {
+#pragma unroll
+                    for (int i = 0; i < 5; i++) B[i] = s.g[umin((b >> 2) + (uint32_t)i, lastDw)];
+                } else load_dw<5>(s, b, false, B);
+            }
             ok = 16u;
 #pragma unroll
             for (int i = 3; i >= 0; i--) {
@@ -548,6 +559,7 @@ struct RepState {
     uint32_t seg;        /* the segment (profile.segLog) the repeat offsets were collected in */
 };
 constexpr uint32_t kRepCap = 32u, kRepMin = 3u;
+constexpr uint32_t kLenCapped = 127u; /* length field of a deferred plain parse word whose candidate hit the cap: >= 64, so the in-window chase ends on it */
 constexpr uint32_t kChosenBit = 0x80000000u; /* marks a parse-word slot rewritten into a chosen-match record */
 
 /* one byte of the block at position x: from the ring, or from HBM when `far` */
@@ -667,7 +679,8 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
             from = kRepCap;
         }
         if (L == from) L = extend_match_from(src, q, off, from, umin(segEnd, ((q >> pf.extLog) + 2u) << pf.extLog), lane,
-                                             DEF ? q - off < ringFrom : off > src.nearLimit);
+                                             DEF ? q - off < ringFrom : off > src.nearLimit,
+                                             DEF ? (((n + 15u) & ~15u) >> 2) - 1u : 0xFFFFFFFFu); /* (DEF: a "far" source may lie just before the match, at the buffer's end) */
         if (DEF) {
             if (lane == 0u) recG[st.nseq] = rep_record(q, off, L, q - st.anchor);
         } else if (lane == 0u) {
@@ -1557,7 +1570,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             const bool start = take && !defer1 && !defer2 && !defer3;
             if constexpr (DEFER && !REP) {
                 /* the deferred plain parse (after the tile loop) works from the start flag, the capped length and the offset of every position */
-                p1B[(tileIdx << kTileLog) + tid] = off | (cl << 17) | (start ? kChosenBit : 0u);
+                p1B[(tileIdx << kTileLog) + tid] = off | ((cl == pf.capLen ? kLenCapped : cl) << 17) | (start ? kChosenBit : 0u); /* offset 17 | length 7 | start flag */
                 return;
             }
             const u64 startMask = __ballot(start);
@@ -2085,8 +2098,133 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     if constexpr (!DEFER) return 0u;
     } /* matcher */
 
-    /* ---------------- DEFER: the parse and the emission, quarter by quarter (all nine waves arrive here) ---------------- */
-    if constexpr (DEFER) {
+    /* ---------------- DEFER, the plain parse (levels 1-4): every matcher wave parses every eighth segment, then emits their records ---------------- */
+    if constexpr (DEFER && !REP) {
+        constexpr uint32_t kSegLog = 12u, kSeg = 1u << kSegLog, kMaxSegs = QZSTD_HIP_BLOCK_MAX >> kSegLog; /* the launcher only starts these kernels with profile.segLog == 12 */
+        static_assert(kMaxSegs <= 64u, "one lane per segment in the prefix step");
+        constexpr uint32_t kNoAnchor = 0xFFFFFFFFu;
+        uint32_t *segCnt = srec, *segEndA = srec + kMaxSegs; /* [32] matches of a segment; the end of its last match (kNoAnchor: none) — srec + pv: 2 x 128 + 2 x 520 words */
+        const uint32_t firstSeg = blk.parseFrom >> kSegLog, nSegs = (nh + kSeg - 1u) >> kSegLog; /* segments that hold a hashable position */
+        __syncthreads(); /* every wave's parse words are stored (the loop's last barriers may have ordered LDS only) */
+        /* PASS 1.  The plain (lazy) greedy parse of a segment (oracle: the loop of qzo_find_sequences_from) depends on nothing before the segment: no match
+         * crosses a boundary, so the cursor enters every segment at its first position.  Window by window — lane = position — the start flags are one
+         * ballot, the chase is scalar (first start at / behind the cursor, jump by its length; a candidate that hit the cap carries kLenCapped, leaves
+         * the chase and is extended to its true, bounded end), and the lanes of the chosen starts store their records {position, offset, length} at
+         * once, ranked by the chosen lanes below them: record k over the words of the segment's positions 2k, 2k + 1 — behind the cursor. */
+        if (matcher) {
+            uint32_t nxt[kWin];
+            if (firstSeg + wave < nSegs) {
+#pragma unroll
+                for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[((firstSeg + wave) << kSegLog) + 64u * j + lane];
+            }
+            for (uint32_t sg = firstSeg + wave; sg < nSegs; sg += (uint32_t)kMatchWaves) {
+                const uint32_t segStart = sg << kSegLog;
+                u64 *recG = reinterpret_cast<u64 *>(p1B + segStart);
+                const uint32_t tEnd = umin(segStart + kSeg, nTiles << kTileLog);
+                uint32_t cnt = 0u, endA = kNoAnchor, cur = segStart;
+#ifndef QZ_EXP_NOPARSE /* (timing experiment only, no sequences: what the tile loop of a deferring kernel takes without its parse) */
+                for (uint32_t base = segStart; base < tEnd; base += kTile) {
+                    uint32_t wds[kWin];
+#pragma unroll
+                    for (uint32_t j = 0; j < kWin; j++) wds[j] = nxt[j];
+                    /* the next tile's words — of this segment, or the first of this wave's next one: in flight while this tile is parsed */
+                    const uint32_t nb = base + kTile < tEnd ? base + kTile : (sg + (uint32_t)kMatchWaves) << kSegLog;
+                    if (base + kTile < tEnd || sg + (uint32_t)kMatchWaves < nSegs) {
+#pragma unroll
+                        for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[nb + 64u * j + lane];
+                    }
+#pragma unroll
+                    for (uint32_t w = 0; w < kWin; w++) {
+                        const uint32_t w0 = base + 64u * w;
+                        const u64 sm = __ballot((wds[w] & kChosenBit) != 0u);
+                        uint32_t c = cur - w0; /* the cursor never lies before the window */
+                        if (c < 64u) {
+                            uint32_t lenF = (wds[w] >> 17) & 127u;
+                            u64 chosen = 0ull;
+                            uint32_t e = 0u, j = 0u, L = 0u; /* e: where the last match taken ends (relative to the window) */
+                            for (;;) {
+                                for (;;) {
+                                    const u64 m = (sm >> c) << c;
+                                    if (!m) { c = 64u; L = 0u; break; } /* no start left in the window: the cursor walks on */
+                                    j = (uint32_t)__builtin_ctzll(m);
+                                    L = rdlane(lenF, j);
+                                    chosen |= 1ull << j;
+                                    c = e = j + L;
+                                    if (c >= 64u) break;
+                                }
+                                if (__builtin_expect(L != kLenCapped, 1)) break;
+                                /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
+                                const uint32_t pj = w0 + j, offj = rdlane(wds[w], j) & 0x1FFFFu;
+                                L = extend_match_from<true>(src, pj, offj, pf.capLen, umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog), lane, true, (nPad >> 2) - 1u);
+                                if (lane == j) lenF = L;
+                                c = e = j + L;
+                                if (c >= 64u) break;
+                            }
+                            cur = w0 + c;
+                            if (chosen) {
+                                endA = w0 + e;
+                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u));
+                                if ((chosen >> lane) & 1ull) recG[cnt + rank] = rep_record(w0 + lane, wds[w] & 0x1FFFFu, lenF, 0u);
+                                cnt += (uint32_t)__popcll(chosen);
+                            }
+                        }
+                    }
+                }
+#endif
+                if (lane == 0u) { segCnt[sg] = cnt; segEndA[sg] = endA; }
+            }
+        }
+        __syncthreads(); /* the segments' counts; every wave's records are stored */
+        /* the segments' first indices and the literal anchors they start from: one lane per segment, two scans */
+        const bool mine = lane >= firstSeg && lane < nSegs;
+        const uint32_t cv = mine ? segCnt[lane] : 0u, ev = mine ? segEndA[lane] : kNoAnchor;
+        uint32_t incl = cv, last = ev; /* inclusive: matches up to and including the lane's segment; the end of the last match up to and including it */
+#pragma unroll
+        for (uint32_t d = 1; d < kMaxSegs; d <<= 1) {
+            const uint32_t ci = (uint32_t)__shfl_up((int)incl, d), li = (uint32_t)__shfl_up((int)last, d);
+            if (lane >= d) { incl += ci; if (last == kNoAnchor) last = li; }
+        }
+        const uint32_t total = rdlane(incl, kMaxSegs - 1u), lastAll = rdlane(last, kMaxSegs - 1u);
+        const uint32_t anchorEndAll = lastAll == kNoAnchor ? blk.parseFrom : lastAll;
+        /* PASS 2: the records of a segment, one lane per sequence (the four bytes before a match and before its source come from device memory) */
+        if (matcher) {
+            for (uint32_t sg = firstSeg + wave; sg < nSegs; sg += (uint32_t)kMatchWaves) {
+                const u64 *recG = reinterpret_cast<const u64 *>(p1B + (sg << kSegLog));
+                const uint32_t cnt = rdlane(cv, sg), first = rdlane(incl, sg) - cnt;
+                uint32_t anchorIn = blk.parseFrom; /* literals pending when the segment starts: behind the last match of any segment before it */
+                if (sg > 0u) { const uint32_t a = rdlane(last, sg - 1u); if (a != kNoAnchor) anchorIn = a; }
+                for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
+                    const uint32_t k = k0 + lane;
+                    if (k < cnt) {
+                        const u64 r = recG[k];
+                        const uint32_t pm = (uint32_t)r & 0x1FFFFu, off = (uint32_t)(r >> 17) & 0x1FFFFu, len = (uint32_t)(r >> 34) & 0x1FFFu;
+                        uint32_t lit = pm - anchorIn;
+                        if (k) { const u64 rp1 = recG[k - 1u]; lit = pm - (((uint32_t)rp1 & 0x1FFFFu) + ((uint32_t)(rp1 >> 34) & 0x1FFFu)); } /* behind the end of the match before */
+                        const uint32_t q = pm - off;
+                        const uint32_t maxb = umin(umin(umin(pf.backExt, lit), q), pm & (kSeg - 1u));
+                        uint32_t b = 0;
+                        if (maxb) { /* as emit_window: the 4 bytes before the match and before its source, top byte = nearest; never counted beyond maxb <= q < pm */
+                            const uint32_t pb = pm >= 4u ? rd32u(src, pm - 4u, true) : rd32u(src, 0u, true) << (8u * (4u - pm));
+                            const uint32_t qb = q >= 4u ? rd32u(src, q - 4u, true) : rd32u(src, 0u, true) << (8u * (4u - q));
+                            const uint32_t x = pb ^ qb;
+                            b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
+                        }
+                        const uint32_t idx = first + k;
+                        if (idx < blk.seqCap) store_entry(out, idx, off, lit - b, len + b, blk.mark);
+                    }
+                }
+            }
+            return 0u;
+        }
+        /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
+        uint32_t count = total + 1u;
+        if (lane == 0 && total < blk.seqCap) store_entry(out, total, 0u, n - anchorEndAll, 0u, blk.mark);
+        if (count >= blk.seqCap - 1u) count = QZSTD_HIP_NSEQ_ERROR; /* src/qatseqprod.c:1318 */
+        return count;
+    }
+
+    /* ---------------- DEFER, the repeat-aware parse: the parse and the emission, quarter by quarter (all nine waves arrive here) ---------------- */
+    if constexpr (DEFER && REP) {
         constexpr uint32_t kSegLog = 12u, kSeg = 1u << kSegLog, kSegsPerQ = kRing >> kSegLog; /* the launcher only starts these kernels with profile.segLog == 12 */
         static_assert(kSegsPerQ == (uint32_t)kMatchWaves, "one wave per segment of a quarter");
         constexpr uint32_t kNoAnchor = 0xFFFFFFFFu;
@@ -2123,7 +2261,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     uint32_t nxt[kWin];
 #pragma unroll
                     for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[segStart + 64u * j + lane];
-                    if constexpr (REP) {
+                    {
                         RepState st = { segStart, segStart, 0u, 0u, 0u, 0u, sg };
                         for (uint32_t base = segStart; base < tEnd; base += kTile) {
 #pragma unroll
@@ -2136,52 +2274,6 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         }
                         cnt = st.nseq;
                         if (cnt) endA = st.anchor;
-                    } else {
-                        /* The plain (lazy) greedy parse of the segment (oracle: the loop of qzo_find_sequences_from): window by window — lane = position —
-                         * the start flags of a window are one ballot, the chase is scalar (first start at / behind the cursor, jump by its length; a
-                         * candidate that hit the cap is extended when it is taken), and the lanes of the chosen starts store their records
-                         * {position, offset, length} at once, ranked by the chosen lanes below them. */
-                        uint32_t cur = segStart;
-                        for (uint32_t base = segStart; base < tEnd; base += kTile) {
-                            uint32_t wds[kWin];
-#pragma unroll
-                            for (uint32_t j = 0; j < kWin; j++) wds[j] = nxt[j];
-                            if (base + kTile < tEnd) { /* the next tile's words: in flight while this one is parsed */
-#pragma unroll
-                                for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[base + kTile + 64u * j + lane];
-                            }
-#pragma unroll
-                            for (uint32_t w = 0; w < kWin; w++) {
-                                const uint32_t w0 = base + 64u * w;
-                                const u64 sm = __ballot((wds[w] & kChosenBit) != 0u);
-                                uint32_t c = cur - w0; /* the cursor never lies before the window */
-                                if (c < 64u) {
-                                    uint32_t len = (wds[w] >> 17) & 63u;
-                                    u64 chosen = 0ull;
-                                    for (;;) {
-                                        const u64 m = (sm >> c) << c;
-                                        if (!m) { c = 64u; break; } /* no start left in the window: the cursor walks on */
-                                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                                        uint32_t L = rdlane(len, j);
-                                        if (__builtin_expect(L == pf.capLen, 0)) { /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
-                                            const uint32_t pj = w0 + j, offj = rdlane(wds[w], j) & 0x1FFFFu;
-                                            L = extend_match_from(src, pj, offj, pf.capLen, umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog), lane, pj - offj < qs);
-                                            if (lane == j) len = L;
-                                        }
-                                        chosen |= 1ull << j;
-                                        c = j + L;
-                                        endA = w0 + c;
-                                        if (c >= 64u) break;
-                                    }
-                                    cur = w0 + c;
-                                    if (chosen) {
-                                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u));
-                                        if ((chosen >> lane) & 1ull) recG[cnt + rank] = rep_record(w0 + lane, wds[w] & 0x1FFFFu, len, 0u);
-                                        cnt += (uint32_t)__popcll(chosen);
-                                    }
-                                }
-                            }
-                        }
                     }
                 }
                 if (lane == 0u) { ctl[wave] = cnt; ctl[kSegsPerQ + wave] = endA; }
@@ -2206,10 +2298,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                             const u64 r = recG[k];
                             const uint32_t pm = (uint32_t)r & 0x1FFFFu, off = (uint32_t)(r >> 17) & 0x1FFFFu, len = (uint32_t)(r >> 34) & 0x1FFFu;
                             uint32_t lit = pm - anchorIn; /* the segment's first match: literals since the last match of any segment before */
-                            if (k) {
-                                if constexpr (REP) lit = (uint32_t)(r >> 47) & 0x1FFFu;
-                                else { const u64 rb = recG[k - 1u]; lit = pm - (((uint32_t)rb & 0x1FFFFu) + ((uint32_t)(rb >> 34) & 0x1FFFu)); } /* behind the end of the match before */
-                            }
+                            if (k) lit = (uint32_t)(r >> 47) & 0x1FFFu;
                             const uint32_t q = pm - off;
                             const uint32_t maxb = umin(umin(umin(pf.backExt, lit), q), pm & (kSeg - 1u));
                             uint32_t b = 0;

@@ -34,12 +34,14 @@ def test_config2_full_size_properties_and_full_parity(gpu_plugin, oracle):
         desc[i].srcOff, desc[i].seqOff, desc[i].srcLen, desc[i].seqCap = i * BLOCK, i * stride, BLOCK, stride
     d_desc = torch.empty(C.sizeof(desc), dtype=torch.uint8, device=dev)
     d_desc.copy_(torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8))
+    work = L.qzstd_hip_workspace_bytes(1, NB, BLOCK)  # the parse words of the launch (4 B per position: the parse runs after the tile loop)
+    d_work = torch.empty(max(work, 4), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     def launch():
         rc = L.qzstd_hip_find_sequences(0, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1, C.c_void_p(d_src.data_ptr()),
                                         C.c_void_p(d_desc.data_ptr()), NB, BLOCK, C.c_void_p(d_seqs.data_ptr()),
-                                        C.c_void_p(d_cnt.data_ptr()), None, 0)
+                                        C.c_void_p(d_cnt.data_ptr()), C.c_void_p(d_work.data_ptr()), work)
         assert rc == 0, gpu_plugin.err()
         torch.cuda.synchronize()
 
