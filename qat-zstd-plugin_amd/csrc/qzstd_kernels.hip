@@ -2143,14 +2143,32 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                             u64 chosen = 0ull;
                             uint32_t e = 0u, j = 0u, L = 0u; /* e: where the last match taken ends (relative to the window) */
                             for (;;) {
-                                for (;;) {
-                                    const u64 m = (sm >> c) << c;
-                                    if (!m) { c = 64u; L = 0u; break; } /* no start left in the window: the cursor walks on */
-                                    j = (uint32_t)__builtin_ctzll(m);
-                                    L = rdlane(lenF, j);
-                                    chosen |= 1ull << j;
-                                    c = e = j + L;
-                                    if (c >= 64u) break;
+                                /* the chase from cursor c (< 64), nine scalar instructions per sequence (the compiler's version of the same loop: sixteen):
+                                 * the starts at / behind c, the first of them, its length, the cursor behind it — until the window is left (c >= 64: by a
+                                 * match, or because no start is left: c = 64, L = 0); e = where the last match taken ends */
+                                {
+                                    u64 m;
+                                    uint32_t t;
+                                    asm volatile("1:\n"
+                                                 "s_lshr_b64 %[m], %[sm], %[c]\n"
+                                                 "s_cbranch_scc0 2f\n"
+                                                 "s_ff1_i32_b64 %[t], %[m]\n"
+                                                 "s_add_u32 %[j], %[c], %[t]\n"
+                                                 "s_bitset1_b64 %[ch], %[j]\n"
+                                                 "v_readlane_b32 %[L], %[len], %[j]\n"
+                                                 "s_add_u32 %[c], %[j], %[L]\n"
+                                                 "s_cmp_lt_u32 %[c], 64\n"
+                                                 "s_cbranch_scc1 1b\n"
+                                                 "s_mov_b32 %[e], %[c]\n"
+                                                 "s_branch 3f\n"
+                                                 "2:\n"
+                                                 "s_mov_b32 %[e], %[c]\n"
+                                                 "s_movk_i32 %[c], 64\n"
+                                                 "s_mov_b32 %[L], 0\n"
+                                                 "3:\n"
+                                                 : [m] "=&s"(m), [t] "=&s"(t), [j] "+s"(j), [ch] "+s"(chosen), [L] "+s"(L), [c] "+s"(c), [e] "+s"(e)
+                                                 : [sm] "s"(sm), [len] "v"(lenF)
+                                                 : "scc");
                                 }
                                 if (__builtin_expect(L != kLenCapped, 1)) break;
                                 /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
