@@ -2105,7 +2105,13 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         constexpr uint32_t kNoAnchor = 0xFFFFFFFFu;
         uint32_t *segCnt = srec, *segEndA = srec + kMaxSegs; /* [32] matches of a segment; the end of its last match (kNoAnchor: none) — srec + pv: 2 x 128 + 2 x 520 words */
         const uint32_t firstSeg = blk.parseFrom >> kSegLog, nSegs = (nh + kSeg - 1u) >> kSegLog; /* segments that hold a hashable position */
+#ifdef QZ_DEBUG_DUMP
+        const u64 tD0 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads(); /* every wave's parse words are stored (the loop's last barriers may have ordered LDS only) */
+#ifdef QZ_DEBUG_DUMP
+        const u64 tD1 = __builtin_amdgcn_s_memtime();
+#endif
         /* PASS 1.  The plain (lazy) greedy parse of a segment (oracle: the loop of qzo_find_sequences_from) depends on nothing before the segment: no match
          * crosses a boundary, so the cursor enters every segment at its first position.  Window by window — lane = position — the start flags are one
          * ballot, the chase is scalar (first start at / behind the cursor, jump by its length; a candidate that hit the cap carries kLenCapped, leaves
@@ -2133,14 +2139,23 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #pragma unroll
                         for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[nb + 64u * j + lane];
                     }
+                    /* three steps per tile, so that only the chase itself is a serial chain: (a) the windows' start masks and length fields — independent
+                     * vector work; (b) the chase through the eight windows; (c) the chosen lanes' records — independent again */
+                    u64 smA[kWin], chA[kWin];
+                    uint32_t lenA[kWin];
+#pragma unroll
+                    for (uint32_t w = 0; w < kWin; w++) {
+                        smA[w] = __ballot((wds[w] & kChosenBit) != 0u);
+                        lenA[w] = (wds[w] >> 17) & 127u;
+                    }
 #pragma unroll
                     for (uint32_t w = 0; w < kWin; w++) {
                         const uint32_t w0 = base + 64u * w;
-                        const u64 sm = __ballot((wds[w] & kChosenBit) != 0u);
+                        const u64 sm = smA[w];
                         uint32_t c = cur - w0; /* the cursor never lies before the window */
+                        u64 chosen = 0ull;
                         if (c < 64u) {
-                            uint32_t lenF = (wds[w] >> 17) & 127u;
-                            u64 chosen = 0ull;
+                            uint32_t lenF = lenA[w];
                             uint32_t e = 0u, j = 0u, L = 0u; /* e: where the last match taken ends (relative to the window) */
                             for (;;) {
                                 /* the chase from cursor c (< 64), nine scalar instructions per sequence (the compiler's version of the same loop: sixteen):
@@ -2178,21 +2193,31 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                                 c = e = j + L;
                                 if (c >= 64u) break;
                             }
+                            lenA[w] = lenF;
                             cur = w0 + c;
-                            if (chosen) {
-                                endA = w0 + e;
-                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u));
-                                if ((chosen >> lane) & 1ull) recG[cnt + rank] = rep_record(w0 + lane, wds[w] & 0x1FFFFu, lenF, 0u);
-                                cnt += (uint32_t)__popcll(chosen);
-                            }
+                            if (chosen) endA = w0 + e;
                         }
+                        chA[w] = chosen;
+                    }
+#pragma unroll
+                    for (uint32_t w = 0; w < kWin; w++) {
+                        const u64 chosen = chA[w];
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u));
+                        if ((chosen >> lane) & 1ull) recG[cnt + rank] = rep_record(base + 64u * w + lane, wds[w] & 0x1FFFFu, lenA[w], 0u);
+                        cnt += (uint32_t)__popcll(chosen);
                     }
                 }
 #endif
                 if (lane == 0u) { segCnt[sg] = cnt; segEndA[sg] = endA; }
             }
         }
+#ifdef QZ_DEBUG_DUMP
+        const u64 tD2 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads(); /* the segments' counts; every wave's records are stored */
+#ifdef QZ_DEBUG_DUMP
+        const u64 tD3 = __builtin_amdgcn_s_memtime();
+#endif
         /* the segments' first indices and the literal anchors they start from: one lane per segment, two scans */
         const bool mine = lane >= firstSeg && lane < nSegs;
         const uint32_t cv = mine ? segCnt[lane] : 0u, ev = mine ? segEndA[lane] : kNoAnchor;
@@ -2211,27 +2236,58 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 const uint32_t cnt = rdlane(cv, sg), first = rdlane(incl, sg) - cnt;
                 uint32_t anchorIn = blk.parseFrom; /* literals pending when the segment starts: behind the last match of any segment before it */
                 if (sg > 0u) { const uint32_t a = rdlane(last, sg - 1u); if (a != kNoAnchor) anchorIn = a; }
-                for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
-                    const uint32_t k = k0 + lane;
-                    if (k < cnt) {
-                        const u64 r = recG[k];
-                        const uint32_t pm = (uint32_t)r & 0x1FFFFu, off = (uint32_t)(r >> 17) & 0x1FFFFu, len = (uint32_t)(r >> 34) & 0x1FFFu;
-                        uint32_t lit = pm - anchorIn;
-                        if (k) { const u64 rp1 = recG[k - 1u]; lit = pm - (((uint32_t)rp1 & 0x1FFFFu) + ((uint32_t)(rp1 >> 34) & 0x1FFFu)); } /* behind the end of the match before */
+                /* four steps of 64 records at a time, every step's loads issued before the first is used: a step is two dependent round trips to
+                 * device memory (the records, then the bytes before the match and before its source) */
+                constexpr uint32_t kU = 4u;
+                for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * kU) {
+                    u64 r[kU], rp1[kU];
+#pragma unroll
+                    for (uint32_t u = 0; u < kU; u++) {
+                        const uint32_t k = k0 + 64u * u + lane;
+                        r[u] = k < cnt ? recG[k] : 0ull;
+                        rp1[u] = (k < cnt && k) ? recG[k - 1u] : 0ull;
+                    }
+                    uint32_t P0[kU], P1[kU], Q0[kU], Q1[kU], lit[kU], maxb[kU];
+#pragma unroll
+                    for (uint32_t u = 0; u < kU; u++) {
+                        const uint32_t k = k0 + 64u * u + lane;
+                        const uint32_t pm = (uint32_t)r[u] & 0x1FFFFu, off = (uint32_t)(r[u] >> 17) & 0x1FFFFu;
+                        lit[u] = k ? pm - (((uint32_t)rp1[u] & 0x1FFFFu) + ((uint32_t)(rp1[u] >> 34) & 0x1FFFu)) /* behind the end of the match before */
+                                   : pm - anchorIn;
                         const uint32_t q = pm - off;
-                        const uint32_t maxb = umin(umin(umin(pf.backExt, lit), q), pm & (kSeg - 1u));
-                        uint32_t b = 0;
-                        if (maxb) { /* as emit_window: the 4 bytes before the match and before its source, top byte = nearest; never counted beyond maxb <= q < pm */
-                            const uint32_t pb = pm >= 4u ? rd32u(src, pm - 4u, true) : rd32u(src, 0u, true) << (8u * (4u - pm));
-                            const uint32_t qb = q >= 4u ? rd32u(src, q - 4u, true) : rd32u(src, 0u, true) << (8u * (4u - q));
-                            const uint32_t x = pb ^ qb;
-                            b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb);
+                        maxb[u] = k < cnt ? umin(umin(umin(pf.backExt, lit[u]), q), pm & (kSeg - 1u)) : 0u;
+                        P0[u] = P1[u] = Q0[u] = Q1[u] = 0u;
+                        if (maxb[u]) { /* as emit_window: the 4 bytes before the match and before its source, top byte = nearest; never counted beyond maxb <= q < pm */
+                            const uint32_t pa = pm >= 4u ? pm - 4u : 0u, qa = q >= 4u ? q - 4u : 0u;
+                            P0[u] = src.g[pa >> 2]; P1[u] = src.g[(pa >> 2) + 1u];
+                            Q0[u] = src.g[qa >> 2]; Q1[u] = src.g[(qa >> 2) + 1u];
                         }
-                        const uint32_t idx = first + k;
-                        if (idx < blk.seqCap) store_entry(out, idx, off, lit - b, len + b, blk.mark);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kU; u++) {
+                        const uint32_t k = k0 + 64u * u + lane;
+                        if (k < cnt) {
+                            const uint32_t pm = (uint32_t)r[u] & 0x1FFFFu, off = (uint32_t)(r[u] >> 17) & 0x1FFFFu, len = (uint32_t)(r[u] >> 34) & 0x1FFFu;
+                            const uint32_t q = pm - off;
+                            uint32_t b = 0;
+                            if (maxb[u]) {
+                                const uint32_t pa = pm >= 4u ? pm - 4u : 0u, qa = q >= 4u ? q - 4u : 0u;
+                                uint32_t pb = __builtin_amdgcn_alignbyte(P1[u], P0[u], pa & 3u), qb = __builtin_amdgcn_alignbyte(Q1[u], Q0[u], qa & 3u);
+                                if (pm < 4u) pb <<= 8u * (4u - pm);
+                                if (q < 4u) qb <<= 8u * (4u - q);
+                                const uint32_t x = pb ^ qb;
+                                b = umin(x ? (uint32_t)__builtin_clz(x) >> 3 : 4u, maxb[u]);
+                            }
+                            const uint32_t idx = first + k;
+                            if (idx < blk.seqCap) store_entry(out, idx, off, lit[u] - b, len + b, blk.mark);
+                        }
                     }
                 }
             }
+#ifdef QZ_DEBUG_DUMP /* cycles: the wait for the loop's last wave, pass 1, the wait for pass 1's last wave, pass 2 */
+            if (lane == 0 && !(blk.mark & QZSTD_HIP_MARK_COMPACT))
+                out[blk.seqCap - 44u - wave] = make_uint4((uint32_t)(tD1 - tD0), (uint32_t)(tD2 - tD1), (uint32_t)(tD3 - tD2), (uint32_t)(__builtin_amdgcn_s_memtime() - tD3));
+#endif
             return 0u;
         }
         /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */

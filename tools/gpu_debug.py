@@ -65,6 +65,11 @@ def timing():
             m0, m1 = c0.mean(axis=0) / ntile, c1.mean(axis=0)
             print("matcher wave %d chain walk per tile: entry build %.0f | per tile over %.1f steps: fetch issue %.0f, tests %.0f, heads+extensions %.0f, wait for next entry %.0f"
                   % (wv, m0[0], m1[1] / ntile, m0[1], m0[2], m0[3], m1[0] * 16 / ntile))
+    if os.environ.get("QZ_POST"):  # the deferred parse (levels 1-4 of a launch): cycles per BLOCK and wave
+        for wv in range(8):
+            rw = np.array([a[(i + 1) * stride - 44 - wv] for i in range(len(blocks))], dtype=np.float64)
+            print("matcher wave %d after the loop, per block: wait for the loop's last wave %.0f, pass 1 (parse) %.0f, wait for its last wave %.0f, pass 2 (emission) %.0f"
+                  % ((wv,) + tuple(rw.mean(axis=0))))
     for wv in range(8):
         rw = np.array([a[(i + 1) * stride - 3 - wv] for i in range(len(blocks))], dtype=np.float64)
         print("matcher wave %d per tile: I1 %.0f waitB1 %.0f I2 %.0f waitB2 %.0f" % ((wv,) + tuple(rw.mean(axis=0) / 256)))
