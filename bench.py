@@ -1081,7 +1081,9 @@ def main():
             os.unlink(fq)
             os.unlink(fbig)
             # ... the announced path with ZSTD_c_searchForExternalRepcodes on (-E1) and the repeat-offset aware parse
-            rep = c_benchmark(fname, block, level, base_t, mode=1, hint=16, ext_rep=1, loops=4, env={"QZSTD_HIP_EXT_REPCODES": "1"})
+            # (round 6: a measured leg like the others — about 1.5 s of passes, the median pass; it used to be one four-loop run of 40 ms with the device
+            # layer's start-up inside, which said nothing about the rate)
+            rep = measured(lambda l: c_benchmark(fname, block, level, base_t, mode=1, hint=16, ext_rep=1, loops=l, passes=True, env={"QZSTD_HIP_EXT_REPCODES": "1"}), 1.5, min_passes=3)
             if "csize" in rep and "csize" in sw and rep.get("bytes_per_thread") == sw.get("bytes_per_thread"):
                 rep["csize_vs_sw"] = round(rep["csize"] / sw["csize"], 4)
             out["e2e_announced_repcodes"] = slim(rep) | {"csize_vs_sw": rep.get("csize_vs_sw")}
