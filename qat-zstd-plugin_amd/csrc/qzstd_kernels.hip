@@ -67,6 +67,13 @@
 #ifndef QZ_PLAIN_DEFER
 #define QZ_PLAIN_DEFER 1 /* the launch kernels of levels 1-4 defer their plain parse and their emission in the same way (csrc/qzstd_profile.c must agree: the workspace) */
 #endif
+#ifndef QZ_PW_COMPACT
+#define QZ_PW_COMPACT 0 /* A/B (round 6), 1 = the deferred plain parse keeps one word per START (packed to the front of its window, the first 128-byte line requested) and the
+                         * windows' start masks instead of one word per position.  Built bit-exact and measured: device-memory traffic 13.4 -> 11.0 GB per 1 GiB launch
+                         * (6.97 -> 5.71 x the algorithmic bytes) but 11.11 -> 11.92 ms (+7 %: a ballot, a rank and a second store per window in the matchers; two
+                         * readlanes per window and three more scalar instructions per sequence in the chase) — the kernel is bound by the instructions it issues,
+                         * not by the bytes it moves (HBM: 1.2 of 8 TB/s): not kept.  profiles/r06_ab_deferred_parse.txt */
+#endif
 #ifndef QZ_CHAIN_SHIFT
 #define QZ_CHAIN_SHIFT 1 /* chain levels: a tile's start flags are written in the next iteration's first interval (A/B: 0) */
 #endif
@@ -154,6 +161,7 @@ struct LaunchArgs {
     uint4 *chain;             /* levels >= 5: per-block chain entries (four links each), chainStride entries per block */
     uint32_t chainStride;     /* uint4 units between the scratch regions of consecutive work items */
     uint32_t chainEntries;    /* 16-byte words of entries per region (positions x kEQ); the region's dense array of first links (4 B per position) follows them */
+    uint32_t pwWords;         /* below the chain levels (the deferred parse): parse words per block region; the windows' start masks (8 B per 64 positions) follow them */
     uint32_t orderedLds;      /* this device's LDS returns from ds_max_rtn, to lanes of one instruction that hit the same address, the
                                * values in lane order (probed once per device, probe_lds_order) */
 #ifdef QZ_DEBUG_DUMP
@@ -1570,7 +1578,16 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             const bool start = take && !defer1 && !defer2 && !defer3;
             if constexpr (DEFER && !REP) {
                 /* the deferred plain parse (after the tile loop) works from the start flag, the capped length and the offset of every position */
-                p1B[(tileIdx << kTileLog) + tid] = off | ((cl == pf.capLen ? kLenCapped : cl) << 17) | (start ? kChosenBit : 0u); /* offset 17 | length 7 | start flag */
+                /* offset 17 | length 7 (kLenCapped: the candidate hit the cap) | lane 6 | start flag.  (QZ_PW_COMPACT, A/B: only a start can be chosen — a
+                 * wave = a window: its start mask goes to the masks' array (8 B), the starts' words packed to the front of the window's 64 words, in lane order) */
+#if QZ_PW_COMPACT
+                const u64 sm = __ballot(start);
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+                if (start) p1B[(tileIdx << kTileLog) + (tid & ~63u) + rk] = off | ((cl == pf.capLen ? kLenCapped : cl) << 17) | (lane << 24);
+                if (lane == 0u) reinterpret_cast<u64 *>(p1B + args.pwWords)[(tileIdx << (kTileLog - 6u)) + (tid >> 6)] = sm;
+#else
+                p1B[(tileIdx << kTileLog) + tid] = off | ((cl == pf.capLen ? kLenCapped : cl) << 17) | (lane << 24) | (start ? kChosenBit : 0u);
+#endif
                 return;
             }
             const u64 startMask = __ballot(start);
@@ -2119,15 +2136,30 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
          * once, ranked by the chosen lanes below them: record k over the words of the segment's positions 2k, 2k + 1 — behind the cursor. */
         if (matcher) {
             uint32_t nxt[kWin];
-            if (firstSeg + wave < nSegs) {
+            /* the words of a tile: a window's words are its STARTS', packed to its front (QZ_PW_COMPACT) — the first 32 of every window are requested (one
+             * 128-byte line), the rest only by a window with more starts than that */
+            constexpr uint32_t kFront = QZ_PW_COMPACT ? 32u : 64u;
+            auto load_tile = [&](uint32_t tb) {
+                if (lane < kFront) {
 #pragma unroll
-                for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[((firstSeg + wave) << kSegLog) + 64u * j + lane];
-            }
+                    for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[tb + 64u * j + lane];
+                }
+            };
+#if QZ_PW_COMPACT
+            const u64 *maskB = reinterpret_cast<const u64 *>(p1B + args.pwWords); /* [position / 64] the windows' start masks */
+            u64 mkN = 0ull; /* the masks of this wave's next segment: lane = window */
+            if (firstSeg + wave < nSegs) mkN = maskB[((firstSeg + wave) << (kSegLog - 6u)) + lane];
+#endif
+            if (firstSeg + wave < nSegs) load_tile((firstSeg + wave) << kSegLog);
             for (uint32_t sg = firstSeg + wave; sg < nSegs; sg += (uint32_t)kMatchWaves) {
                 const uint32_t segStart = sg << kSegLog;
                 u64 *recG = reinterpret_cast<u64 *>(p1B + segStart);
                 const uint32_t tEnd = umin(segStart + kSeg, nTiles << kTileLog);
                 uint32_t cnt = 0u, endA = kNoAnchor, cur = segStart;
+#if QZ_PW_COMPACT
+                const uint32_t mkLo = (uint32_t)mkN, mkHi = (uint32_t)(mkN >> 32);
+                if (sg + (uint32_t)kMatchWaves < nSegs) mkN = maskB[((sg + (uint32_t)kMatchWaves) << (kSegLog - 6u)) + lane];
+#endif
 #ifndef QZ_EXP_NOPARSE /* (timing experiment only, no sequences: what the tile loop of a deferring kernel takes without its parse) */
                 for (uint32_t base = segStart; base < tEnd; base += kTile) {
                     uint32_t wds[kWin];
@@ -2135,17 +2167,22 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     for (uint32_t j = 0; j < kWin; j++) wds[j] = nxt[j];
                     /* the next tile's words — of this segment, or the first of this wave's next one: in flight while this tile is parsed */
                     const uint32_t nb = base + kTile < tEnd ? base + kTile : (sg + (uint32_t)kMatchWaves) << kSegLog;
-                    if (base + kTile < tEnd || sg + (uint32_t)kMatchWaves < nSegs) {
-#pragma unroll
-                        for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[nb + 64u * j + lane];
-                    }
+                    if (base + kTile < tEnd || sg + (uint32_t)kMatchWaves < nSegs) load_tile(nb);
                     /* three steps per tile, so that only the chase itself is a serial chain: (a) the windows' start masks and length fields — independent
-                     * vector work; (b) the chase through the eight windows; (c) the chosen lanes' records — independent again */
+                     * vector work; (b) the chase through the eight windows; (c) the chosen starts' records — independent again */
                     u64 smA[kWin], chA[kWin];
                     uint32_t lenA[kWin];
 #pragma unroll
                     for (uint32_t w = 0; w < kWin; w++) {
+#if QZ_PW_COMPACT
+                        const uint32_t wi = ((base - segStart) >> 6) + w;
+                        smA[w] = (u64)rdlane(mkLo, wi) | ((u64)rdlane(mkHi, wi) << 32);
+                        if (__builtin_expect((uint32_t)__popcll(smA[w]) > kFront, 0)) { /* (rare: more starts than the line requested) */
+                            if (lane >= kFront) wds[w] = p1B[base + 64u * w + lane];
+                        }
+#else
                         smA[w] = __ballot((wds[w] & kChosenBit) != 0u);
+#endif
                         lenA[w] = (wds[w] >> 17) & 127u;
                     }
 #pragma unroll
@@ -2153,17 +2190,43 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         const uint32_t w0 = base + 64u * w;
                         const u64 sm = smA[w];
                         uint32_t c = cur - w0; /* the cursor never lies before the window */
-                        u64 chosen = 0ull;
+                        u64 chosen = 0ull; /* the starts taken: by rank among the window's starts (QZ_PW_COMPACT: the lane that holds the start's word), else by position */
                         if (c < 64u) {
                             uint32_t lenF = lenA[w];
-                            uint32_t e = 0u, j = 0u, L = 0u; /* e: where the last match taken ends (relative to the window) */
+                            uint32_t e = 0u, j = 0u, r = 0u, L = 0u; /* e: where the last match taken ends (relative to the window) */
                             for (;;) {
-                                /* the chase from cursor c (< 64), nine scalar instructions per sequence (the compiler's version of the same loop: sixteen):
-                                 * the starts at / behind c, the first of them, its length, the cursor behind it — until the window is left (c >= 64: by a
-                                 * match, or because no start is left: c = 64, L = 0); e = where the last match taken ends */
+                                /* the chase from cursor c (< 64), a dozen scalar instructions per sequence: the starts at / behind c, the first of them (j; r = its
+                                 * rank = the lane of its word), its length, the cursor behind it — until the window is left (c >= 64: by a match, or because no
+                                 * start is left: c = 64, L = 0); e = where the last match taken ends */
                                 {
                                     u64 m;
                                     uint32_t t;
+#if QZ_PW_COMPACT
+                                    u64 tm;
+                                    asm volatile("1:\n"
+                                                 "s_lshr_b64 %[m], %[sm], %[c]\n"
+                                                 "s_cbranch_scc0 2f\n"
+                                                 "s_ff1_i32_b64 %[t], %[m]\n"
+                                                 "s_add_u32 %[j], %[c], %[t]\n"
+                                                 "s_bfm_b64 %[tm], %[j], 0\n"
+                                                 "s_and_b64 %[tm], %[tm], %[sm]\n"
+                                                 "s_bcnt1_i32_b64 %[r], %[tm]\n"
+                                                 "s_bitset1_b64 %[ch], %[r]\n"
+                                                 "v_readlane_b32 %[L], %[len], %[r]\n"
+                                                 "s_add_u32 %[c], %[j], %[L]\n"
+                                                 "s_cmp_lt_u32 %[c], 64\n"
+                                                 "s_cbranch_scc1 1b\n"
+                                                 "s_mov_b32 %[e], %[c]\n"
+                                                 "s_branch 3f\n"
+                                                 "2:\n"
+                                                 "s_mov_b32 %[e], %[c]\n"
+                                                 "s_movk_i32 %[c], 64\n"
+                                                 "s_mov_b32 %[L], 0\n"
+                                                 "3:\n"
+                                                 : [m] "=&s"(m), [t] "=&s"(t), [tm] "=&s"(tm), [j] "+s"(j), [r] "+s"(r), [ch] "+s"(chosen), [L] "+s"(L), [c] "+s"(c), [e] "+s"(e)
+                                                 : [sm] "s"(sm), [len] "v"(lenF)
+                                                 : "scc");
+#else
                                     asm volatile("1:\n"
                                                  "s_lshr_b64 %[m], %[sm], %[c]\n"
                                                  "s_cbranch_scc0 2f\n"
@@ -2184,12 +2247,14 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                                                  : [m] "=&s"(m), [t] "=&s"(t), [j] "+s"(j), [ch] "+s"(chosen), [L] "+s"(L), [c] "+s"(c), [e] "+s"(e)
                                                  : [sm] "s"(sm), [len] "v"(lenF)
                                                  : "scc");
+                                    r = j;
+#endif
                                 }
                                 if (__builtin_expect(L != kLenCapped, 1)) break;
                                 /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
-                                const uint32_t pj = w0 + j, offj = rdlane(wds[w], j) & 0x1FFFFu;
+                                const uint32_t pj = w0 + j, offj = rdlane(wds[w], r) & 0x1FFFFu;
                                 L = extend_match_from<true>(src, pj, offj, pf.capLen, umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog), lane, true, (nPad >> 2) - 1u);
-                                if (lane == j) lenF = L;
+                                if (lane == r) lenF = L;
                                 c = e = j + L;
                                 if (c >= 64u) break;
                             }
@@ -2203,7 +2268,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     for (uint32_t w = 0; w < kWin; w++) {
                         const u64 chosen = chA[w];
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u));
-                        if ((chosen >> lane) & 1ull) recG[cnt + rank] = rep_record(base + 64u * w + lane, wds[w] & 0x1FFFFu, lenA[w], 0u);
+                        if ((chosen >> lane) & 1ull) recG[cnt + rank] = rep_record(base + 64u * w + ((wds[w] >> 24) & 63u), wds[w] & 0x1FFFFu, lenA[w], 0u);
                         cnt += (uint32_t)__popcll(chosen);
                     }
                 }
@@ -3274,6 +3339,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         }
     }
     a.chain = nullptr;
+    a.pwWords = 0;
     a.chainStride = 0;
     a.chainEntries = 0;
     a.orderedLds = 0;
@@ -3289,6 +3355,7 @@ int qzstd_hip_find_sequences(int device, void *stream, int level, const void *d_
         if (!d_work || workBytes < need || need == 0) return fail_msg("qzstd_hip_find_sequences: workspace missing or too small (qzstd_hip_workspace_bytes)");
         a.chain = static_cast<uint4 *>(d_work);
         a.chainStride = (uint32_t)(need / nBlocks / sizeof(uint4));
+        a.pwWords = (uint32_t)(need / nBlocks / 33u * 8u); /* a region = 4 B per position + 8 B per 64 positions (the windows' start masks) */
     }
     if (a.prof.segLog != 12u) return fail_msg("qzstd_hip_find_sequences: unsupported profile (the deferred parse of a launch works on 4 KiB segments)");
     a.src = static_cast<const uint8_t *>(d_src);

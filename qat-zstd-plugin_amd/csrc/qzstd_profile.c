@@ -104,7 +104,8 @@ size_t qzstd_hip_workspace_bytes(int level, uint32_t nBlocks, uint32_t maxBlockL
 #ifndef QZ_REP_DEFER
 #define QZ_REP_DEFER 1
 #endif
-    if (!p.chainDepth) return (p.repWin ? QZ_REP_DEFER != 0 : QZ_PLAIN_DEFER != 0) ? (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * 4u : 0;
+    if (!p.chainDepth) /* one word per position (the plain parse only uses the front of every 64: its starts) + the windows' start masks, 8 B per 64 positions */
+        return (p.repWin ? QZ_REP_DEFER != 0 : QZ_PLAIN_DEFER != 0) ? (size_t)nBlocks * ((((size_t)maxBlockLen + 511u) & ~(size_t)511u) / 8u * 33u) : 0;
     return (size_t)nBlocks * (((size_t)maxBlockLen + 511u) & ~(size_t)511u) * (4u * QZSTD_HIP_CHAIN_ENTRY_LINKS + 4u); /* a chain entry of QZSTD_HIP_CHAIN_ENTRY_LINKS links + the first link again, dense */
 }
 

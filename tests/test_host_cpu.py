@@ -97,7 +97,7 @@ def test_workspace_per_level(plugin):
     for level in range(1, 5):
         assert plugin.profile(level, 131072).chainDepth == 0
         for lv in (level, level | 0x100):
-            assert W(lv, 100, 131072) == 100 * 131072 * 4 and W(lv, 3, 1000) == 3 * 1024 * 4
+            assert W(lv, 100, 131072) == 100 * (131072 * 4 + 131072 // 8) and W(lv, 3, 1000) == 3 * (1024 * 4 + 1024 // 8)  # words + the windows' start masks
         assert plugin.profile(level, 131072).subTileLog == (6 if level == 2 else 0)
     for level in range(5, 13):
         assert plugin.profile(level, 131072).chainDepth in (8, 12, 32, 40, 64) and plugin.profile(level, 131072).subTileLog == 6
