@@ -942,6 +942,10 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
      * inserts for the matchers (CHAIN) or walks repeat offsets (REP) */
     constexpr uint32_t kLagT = (CHAIN || REP) ? 2u : kParseLag;
     constexpr bool kDecoupled = kLagT > 2u;
+    static_assert(!(DEFER && kDecoupled), "the deferred parse replaces the decoupled parse wave experiment");
+    /* iterations of the tile loop: the tiles, + the kLagT in which the last tiles are parsed and emitted — which a deferring kernel below the chain
+     * levels does after the loop (at the chain levels a tile's flags are written one iteration later: QZ_CHAIN_SHIFT) */
+    const uint32_t itEnd = (DEFER && !CHAIN) ? nTiles : nTiles + kLagT;
 #ifndef QZ_TILE_SHIFT
 #define QZ_TILE_SHIFT 1 /* A/B builds: 0 = lengths, start flags and parse words of a tile all inside its own second interval, as in rounds 1-5 */
 #endif
@@ -1449,7 +1453,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             anchorEnd = st.anchor;
         } else if (REP) {
             RepState st = { blk.parseFrom, blk.parseFrom, 0u, 0u, 0u, 0u, pf.segLog ? blk.parseFrom >> pf.segLog : 0u };
-            for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
+            for (uint32_t it = itBegin; it < itEnd; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u, base = k << kTileLog;
                 uint32_t *pvT = pv + (k % kLagT) * kPvStride, *srecT = srec + (k % kLagT) * kWin * kSrecWords;
@@ -1472,7 +1476,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             anchorEnd = st.anchor;
         } else {
             ParseState st = { blk.parseFrom, blk.parseFrom, 0u };
-            for (uint32_t it = itBegin; it < nTiles + 2u; it++) {
+            for (uint32_t it = itBegin; it < itEnd; it++) {
                 const bool work = it >= 1u && it - 1u < nTiles && it - 1u >= firstTile && !QZ_ABLATED(1u);
                 const uint32_t k = it - 1u;
                 if (work && !DEFER && !(CHAIN && QZ_CHAIN_SHIFT))
@@ -1616,7 +1620,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     uint32_t cP[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) cP[i] = 0u;
-    for (uint32_t it = itBegin; it < nTiles + kLagT; it++) {
+    for (uint32_t it = itBegin; it < itEnd; it++) {
         const uint32_t t0 = it << kTileLog;
         const uint32_t p = t0 + tid; /* own position in tile it */
         const uint32_t stamp = (nTilesMax - 1u - (it & (nTilesMax - 1u))) << stampShift;
