@@ -2195,19 +2195,22 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                         const u64 sm = smA[w];
                         uint32_t c = cur - w0; /* the cursor never lies before the window */
                         u64 chosen = 0ull; /* the starts taken: by rank among the window's starts (QZ_PW_COMPACT: the lane that holds the start's word), else by position */
-                        if (c < 64u) {
+                        {
                             uint32_t lenF = lenA[w];
                             uint32_t e = 0u, j = 0u, r = 0u, L = 0u; /* e: where the last match taken ends (relative to the window) */
-                            for (;;) {
-                                /* the chase from cursor c (< 64), a dozen scalar instructions per sequence: the starts at / behind c, the first of them (j; r = its
-                                 * rank = the lane of its word), its length, the cursor behind it — until the window is left (c >= 64: by a match, or because no
-                                 * start is left: c = 64, L = 0); e = where the last match taken ends */
+                            /* the chase from cursor c, hand-written: the starts at / behind c, the first of them (j; r = the lane of its word), its length, the cursor
+                             * behind it — NINE scalar instructions per sequence (the compiler's version of the same loop: sixteen) — until the window is left (c >= 64:
+                             * by a match, or because no start is left: c = 64, L = 0); e = where the last match taken ends.  A cursor behind the window (a long
+                             * match) skips the chase inside the asm: straight-line code around it */
+                            auto chase = [&]() {
                                 {
                                     u64 m;
                                     uint32_t t;
 #if QZ_PW_COMPACT
                                     u64 tm;
-                                    asm volatile("1:\n"
+                                    asm volatile("s_cmp_lt_u32 %[c], 64\n"
+                                                 "s_cbranch_scc0 3f\n"
+                                                 "1:\n"
                                                  "s_lshr_b64 %[m], %[sm], %[c]\n"
                                                  "s_cbranch_scc0 2f\n"
                                                  "s_ff1_i32_b64 %[t], %[m]\n"
@@ -2231,7 +2234,9 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                                                  : [sm] "s"(sm), [len] "v"(lenF)
                                                  : "scc");
 #else
-                                    asm volatile("1:\n"
+                                    asm volatile("s_cmp_lt_u32 %[c], 64\n"
+                                                 "s_cbranch_scc0 3f\n"
+                                                 "1:\n"
                                                  "s_lshr_b64 %[m], %[sm], %[c]\n"
                                                  "s_cbranch_scc0 2f\n"
                                                  "s_ff1_i32_b64 %[t], %[m]\n"
@@ -2254,13 +2259,16 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                                     r = j;
 #endif
                                 }
-                                if (__builtin_expect(L != kLenCapped, 1)) break;
-                                /* the match just taken hit the candidate cap: extend it to its true (bounded) end */
+                            };
+                            chase();
+                            while (__builtin_expect(L == kLenCapped, 0)) {
+                                /* the match just taken hit the candidate cap: extend it to its true (bounded) end, then go on from there */
                                 const uint32_t pj = w0 + j, offj = rdlane(wds[w], r) & 0x1FFFFu;
                                 L = extend_match_from<true>(src, pj, offj, pf.capLen, umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog), lane, true, (nPad >> 2) - 1u);
                                 if (lane == r) lenF = L;
                                 c = e = j + L;
-                                if (c >= 64u) break;
+                                L = 0u;
+                                chase();
                             }
                             lenA[w] = lenF;
                             cur = w0 + c;
