@@ -2138,7 +2138,18 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
          * ballot, the chase is scalar (first start at / behind the cursor, jump by its length; a candidate that hit the cap carries kLenCapped, leaves
          * the chase and is extended to its true, bounded end), and the lanes of the chosen starts store their records {position, offset, length} at
          * once, ranked by the chosen lanes below them: record k over the words of the segment's positions 2k, 2k + 1 — behind the cursor. */
-        if (matcher) {
+#ifndef QZ_DEFER_DYNAMIC
+#define QZ_DEFER_DYNAMIC 0 /* A/B, 1 = the segments of a block are handed out to ALL NINE waves as they become free (an LDS counter; every wave holds one ahead for its
+                            * prefetch) instead of every eighth to a matcher wave: bit-exact, level 1 10.79 vs 10.76 ms per GiB, levels 2 / 3 -1 %, 32 and 64 KiB blocks
+                            * +2 % (eight or sixteen segments, two per wave taken at once): nothing in it — not kept */
+#endif
+        uint32_t *segNext = srec + 2u * kMaxSegs; /* [2] the next segment to hand out in pass 1 / pass 2 (zero since the kernel's start: nothing writes srec in a deferring loop) */
+        auto grab = [&](uint32_t which) -> uint32_t { /* the next segment of the block, or >= nSegs */
+            uint32_t v = 0u;
+            if (lane == 0u) v = atomicAdd(&segNext[which], 1u);
+            return firstSeg + rdfirst(v);
+        };
+        if (QZ_DEFER_DYNAMIC || matcher) {
             uint32_t nxt[kWin];
             /* the words of a tile: a window's words are its STARTS', packed to its front (QZ_PW_COMPACT) — the first 32 of every window are requested (one
              * 128-byte line), the rest only by a window with more starts than that */
@@ -2152,17 +2163,22 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #if QZ_PW_COMPACT
             const u64 *maskB = reinterpret_cast<const u64 *>(p1B + args.pwWords); /* [position / 64] the windows' start masks */
             u64 mkN = 0ull; /* the masks of this wave's next segment: lane = window */
-            if (firstSeg + wave < nSegs) mkN = maskB[((firstSeg + wave) << (kSegLog - 6u)) + lane];
+            uint32_t sgN = QZ_DEFER_DYNAMIC ? grab(0u) : firstSeg + wave; /* this wave's next segment */
+            if (sgN < nSegs) mkN = maskB[(sgN << (kSegLog - 6u)) + lane];
+#else
+            uint32_t sgN = QZ_DEFER_DYNAMIC ? grab(0u) : firstSeg + wave; /* this wave's next segment */
 #endif
-            if (firstSeg + wave < nSegs) load_tile((firstSeg + wave) << kSegLog);
-            for (uint32_t sg = firstSeg + wave; sg < nSegs; sg += (uint32_t)kMatchWaves) {
+            if (sgN < nSegs) load_tile(sgN << kSegLog);
+            while (sgN < nSegs) {
+                const uint32_t sg = sgN;
+                sgN = QZ_DEFER_DYNAMIC ? grab(0u) : sg + (uint32_t)kMatchWaves;
                 const uint32_t segStart = sg << kSegLog;
                 u64 *recG = reinterpret_cast<u64 *>(p1B + segStart);
                 const uint32_t tEnd = umin(segStart + kSeg, nTiles << kTileLog);
                 uint32_t cnt = 0u, endA = kNoAnchor, cur = segStart;
 #if QZ_PW_COMPACT
                 const uint32_t mkLo = (uint32_t)mkN, mkHi = (uint32_t)(mkN >> 32);
-                if (sg + (uint32_t)kMatchWaves < nSegs) mkN = maskB[((sg + (uint32_t)kMatchWaves) << (kSegLog - 6u)) + lane];
+                if (sgN < nSegs) mkN = maskB[(sgN << (kSegLog - 6u)) + lane];
 #endif
 #ifndef QZ_EXP_NOPARSE /* (timing experiment only, no sequences: what the tile loop of a deferring kernel takes without its parse) */
                 for (uint32_t base = segStart; base < tEnd; base += kTile) {
@@ -2170,8 +2186,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #pragma unroll
                     for (uint32_t j = 0; j < kWin; j++) wds[j] = nxt[j];
                     /* the next tile's words — of this segment, or the first of this wave's next one: in flight while this tile is parsed */
-                    const uint32_t nb = base + kTile < tEnd ? base + kTile : (sg + (uint32_t)kMatchWaves) << kSegLog;
-                    if (base + kTile < tEnd || sg + (uint32_t)kMatchWaves < nSegs) load_tile(nb);
+                    const uint32_t nb = base + kTile < tEnd ? base + kTile : sgN << kSegLog;
+                    if (base + kTile < tEnd || sgN < nSegs) load_tile(nb);
                     /* three steps per tile, so that only the chase itself is a serial chain: (a) the windows' start masks and length fields — independent
                      * vector work; (b) the chase through the eight windows; (c) the chosen starts' records — independent again */
                     u64 smA[kWin], chA[kWin];
@@ -2307,8 +2323,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         const uint32_t total = rdlane(incl, kMaxSegs - 1u), lastAll = rdlane(last, kMaxSegs - 1u);
         const uint32_t anchorEndAll = lastAll == kNoAnchor ? blk.parseFrom : lastAll;
         /* PASS 2: the records of a segment, one lane per sequence (the four bytes before a match and before its source come from device memory) */
-        if (matcher) {
-            for (uint32_t sg = firstSeg + wave; sg < nSegs; sg += (uint32_t)kMatchWaves) {
+        if (QZ_DEFER_DYNAMIC || matcher) {
+            for (uint32_t sg = QZ_DEFER_DYNAMIC ? grab(1u) : firstSeg + wave; sg < nSegs; sg = QZ_DEFER_DYNAMIC ? grab(1u) : sg + (uint32_t)kMatchWaves) {
                 const u64 *recG = reinterpret_cast<const u64 *>(p1B + (sg << kSegLog));
                 const uint32_t cnt = rdlane(cv, sg), first = rdlane(incl, sg) - cnt;
                 uint32_t anchorIn = blk.parseFrom; /* literals pending when the segment starts: behind the last match of any segment before it */
@@ -2365,8 +2381,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             if (lane == 0 && !(blk.mark & QZSTD_HIP_MARK_COMPACT))
                 out[blk.seqCap - 44u - wave] = make_uint4((uint32_t)(tD1 - tD0), (uint32_t)(tD2 - tD1), (uint32_t)(tD3 - tD2), (uint32_t)(__builtin_amdgcn_s_memtime() - tD3));
 #endif
-            return 0u;
         }
+        if (matcher) return 0u;
         /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
         uint32_t count = total + 1u;
         if (lane == 0 && total < blk.seqCap) store_entry(out, total, 0u, n - anchorEndAll, 0u, blk.mark);
