@@ -970,6 +970,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         return QZSTD_HIP_NSEQ_ERROR; /* not a segment boundary of this level: refused (uniform: before the first barrier) */
     }
     if (NEAR && n > kRing) return QZSTD_HIP_NSEQ_ERROR; /* a descriptor longer than the launch's maxBlockLen: refused, never compared from a ring that lost its bytes */
+    if (DEFER && args.pwWords != 0u && ((n + kTile - 1u) & ~(kTile - 1u)) > args.pwWords) return QZSTD_HIP_NSEQ_ERROR; /* ... nor parsed out of a scratch region it does not fit (uniform: before the first barrier) */
 
     /* ---- LDS layout (qzstd_hip_lds_bytes(): 72 560 B at levels 1-2, 65 392 B at levels 5-12 = two workgroups per CU; 138 096 B at levels 3-4) ---- */
     /* The workgroup's LDS is addressed from an integer constant, not from the `smem` symbol: the dynamic allocation starts at

@@ -214,6 +214,20 @@ def test_near_kernels_at_the_ring_boundary(gpu_plugin, oracle, level):
     check_blocks(gpu_plugin, oracle, blocks + [K.by_name("text", 32769, seed=8)], level)  # maxBlockLen 32769: not NEAR
 
 
+@pytest.mark.parametrize("level", [1, 3, 0x101])
+def test_descriptor_longer_than_the_launch_says_is_refused(gpu_plugin, oracle, level):
+    """round 6: below the chain levels a launch parses out of a scratch region sized by its maxBlockLen (one parse word per position); a descriptor
+    longer than that must come back as an error block — never parsed out of words that lie in its neighbour's region — and the blocks that fit
+    must be the oracle's"""
+    blocks = [K.by_name("text", 70000, seed=3), K.by_name("system", 40000, seed=4), K.by_name("mix", 39999, seed=5)]
+    counts, seqs, stride = gpu_plugin.find_batch(blocks, level, launch_max_len=40000)
+    assert counts[0] == B.NSEQ_ERROR
+    for i in (1, 2):
+        want_n, want = oracle.find(oracle.profile(level, len(blocks[i])), blocks[i], cap=stride)
+        assert counts[i] == want_n
+        assert np.array_equal(seqs_to_np(seqs, i * stride, want_n), seqs_to_np(want, 0, want_n))
+
+
 def test_two_workgroups_per_cu_where_the_design_says_so(gpu_plugin):
     """the LDS budget is sized for two workgroups per CU at levels 1-2 and 5-12 and one at levels 3-4 (qzstd_hip_lds_bytes); the runtime's
     occupancy query has to agree — a register or LDS regression that halves the residency shows here, not only in the timings"""

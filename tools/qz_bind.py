@@ -407,7 +407,7 @@ class Plugin:
         return ServiceLane(self, slot, device)
 
     def find_batch(self, blocks: list[bytes], level: int = 1, device: int = 0, stride: int | None = None,
-                   caps: list[int] | None = None, parse_from: list[int] | None = None, packed_tag: int = 0):
+                   caps: list[int] | None = None, parse_from: list[int] | None = None, packed_tag: int = 0, launch_max_len: int | None = None):
         """Run the HIP match-finder over `blocks` through the C ABI (device memory managed
         with qzstd_hip_malloc / memcpy).  Returns (counts, list of Sequence arrays).
         packed_tag != 0: the items ask for PACKED entries (qzstd_hip.h: QZSTD_HIP_MARK_COMPACT | tag, 8 bytes each, seqOff in 16-byte units);
@@ -416,6 +416,8 @@ class Plugin:
         nb = len(blocks)
         maxlen = max([len(b) for b in blocks] + [1])
         stride = stride or sequence_bound(maxlen)
+        if launch_max_len is not None:  # (tests: a launch that understates its longest block)
+            maxlen = launch_max_len
         offs, total = [], 0
         for b in blocks:
             offs.append(total)
