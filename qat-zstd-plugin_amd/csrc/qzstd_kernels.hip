@@ -67,13 +67,6 @@
 #ifndef QZ_PLAIN_DEFER
 #define QZ_PLAIN_DEFER 1 /* the launch kernels of levels 1-4 defer their plain parse and their emission in the same way (csrc/qzstd_profile.c must agree: the workspace) */
 #endif
-#ifndef QZ_PW_COMPACT
-#define QZ_PW_COMPACT 0 /* A/B (round 6), 1 = the deferred plain parse keeps one word per START (packed to the front of its window, the first 128-byte line requested) and the
-                         * windows' start masks instead of one word per position.  Built bit-exact and measured: device-memory traffic 13.4 -> 11.0 GB per 1 GiB launch
-                         * (6.97 -> 5.71 x the algorithmic bytes) but 11.11 -> 11.92 ms (+7 %: a ballot, a rank and a second store per window in the matchers; two
-                         * readlanes per window and three more scalar instructions per sequence in the chase) — the kernel is bound by the instructions it issues,
-                         * not by the bytes it moves (HBM: 1.2 of 8 TB/s): not kept.  profiles/r06_ab_deferred_parse.txt */
-#endif
 #ifndef QZ_CHAIN_SHIFT
 #define QZ_CHAIN_SHIFT 1 /* chain levels: a tile's start flags are written in the next iteration's first interval (A/B: 0) */
 #endif
@@ -707,6 +700,88 @@ __device__ __forceinline__ void parse_rep_span(const qzstd_hip_profile_t &pf, co
         st.cur = st.anchor = q + L;
         rc = rdfirst(ring_off_s(st.cur)); /* a match may be long: recompute */
         (void)curIn;
+    }
+}
+
+/* The plain (lazy) greedy parse of the deferring kernels (qz_item<..., DEFER>, levels 1-4; oracle: the loop of qzo_find_sequences_from), windows
+ * [W0, W1) of the tile at `base`: lane = position, wds[w] = the parse words of window w (offset 17 | capped length 7, kLenCapped = hit the cap | lane 6 |
+ * start flag in bit 31).  Three steps, so that only the chase itself is a serial chain:
+ *   (a) the windows' start masks (one compare into an SGPR pair each) and length fields                                — independent vector work
+ *   (b) the chase through the windows, hand-written: the starts at / behind the cursor c, the first of them, its length, the cursor behind it — NINE
+ *       scalar instructions per sequence (the compiler's version of the same loop: sixteen) — until the window is left (c >= 64: by a match, or because
+ *       no start is left: c = 64, L = 0); a candidate that hit the cap carries kLenCapped, ends the chase and is extended to its true, bounded end
+ *       (cooperatively, both sides from device memory); a cursor behind the window (a long match) skips the chase inside the asm
+ *   (c) the lanes of the chosen starts store their records {position, offset, length} at [count + rank among the chosen]   — independent again
+ * st.cur = the cursor, st.cnt = the segment's matches so far, st.endA = where its last match ends. */
+struct PlainParse {
+    uint32_t cur, cnt, endA;
+};
+template <uint32_t W0, uint32_t W1>
+__device__ __forceinline__ void parse_plain_windows(const qzstd_hip_profile_t &pf, const Src &src, u64 *recG, const uint32_t base, const uint32_t n,
+                                                    const uint32_t lastDw, const uint32_t lane, const uint32_t (&wds)[kWin], PlainParse &st)
+{
+    u64 smA[kWin], chA[kWin];
+    uint32_t lenA[kWin];
+#pragma unroll
+    for (uint32_t w = W0; w < W1; w++) {
+        smA[w] = __ballot((wds[w] & kChosenBit) != 0u);
+        lenA[w] = (wds[w] >> 17) & 127u;
+    }
+#pragma unroll
+    for (uint32_t w = W0; w < W1; w++) {
+        const uint32_t w0 = base + 64u * w;
+        const u64 sm = smA[w];
+        uint32_t c = rdfirst(st.cur - w0); /* the cursor never lies before the window (uniform: said so, for the scalar chase) */
+        u64 chosen = 0ull;
+        uint32_t lenF = lenA[w];
+        uint32_t e = 0u, j = 0u, L = 0u; /* e: where the last match taken ends (relative to the window) */
+        auto chase = [&]() {
+            u64 m;
+            uint32_t t;
+            asm volatile("s_cmp_lt_u32 %[c], 64\n"
+                         "s_cbranch_scc0 3f\n"
+                         "1:\n"
+                         "s_lshr_b64 %[m], %[sm], %[c]\n"
+                         "s_cbranch_scc0 2f\n"
+                         "s_ff1_i32_b64 %[t], %[m]\n"
+                         "s_add_u32 %[j], %[c], %[t]\n"
+                         "s_bitset1_b64 %[ch], %[j]\n"
+                         "v_readlane_b32 %[L], %[len], %[j]\n"
+                         "s_add_u32 %[c], %[j], %[L]\n"
+                         "s_cmp_lt_u32 %[c], 64\n"
+                         "s_cbranch_scc1 1b\n"
+                         "s_mov_b32 %[e], %[c]\n"
+                         "s_branch 3f\n"
+                         "2:\n"
+                         "s_mov_b32 %[e], %[c]\n"
+                         "s_movk_i32 %[c], 64\n"
+                         "s_mov_b32 %[L], 0\n"
+                         "3:\n"
+                         : [m] "=&s"(m), [t] "=&s"(t), [j] "+s"(j), [ch] "+s"(chosen), [L] "+s"(L), [c] "+s"(c), [e] "+s"(e)
+                         : [sm] "s"(sm), [len] "v"(lenF)
+                         : "scc");
+        };
+        chase();
+        while (__builtin_expect(L == kLenCapped, 0)) {
+            /* the match just taken hit the candidate cap: extend it to its true (bounded) end, then go on from there */
+            const uint32_t pj = w0 + j, offj = rdlane(wds[w], j) & 0x1FFFFu;
+            L = extend_match_from<true>(src, pj, offj, pf.capLen, umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog), lane, true, lastDw);
+            if (lane == j) lenF = L;
+            c = e = j + L;
+            L = 0u;
+            chase();
+        }
+        lenA[w] = lenF;
+        st.cur = w0 + c;
+        if (chosen) st.endA = w0 + e;
+        chA[w] = chosen;
+    }
+#pragma unroll
+    for (uint32_t w = W0; w < W1; w++) {
+        const u64 chosen = chA[w];
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u));
+        if ((chosen >> lane) & 1ull) recG[st.cnt + rank] = rep_record(base + 64u * w + lane, wds[w] & 0x1FFFFu, lenA[w], 0u);
+        st.cnt += (uint32_t)__popcll(chosen);
     }
 }
 
@@ -1364,6 +1439,27 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
     }
     __syncthreads();
 
+    /* DEFER, plain parse, A/B (QZ_DEFER_INLOOP): what the NINTH wave — which only keeps the barriers' count in a deferring loop — could parse of the block
+     * WHILE the matchers match: a quarter tile (two windows) per iteration, between the loop's full barrier and its LDS-only one, of tiles whose words
+     * are complete.  That is a quarter of the matchers' pace — eight of a 128 KiB block's 32 segments — and takes the parse after the loop from four
+     * rounds to three.  Measured slower (below): the state stays here for the A/B build. */
+    PlainParse nwSt;                /* the segment in progress */
+    uint32_t nwSeg, nwBase, nwQ;    /* ... its index, the tile in progress, quarters of that tile done */
+    bool nwBegun = false, nwHave = false; /* inside a segment; nwNxt holds the words of the tile after this one */
+    uint32_t nwWds[kWin], nwNxt[kWin];
+    nwSeg = blk.parseFrom >> 12;
+    nwBase = nwSeg << 12;
+    nwQ = 0u;
+    nwSt = PlainParse{ nwBase, 0u, 0xFFFFFFFFu };
+#pragma unroll
+    for (uint32_t j = 0; j < kWin; j++) nwWds[j] = nwNxt[j] = 0u;
+#ifndef QZ_DEFER_INLOOP
+#define QZ_DEFER_INLOOP 0 /* A/B, 1 = the ninth wave parses a quarter tile per iteration during the loop (below).  Built bit-exact and measured SLOWER: level 1 10.81 -> 11.55 ms
+                           * per GiB, level 3 19.3 -> 20.8, level 4 19.8 -> 21.2 (only level 2, whose matchers wait for their turns anyway, gains: 15.0 -> 14.5) —
+                           * even two windows per iteration on the ninth wave delay the two matcher waves of its SIMD, and with them every barrier: what rounds
+                           * 1-5 knew as the co-critical parse wave.  Not kept: 0 = the ninth wave only keeps the barriers' count, the whole parse runs after
+                           * the loop on all nine waves.  profiles/r06_ab_deferred_parse.txt */
+#endif
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
 #ifndef QZ_PARSE_PRIO
@@ -1487,6 +1583,49 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 QZ_PLAP(pI1)
                 __syncthreads(); /* B1 */
                 QZ_PLAP(pW1)
+                if constexpr (DEFER && !REP && !CHAIN && QZ_DEFER_INLOOP != 0) {
+                    /* B1 was a full barrier: the words the matchers stored in iterations < it are complete */
+                    const uint32_t nSegsP = (nh + 4095u) >> 12;
+                    if (nwSeg < nSegsP && (nwBase >> kTileLog) + 1u <= it) {
+                        const uint32_t tEnd = umin((nwSeg << 12) + 4096u, nTiles << kTileLog);
+                        u64 *recG = reinterpret_cast<u64 *>(p1B + (nwSeg << 12));
+                        const uint32_t lastDw = (nPad >> 2) - 1u;
+                        if (nwQ == 0u) { /* a new tile: its words (requested a tile ago if they were complete then), and the next tile's */
+                            if (nwHave) {
+#pragma unroll
+                                for (uint32_t j = 0; j < kWin; j++) nwWds[j] = nwNxt[j];
+                            } else {
+#pragma unroll
+                                for (uint32_t j = 0; j < kWin; j++) nwWds[j] = p1B[nwBase + 64u * j + lane];
+                            }
+                            nwBegun = true;
+                            const bool more = nwBase + kTile < tEnd || nwSeg + 1u < nSegsP;
+                            const uint32_t nb = nwBase + kTile < tEnd ? nwBase + kTile : (nwSeg + 1u) << 12;
+                            nwHave = more && (nb >> kTileLog) + 1u <= it;
+                            if (nwHave) {
+#pragma unroll
+                                for (uint32_t j = 0; j < kWin; j++) nwNxt[j] = p1B[nb + 64u * j + lane];
+                            }
+                        }
+                        switch (nwQ) {
+                        case 0u: parse_plain_windows<0, 2>(pf, src, recG, nwBase, n, lastDw, lane, nwWds, nwSt); break;
+                        case 1u: parse_plain_windows<2, 4>(pf, src, recG, nwBase, n, lastDw, lane, nwWds, nwSt); break;
+                        case 2u: parse_plain_windows<4, 6>(pf, src, recG, nwBase, n, lastDw, lane, nwWds, nwSt); break;
+                        default: parse_plain_windows<6, 8>(pf, src, recG, nwBase, n, lastDw, lane, nwWds, nwSt); break;
+                        }
+                        nwQ = (nwQ + 1u) & 3u;
+                        if (nwQ == 0u) {
+                            nwBase += kTile;
+                            if (nwBase >= tEnd) { /* the segment is done: its count and its last match end (LDS: srec, as the parse after the loop leaves them) */
+                                if (lane == 0u) { srec[nwSeg] = nwSt.cnt; srec[32u + nwSeg] = nwSt.endA; }
+                                nwSeg++;
+                                nwBase = nwSeg << 12;
+                                nwSt = PlainParse{ nwBase, 0u, 0xFFFFFFFFu };
+                                nwBegun = false;
+                            }
+                        }
+                    }
+                }
                 if (work && !DEFER) {
                     if (CHAIN && QZ_CHAIN_SHIFT)
                         parse_tile<0, kWin>(pf, src, pv + (k % kLagT) * kPvStride, srec + (k % kLagT) * kWin * kSrecWords, k << kTileLog, n, lane, st);
@@ -1583,16 +1722,9 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             const bool start = take && !defer1 && !defer2 && !defer3;
             if constexpr (DEFER && !REP) {
                 /* the deferred plain parse (after the tile loop) works from the start flag, the capped length and the offset of every position */
-                /* offset 17 | length 7 (kLenCapped: the candidate hit the cap) | lane 6 | start flag.  (QZ_PW_COMPACT, A/B: only a start can be chosen — a
-                 * wave = a window: its start mask goes to the masks' array (8 B), the starts' words packed to the front of the window's 64 words, in lane order) */
-#if QZ_PW_COMPACT
-                const u64 sm = __ballot(start);
-                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
-                if (start) p1B[(tileIdx << kTileLog) + (tid & ~63u) + rk] = off | ((cl == pf.capLen ? kLenCapped : cl) << 17) | (lane << 24);
-                if (lane == 0u) reinterpret_cast<u64 *>(p1B + args.pwWords)[(tileIdx << (kTileLog - 6u)) + (tid >> 6)] = sm;
-#else
-                p1B[(tileIdx << kTileLog) + tid] = off | ((cl == pf.capLen ? kLenCapped : cl) << 17) | (lane << 24) | (start ? kChosenBit : 0u);
-#endif
+                /* offset 17 | length 7 (kLenCapped: the candidate hit the cap) | start flag.  (A/B, commit 72302cb: only a start can be chosen — a window's
+                 * start mask + the words of its starts only: device-memory traffic 6.97 -> 5.71 x algorithmic, kernel time +7 %: not kept) */
+                p1B[(tileIdx << kTileLog) + tid] = off | ((cl == pf.capLen ? kLenCapped : cl) << 17) | (start ? kChosenBit : 0u);
                 return;
             }
             const u64 startMask = __ballot(start);
@@ -2130,6 +2262,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #ifdef QZ_DEBUG_DUMP
         const u64 tD0 = __builtin_amdgcn_s_memtime();
 #endif
+        if (!matcher && lane == 0u) segCnt[2u * kMaxSegs] = nwSeg + (nwBegun ? 1u : 0u); /* the first segment nobody has begun (the ninth wave's own progress) */
         __syncthreads(); /* every wave's parse words are stored (the loop's last barriers may have ordered LDS only) */
 #ifdef QZ_DEBUG_DUMP
         const u64 tD1 = __builtin_amdgcn_s_memtime();
@@ -2139,48 +2272,44 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
          * ballot, the chase is scalar (first start at / behind the cursor, jump by its length; a candidate that hit the cap carries kLenCapped, leaves
          * the chase and is extended to its true, bounded end), and the lanes of the chosen starts store their records {position, offset, length} at
          * once, ranked by the chosen lanes below them: record k over the words of the segment's positions 2k, 2k + 1 — behind the cursor. */
-#ifndef QZ_DEFER_DYNAMIC
-#define QZ_DEFER_DYNAMIC 0 /* A/B, 1 = the segments of a block are handed out to ALL NINE waves as they become free (an LDS counter; every wave holds one ahead for its
-                            * prefetch) instead of every eighth to a matcher wave: bit-exact, level 1 10.79 vs 10.76 ms per GiB, levels 2 / 3 -1 %, 32 and 64 KiB blocks
-                            * +2 % (eight or sixteen segments, two per wave taken at once): nothing in it — not kept */
-#endif
-        uint32_t *segNext = srec + 2u * kMaxSegs; /* [2] the next segment to hand out in pass 1 / pass 2 (zero since the kernel's start: nothing writes srec in a deferring loop) */
-        auto grab = [&](uint32_t which) -> uint32_t { /* the next segment of the block, or >= nSegs */
-            uint32_t v = 0u;
-            if (lane == 0u) v = atomicAdd(&segNext[which], 1u);
-            return firstSeg + rdfirst(v);
-        };
-        if (QZ_DEFER_DYNAMIC || matcher) {
-            uint32_t nxt[kWin];
-            /* the words of a tile: a window's words are its STARTS', packed to its front (QZ_PW_COMPACT) — the first 32 of every window are requested (one
-             * 128-byte line), the rest only by a window with more starts than that */
-            constexpr uint32_t kFront = QZ_PW_COMPACT ? 32u : 64u;
-            auto load_tile = [&](uint32_t tb) {
-                if (lane < kFront) {
+        /* (measured and not kept, bit-exact both: the segments handed out dynamically to all nine waves — commit d4651d4: level 1 the same, short blocks
+         * +2 %; the words of the starts only + the windows' start masks — commit 72302cb: traffic -18 %, time +7 %) */
+        {
+            /* which segments are left: the ninth wave has parsed segments [firstSeg, nwSeg) during the tile loop and may stand inside segment nwSeg,
+             * which it finishes itself.  S0 = the first segment nobody has begun: wave w (ALL NINE) takes S0 + w, S0 + w + 9, ... */
+            const uint32_t S0 = rdfirst(segCnt[2u * kMaxSegs]);
+            const uint32_t lastDw = (nPad >> 2) - 1u;
+            auto load_tile = [&](uint32_t tb, uint32_t (&dst)[kWin]) {
 #pragma unroll
-                    for (uint32_t j = 0; j < kWin; j++) nxt[j] = p1B[tb + 64u * j + lane];
-                }
+                for (uint32_t j = 0; j < kWin; j++) dst[j] = p1B[tb + 64u * j + lane];
             };
-#if QZ_PW_COMPACT
-            const u64 *maskB = reinterpret_cast<const u64 *>(p1B + args.pwWords); /* [position / 64] the windows' start masks */
-            u64 mkN = 0ull; /* the masks of this wave's next segment: lane = window */
-            uint32_t sgN = QZ_DEFER_DYNAMIC ? grab(0u) : firstSeg + wave; /* this wave's next segment */
-            if (sgN < nSegs) mkN = maskB[(sgN << (kSegLog - 6u)) + lane];
-#else
-            uint32_t sgN = QZ_DEFER_DYNAMIC ? grab(0u) : firstSeg + wave; /* this wave's next segment */
-#endif
-            if (sgN < nSegs) load_tile(sgN << kSegLog);
+            uint32_t nxt[kWin];
+            if (!matcher && nwBegun) {
+                /* the ninth wave's segment in progress: the quarter tiles left of its tile, then its other tiles */
+                const uint32_t tEnd = umin((nwSeg << kSegLog) + kSeg, nTiles << kTileLog);
+                u64 *recG = reinterpret_cast<u64 *>(p1B + (nwSeg << kSegLog));
+                if (nwQ != 0u) {
+                    if (nwQ <= 1u) parse_plain_windows<2, 4>(pf, src, recG, nwBase, n, lastDw, lane, nwWds, nwSt);
+                    if (nwQ <= 2u) parse_plain_windows<4, 6>(pf, src, recG, nwBase, n, lastDw, lane, nwWds, nwSt);
+                    parse_plain_windows<6, 8>(pf, src, recG, nwBase, n, lastDw, lane, nwWds, nwSt);
+                    nwBase += kTile;
+                }
+                for (uint32_t base = nwBase; base < tEnd; base += kTile) {
+                    uint32_t wds[kWin];
+                    load_tile(base, wds);
+                    parse_plain_windows<0, kWin>(pf, src, recG, base, n, lastDw, lane, wds, nwSt);
+                }
+                if (lane == 0u) { segCnt[nwSeg] = nwSt.cnt; segEndA[nwSeg] = nwSt.endA; }
+            }
+            uint32_t sgN = S0 + wave;
+            if (sgN < nSegs) load_tile(sgN << kSegLog, nxt);
             while (sgN < nSegs) {
                 const uint32_t sg = sgN;
-                sgN = QZ_DEFER_DYNAMIC ? grab(0u) : sg + (uint32_t)kMatchWaves;
+                sgN = sg + (uint32_t)kMatchWaves + 1u;
                 const uint32_t segStart = sg << kSegLog;
                 u64 *recG = reinterpret_cast<u64 *>(p1B + segStart);
                 const uint32_t tEnd = umin(segStart + kSeg, nTiles << kTileLog);
-                uint32_t cnt = 0u, endA = kNoAnchor, cur = segStart;
-#if QZ_PW_COMPACT
-                const uint32_t mkLo = (uint32_t)mkN, mkHi = (uint32_t)(mkN >> 32);
-                if (sgN < nSegs) mkN = maskB[(sgN << (kSegLog - 6u)) + lane];
-#endif
+                PlainParse st = { segStart, 0u, kNoAnchor };
 #ifndef QZ_EXP_NOPARSE /* (timing experiment only, no sequences: what the tile loop of a deferring kernel takes without its parse) */
                 for (uint32_t base = segStart; base < tEnd; base += kTile) {
                     uint32_t wds[kWin];
@@ -2188,121 +2317,11 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                     for (uint32_t j = 0; j < kWin; j++) wds[j] = nxt[j];
                     /* the next tile's words — of this segment, or the first of this wave's next one: in flight while this tile is parsed */
                     const uint32_t nb = base + kTile < tEnd ? base + kTile : sgN << kSegLog;
-                    if (base + kTile < tEnd || sgN < nSegs) load_tile(nb);
-                    /* three steps per tile, so that only the chase itself is a serial chain: (a) the windows' start masks and length fields — independent
-                     * vector work; (b) the chase through the eight windows; (c) the chosen starts' records — independent again */
-                    u64 smA[kWin], chA[kWin];
-                    uint32_t lenA[kWin];
-#pragma unroll
-                    for (uint32_t w = 0; w < kWin; w++) {
-#if QZ_PW_COMPACT
-                        const uint32_t wi = ((base - segStart) >> 6) + w;
-                        smA[w] = (u64)rdlane(mkLo, wi) | ((u64)rdlane(mkHi, wi) << 32);
-                        if (__builtin_expect((uint32_t)__popcll(smA[w]) > kFront, 0)) { /* (rare: more starts than the line requested) */
-                            if (lane >= kFront) wds[w] = p1B[base + 64u * w + lane];
-                        }
-#else
-                        smA[w] = __ballot((wds[w] & kChosenBit) != 0u);
-#endif
-                        lenA[w] = (wds[w] >> 17) & 127u;
-                    }
-#pragma unroll
-                    for (uint32_t w = 0; w < kWin; w++) {
-                        const uint32_t w0 = base + 64u * w;
-                        const u64 sm = smA[w];
-                        uint32_t c = cur - w0; /* the cursor never lies before the window */
-                        u64 chosen = 0ull; /* the starts taken: by rank among the window's starts (QZ_PW_COMPACT: the lane that holds the start's word), else by position */
-                        {
-                            uint32_t lenF = lenA[w];
-                            uint32_t e = 0u, j = 0u, r = 0u, L = 0u; /* e: where the last match taken ends (relative to the window) */
-                            /* the chase from cursor c, hand-written: the starts at / behind c, the first of them (j; r = the lane of its word), its length, the cursor
-                             * behind it — NINE scalar instructions per sequence (the compiler's version of the same loop: sixteen) — until the window is left (c >= 64:
-                             * by a match, or because no start is left: c = 64, L = 0); e = where the last match taken ends.  A cursor behind the window (a long
-                             * match) skips the chase inside the asm: straight-line code around it */
-                            auto chase = [&]() {
-                                {
-                                    u64 m;
-                                    uint32_t t;
-#if QZ_PW_COMPACT
-                                    u64 tm;
-                                    asm volatile("s_cmp_lt_u32 %[c], 64\n"
-                                                 "s_cbranch_scc0 3f\n"
-                                                 "1:\n"
-                                                 "s_lshr_b64 %[m], %[sm], %[c]\n"
-                                                 "s_cbranch_scc0 2f\n"
-                                                 "s_ff1_i32_b64 %[t], %[m]\n"
-                                                 "s_add_u32 %[j], %[c], %[t]\n"
-                                                 "s_bfm_b64 %[tm], %[j], 0\n"
-                                                 "s_and_b64 %[tm], %[tm], %[sm]\n"
-                                                 "s_bcnt1_i32_b64 %[r], %[tm]\n"
-                                                 "s_bitset1_b64 %[ch], %[r]\n"
-                                                 "v_readlane_b32 %[L], %[len], %[r]\n"
-                                                 "s_add_u32 %[c], %[j], %[L]\n"
-                                                 "s_cmp_lt_u32 %[c], 64\n"
-                                                 "s_cbranch_scc1 1b\n"
-                                                 "s_mov_b32 %[e], %[c]\n"
-                                                 "s_branch 3f\n"
-                                                 "2:\n"
-                                                 "s_mov_b32 %[e], %[c]\n"
-                                                 "s_movk_i32 %[c], 64\n"
-                                                 "s_mov_b32 %[L], 0\n"
-                                                 "3:\n"
-                                                 : [m] "=&s"(m), [t] "=&s"(t), [tm] "=&s"(tm), [j] "+s"(j), [r] "+s"(r), [ch] "+s"(chosen), [L] "+s"(L), [c] "+s"(c), [e] "+s"(e)
-                                                 : [sm] "s"(sm), [len] "v"(lenF)
-                                                 : "scc");
-#else
-                                    asm volatile("s_cmp_lt_u32 %[c], 64\n"
-                                                 "s_cbranch_scc0 3f\n"
-                                                 "1:\n"
-                                                 "s_lshr_b64 %[m], %[sm], %[c]\n"
-                                                 "s_cbranch_scc0 2f\n"
-                                                 "s_ff1_i32_b64 %[t], %[m]\n"
-                                                 "s_add_u32 %[j], %[c], %[t]\n"
-                                                 "s_bitset1_b64 %[ch], %[j]\n"
-                                                 "v_readlane_b32 %[L], %[len], %[j]\n"
-                                                 "s_add_u32 %[c], %[j], %[L]\n"
-                                                 "s_cmp_lt_u32 %[c], 64\n"
-                                                 "s_cbranch_scc1 1b\n"
-                                                 "s_mov_b32 %[e], %[c]\n"
-                                                 "s_branch 3f\n"
-                                                 "2:\n"
-                                                 "s_mov_b32 %[e], %[c]\n"
-                                                 "s_movk_i32 %[c], 64\n"
-                                                 "s_mov_b32 %[L], 0\n"
-                                                 "3:\n"
-                                                 : [m] "=&s"(m), [t] "=&s"(t), [j] "+s"(j), [ch] "+s"(chosen), [L] "+s"(L), [c] "+s"(c), [e] "+s"(e)
-                                                 : [sm] "s"(sm), [len] "v"(lenF)
-                                                 : "scc");
-                                    r = j;
-#endif
-                                }
-                            };
-                            chase();
-                            while (__builtin_expect(L == kLenCapped, 0)) {
-                                /* the match just taken hit the candidate cap: extend it to its true (bounded) end, then go on from there */
-                                const uint32_t pj = w0 + j, offj = rdlane(wds[w], r) & 0x1FFFFu;
-                                L = extend_match_from<true>(src, pj, offj, pf.capLen, umin(seg_end(pf, pj, n), ((pj >> pf.extLog) + 2u) << pf.extLog), lane, true, (nPad >> 2) - 1u);
-                                if (lane == r) lenF = L;
-                                c = e = j + L;
-                                L = 0u;
-                                chase();
-                            }
-                            lenA[w] = lenF;
-                            cur = w0 + c;
-                            if (chosen) endA = w0 + e;
-                        }
-                        chA[w] = chosen;
-                    }
-#pragma unroll
-                    for (uint32_t w = 0; w < kWin; w++) {
-                        const u64 chosen = chA[w];
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chosen >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chosen, 0u));
-                        if ((chosen >> lane) & 1ull) recG[cnt + rank] = rep_record(base + 64u * w + ((wds[w] >> 24) & 63u), wds[w] & 0x1FFFFu, lenA[w], 0u);
-                        cnt += (uint32_t)__popcll(chosen);
-                    }
+                    if (base + kTile < tEnd || sgN < nSegs) load_tile(nb, nxt);
+                    parse_plain_windows<0, kWin>(pf, src, recG, base, n, lastDw, lane, wds, st);
                 }
 #endif
-                if (lane == 0u) { segCnt[sg] = cnt; segEndA[sg] = endA; }
+                if (lane == 0u) { segCnt[sg] = st.cnt; segEndA[sg] = st.endA; }
             }
         }
 #ifdef QZ_DEBUG_DUMP
@@ -2324,8 +2343,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         const uint32_t total = rdlane(incl, kMaxSegs - 1u), lastAll = rdlane(last, kMaxSegs - 1u);
         const uint32_t anchorEndAll = lastAll == kNoAnchor ? blk.parseFrom : lastAll;
         /* PASS 2: the records of a segment, one lane per sequence (the four bytes before a match and before its source come from device memory) */
-        if (QZ_DEFER_DYNAMIC || matcher) {
-            for (uint32_t sg = QZ_DEFER_DYNAMIC ? grab(1u) : firstSeg + wave; sg < nSegs; sg = QZ_DEFER_DYNAMIC ? grab(1u) : sg + (uint32_t)kMatchWaves) {
+        {
+            for (uint32_t sg = firstSeg + wave; sg < nSegs; sg += (uint32_t)kMatchWaves + 1u) { /* (any wave may emit any segment: the records were stored before the barrier) */
                 const u64 *recG = reinterpret_cast<const u64 *>(p1B + (sg << kSegLog));
                 const uint32_t cnt = rdlane(cv, sg), first = rdlane(incl, sg) - cnt;
                 uint32_t anchorIn = blk.parseFrom; /* literals pending when the segment starts: behind the last match of any segment before it */
