@@ -20,15 +20,21 @@
  *     current tile;
  *   - the 8 matcher waves measure the candidate lengths (16 bytes, then 32 per step), apply the
  *     lazy start rules with three DPP shifts, and reduce every position to one packed word;
- *   - a dedicated 9th wave runs the serial greedy chain as a 4-instruction scalar pointer chase
- *     (bitset / readlane / compare / select), extends capped matches cooperatively when it
- *     takes them, and publishes per-window records; the matcher waves then emit their chosen
- *     {offset, litLength, matchLength} entries ranked by a popcount prefix.
+ *   - the serial greedy parse.  In the resident service's work items (one 4 KiB segment each) and at the chain
+ *     levels a dedicated 9th wave runs it in lock-step with the matchers as a 4-instruction scalar pointer chase
+ *     (bitset / readlane / compare / select), extends capped matches cooperatively when it takes them, and
+ *     publishes per-window records; the matcher waves then emit their chosen {offset, litLength, matchLength}
+ *     entries ranked by a popcount prefix.  In the LAUNCH kernels of levels 1-4 (round 6; qz_item: DEFER) the
+ *     parse and the emission run AFTER the tile loop: the parse of a 4 KiB segment depends on nothing before
+ *     the segment and the candidates do not depend on the parse, so the loop only matches (one parse word per
+ *     position to the launch's scratch) and then the waves parse the block's segments side by side
+ *     (parse_plain_windows / parse_rep_span<true>) and emit one lane per sequence.
  *
  * Kernel variants (template parameters of qzstd_find_sequences_kernel):
  *   HAS_LONG  levels >= 3: the second table;
- *   CHAIN     levels >= 5: hash chains, 4 B per position in DEVICE memory (the workspace argument of
- *             qzstd_hip_find_sequences), walked after the table probes;
+ *   CHAIN     levels >= 5: hash chains, four links (16 B) per position in DEVICE memory (the workspace argument of
+ *             qzstd_hip_find_sequences; below the chain levels the workspace holds the deferred parse's words),
+ *             walked after the table probes;
  *   TURNS     level 2 and levels >= 5: the tables are updated per 64 positions, the matcher waves taking
  *             turns in position order;
  *   REP       levels >= 10, or any level | QZSTD_HIP_LEVEL_REPCODES: the repeat-offset aware parse
