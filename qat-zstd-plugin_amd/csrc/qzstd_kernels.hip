@@ -1466,6 +1466,12 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                            * 1-5 knew as the co-critical parse wave.  Not kept: 0 = the ninth wave only keeps the barriers' count, the whole parse runs after
                            * the loop on all nine waves.  profiles/r06_ab_deferred_parse.txt */
 #endif
+#ifndef QZ_NINTH_EXIT
+#define QZ_NINTH_EXIT 0 /* A/B: 1 = in a kernel that defers its plain parse the ninth wave ENDS before the tile loop (s_endpgm: a barrier only waits for the waves
+                         * that are left — ISA: S_BARRIER) instead of keeping the barriers' count; eight waves parse and emit after the loop, wave 0 closes the block */
+#endif
+    constexpr bool kNinthExit = DEFER && !REP && !CHAIN && QZ_NINTH_EXIT != 0 && QZ_DEFER_INLOOP == 0;
+    if (kNinthExit && !matcher) __builtin_amdgcn_endpgm(); /* (after the start-up's barrier: the wave has cleared and prefilled its share) */
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
 #ifndef QZ_PARSE_PRIO
@@ -2268,7 +2274,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 #ifdef QZ_DEBUG_DUMP
         const u64 tD0 = __builtin_amdgcn_s_memtime();
 #endif
-        if (!matcher && lane == 0u) segCnt[2u * kMaxSegs] = nwSeg + (nwBegun ? 1u : 0u); /* the first segment nobody has begun (the ninth wave's own progress) */
+        if ((kNinthExit ? wave == 0u : !matcher) && lane == 0u) segCnt[2u * kMaxSegs] = nwSeg + (nwBegun ? 1u : 0u); /* the first segment nobody has begun (the ninth wave's own progress) */
         __syncthreads(); /* every wave's parse words are stored (the loop's last barriers may have ordered LDS only) */
 #ifdef QZ_DEBUG_DUMP
         const u64 tD1 = __builtin_amdgcn_s_memtime();
@@ -2307,11 +2313,12 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 }
                 if (lane == 0u) { segCnt[nwSeg] = nwSt.cnt; segEndA[nwSeg] = nwSt.endA; }
             }
+            constexpr uint32_t kParsers = kNinthExit ? (uint32_t)kMatchWaves : (uint32_t)kMatchWaves + 1u; /* waves that are left */
             uint32_t sgN = S0 + wave;
             if (sgN < nSegs) load_tile(sgN << kSegLog, nxt);
             while (sgN < nSegs) {
                 const uint32_t sg = sgN;
-                sgN = sg + (uint32_t)kMatchWaves + 1u;
+                sgN = sg + kParsers;
                 const uint32_t segStart = sg << kSegLog;
                 u64 *recG = reinterpret_cast<u64 *>(p1B + segStart);
                 const uint32_t tEnd = umin(segStart + kSeg, nTiles << kTileLog);
@@ -2350,7 +2357,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
         const uint32_t anchorEndAll = lastAll == kNoAnchor ? blk.parseFrom : lastAll;
         /* PASS 2: the records of a segment, one lane per sequence (the four bytes before a match and before its source come from device memory) */
         {
-            for (uint32_t sg = firstSeg + wave; sg < nSegs; sg += (uint32_t)kMatchWaves + 1u) { /* (any wave may emit any segment: the records were stored before the barrier) */
+            for (uint32_t sg = firstSeg + wave; sg < nSegs; sg += kNinthExit ? (uint32_t)kMatchWaves : (uint32_t)kMatchWaves + 1u) { /* (any wave may emit any segment: the records were stored before the barrier) */
                 const u64 *recG = reinterpret_cast<const u64 *>(p1B + (sg << kSegLog));
                 const uint32_t cnt = rdlane(cv, sg), first = rdlane(incl, sg) - cnt;
                 uint32_t anchorIn = blk.parseFrom; /* literals pending when the segment starts: behind the last match of any segment before it */
@@ -2408,7 +2415,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                 out[blk.seqCap - 44u - wave] = make_uint4((uint32_t)(tD1 - tD0), (uint32_t)(tD2 - tD1), (uint32_t)(tD3 - tD2), (uint32_t)(__builtin_amdgcn_s_memtime() - tD3));
 #endif
         }
-        if (matcher) return 0u;
+        if (kNinthExit ? wave != 0u : matcher) return 0u;
         /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
         uint32_t count = total + 1u;
         if (lane == 0 && total < blk.seqCap) store_entry(out, total, 0u, n - anchorEndAll, 0u, blk.mark);
@@ -2549,7 +2556,8 @@ __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_ke
      * stores are performed, then the count with a system-scope release.  The resident service publishes its items the same way. */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == (uint32_t)kMatchThreads) /* lane 0 of the parse wave */
+    constexpr bool kNinthGone = kDefer && !REP && !CHAIN && QZ_NINTH_EXIT != 0 && QZ_DEFER_INLOOP == 0;
+    if (threadIdx.x == (kNinthGone ? 0u : (uint32_t)kMatchThreads)) /* lane 0 of the parse wave (of wave 0 where the ninth wave has ended: QZ_NINTH_EXIT) */
         __hip_atomic_store(args.nseq + blockIdx.x, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
