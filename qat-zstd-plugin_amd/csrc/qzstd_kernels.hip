@@ -1467,10 +1467,13 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                            * the loop on all nine waves.  profiles/r06_ab_deferred_parse.txt */
 #endif
 #ifndef QZ_NINTH_EXIT
-#define QZ_NINTH_EXIT 0 /* A/B: 1 = in a kernel that defers its plain parse the ninth wave ENDS before the tile loop (s_endpgm: a barrier only waits for the waves
-                         * that are left — ISA: S_BARRIER) instead of keeping the barriers' count; eight waves parse and emit after the loop, wave 0 closes the block */
+#define QZ_NINTH_EXIT 1 /* in a kernel that defers its parse below the chain levels the ninth wave has nothing to do in the tile loop: it ENDS before the loop (s_endpgm: a
+                         * barrier only waits for the waves that are left — ISA, S_BARRIER) instead of keeping the barriers' count; eight waves parse and emit after
+                         * the loop, wave 0 closes the block.  Level 1 10.82 -> 9.63 ms per GiB (-11 %), level 2 14.9 -> 12.8, 32 KiB blocks 12.2 -> 10.5, level 3 (one
+                         * workgroup per CU) unchanged: with two workgroups per CU the idle wave was the 17th and 18th of the CU — sixteen matcher waves sit four to a
+                         * SIMD.  A/B: 0 = it stays and keeps the count.  profiles/r06_ab_deferred_parse.txt */
 #endif
-    constexpr bool kNinthExit = DEFER && !REP && !CHAIN && QZ_NINTH_EXIT != 0 && QZ_DEFER_INLOOP == 0;
+    constexpr bool kNinthExit = DEFER && !CHAIN && QZ_NINTH_EXIT != 0 && (REP || QZ_DEFER_INLOOP == 0);
     if (kNinthExit && !matcher) __builtin_amdgcn_endpgm(); /* (after the start-up's barrier: the wave has cleared and prefilled its share) */
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
@@ -2437,7 +2440,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             const uint32_t qs = Q * kRing;
             /* the quarter's bytes into the ring: position x at x mod kRing, as in the tile loop (what a 64-byte read finds behind the ring's end
              * belongs to the next segment and is masked) */
-            for (uint32_t o = qs + tid * 16u; o < umin(qs + kRing, nPad); o += (uint32_t)kThreads * 16u) {
+            for (uint32_t o = qs + tid * 16u; o < umin(qs + kRing, nPad); o += (kNinthExit ? (uint32_t)kMatchThreads : (uint32_t)kThreads) * 16u) { /* (by the threads that are left) */
                 const uint4 v = g128[o >> 4];
                 ring128[(o & kRingMask) >> 4] = v;
                 if ((o & kRingMask) < kMirror) ring128[(kRing + (o & kRingMask)) >> 4] = v; /* (the emission's four bytes before a position may wrap) */
@@ -2520,7 +2523,7 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
             }
             __syncthreads(); /* the ring and the control words are rewritten by the next quarter */
         }
-        if (matcher) return 0u;
+        if (kNinthExit ? wave != 0u : matcher) return 0u; /* (where the ninth wave has ended, wave 0 closes the block) */
         /* delimiter {lit = tail, 0, 0}: QZSTD_decLz4s, src/qatseqprod.c:1037-1045 */
         uint32_t count = total + 1u;
         if (lane == 0 && total < blk.seqCap) store_entry(out, total, 0u, n - anchorCarry, 0u, blk.mark);
@@ -2556,7 +2559,7 @@ __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_ke
      * stores are performed, then the count with a system-scope release.  The resident service publishes its items the same way. */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    constexpr bool kNinthGone = kDefer && !REP && !CHAIN && QZ_NINTH_EXIT != 0 && QZ_DEFER_INLOOP == 0;
+    constexpr bool kNinthGone = kDefer && !CHAIN && QZ_NINTH_EXIT != 0 && (REP || QZ_DEFER_INLOOP == 0);
     if (threadIdx.x == (kNinthGone ? 0u : (uint32_t)kMatchThreads)) /* lane 0 of the parse wave (of wave 0 where the ninth wave has ended: QZ_NINTH_EXIT) */
         __hip_atomic_store(args.nseq + blockIdx.x, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
