@@ -1007,7 +1007,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
      * "quarter" by quarter: the quarter's bytes are staged in the ring, EIGHT waves parse its eight segments at the same time (parse_rep_span<true>,
      * a tile of parse words at a time through a private LDS window, 8-byte records back over the words), the segments' counts are summed, and every
      * wave emits its own segment's records, one lane per sequence.  Same definition (oracle: qzo_parse_rep), same sequences. */
-    static_assert(!DEFER || !CHAIN || REP, "at the chain levels only the repeat-aware parse can be deferred");
+    /* DEFER at the chain levels (A/B, QZ_CHAIN8): there the ninth wave also INSERTS for the matchers (chain_insert_tile, one tile ahead); with the parse
+     * deferred, matcher wave 0 — the wave that reaches every barrier of a chain level first — takes the inserts over, and the ninth wave ends */
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -1473,7 +1474,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
                          * workgroup per CU) unchanged: with two workgroups per CU the idle wave was the 17th and 18th of the CU — sixteen matcher waves sit four to a
                          * SIMD.  A/B: 0 = it stays and keeps the count.  profiles/r06_ab_deferred_parse.txt */
 #endif
-    constexpr bool kNinthExit = DEFER && !CHAIN && QZ_NINTH_EXIT != 0 && (REP || QZ_DEFER_INLOOP == 0);
+    constexpr bool kNinthExit = DEFER && QZ_NINTH_EXIT != 0 && (REP || CHAIN || QZ_DEFER_INLOOP == 0);
+    constexpr bool kWave0Inserts = CHAIN && kNinthExit;
     if (kNinthExit && !matcher) __builtin_amdgcn_endpgm(); /* (after the start-up's barrier: the wave has cleared and prefilled its share) */
     if (!matcher) {
         /* ---------------- the parse wave: its own scalar loop, same barrier cadence ---------------- */
@@ -1780,6 +1782,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 
         /* ================= interval 1 ================= */
         QZ_PRIO(2);
+        if (kWave0Inserts && wave == 0u && it == itBegin && it < nTiles) /* (the ninth wave's job where it is alive) */
+            chain_insert_tile(pf, src, tbl, (it & 1u) ? P1odd : nearTab, it << kTileLog, n, nh, lane, args.orderedLds != 0u);
         /* the position's own first 20 bytes (5 aligned dwords): issued first so that their LDS latency
          * hides behind the emission below; used by the hash now and by the candidate compare later */
 #ifndef QZ_SHIFT_CARRY_P
@@ -1889,6 +1893,8 @@ __device__ __forceinline__ uint32_t qz_item(const LaunchArgs &args, const qzstd_
 
         /* ================= interval 2 ================= */
         QZ_PRIO(2);
+        if (kWave0Inserts && wave == 0u && it + 1u < nTiles)
+            chain_insert_tile(pf, src, tbl, ((it + 1u) & 1u) ? P1odd : nearTab, (it + 1u) << kTileLog, n, nh, lane, args.orderedLds != 0u);
 #if defined(QZ_PAD_VALU) || defined(QZ_PAD_SALU) || defined(QZ_PAD_LDS)
         /* calibration builds only (make variant XFLAGS=-DQZ_PAD_VALU=64 ...): what ONE more instruction of a kind costs per matcher wave
          * and tile — the slope says which issue resource binds the kernel */
@@ -2549,7 +2555,13 @@ __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_ke
     const qzstd_hip_block_t blk = args.blocks[blockIdx.x];
     /* the launch kernels parse repeat-aware levels AFTER the tile loop (qz_item: DEFER): the parse words go to the dense 4-byte array of the block's
      * scratch region — behind the chain entries at the chain levels (chainEntries), the whole region below them */
-    constexpr bool kDefer = CHAIN ? (REP && QZ_REP_DEFER > 1) : (REP ? QZ_REP_DEFER != 0 : QZ_PLAIN_DEFER != 0);
+#ifndef QZ_CHAIN8
+#define QZ_CHAIN8 1 /* the chain levels defer their parse too, matcher wave 0 (the wave that reaches their barriers first) inserts for the others, the ninth wave ends: eight
+                     * waves per workgroup.  Bit-exact; level 6 (config 3's shape) 75.2 -> 66.8 ms per GiB, level 12 on 32 KiB web-log blocks (config 4's) 106.2 -> 90.0,
+                     * level 12 on 128 KiB 186.0 -> 169.6, level 9 290.7 -> 243.2, level 5 56.1 -> 50.1.  (With the ninth wave alive the deferred parse was SLOWER at
+                     * these levels: 185.8 -> 192.1 — the gain is the wave's end.)  A/B: 0 = nine waves, the parse wave inserts and parses in lock-step */
+#endif
+    constexpr bool kDefer = CHAIN ? (QZ_CHAIN8 != 0 || (REP && QZ_REP_DEFER > 1)) : (REP ? QZ_REP_DEFER != 0 : QZ_PLAIN_DEFER != 0);
     const uint32_t count = qz_item<HAS_LONG, REP, CHAIN, TURNS, NEAR, kDefer>(args, blk, args.src + blk.srcOff, args.seqs + blk.seqOff,
                                                                 CHAIN ? args.chain + (size_t)blockIdx.x * args.chainStride : nullptr,
                                                                 (CHAIN || kDefer) ? reinterpret_cast<uint32_t *>(args.chain + (size_t)blockIdx.x * args.chainStride + args.chainEntries) : nullptr,
@@ -2559,7 +2571,7 @@ __global__ __launch_bounds__(kThreads) QZ_OCCUPANCY void qzstd_find_sequences_ke
      * stores are performed, then the count with a system-scope release.  The resident service publishes its items the same way. */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    constexpr bool kNinthGone = kDefer && !CHAIN && QZ_NINTH_EXIT != 0 && (REP || QZ_DEFER_INLOOP == 0);
+    constexpr bool kNinthGone = kDefer && QZ_NINTH_EXIT != 0 && (REP || CHAIN || QZ_DEFER_INLOOP == 0);
     if (threadIdx.x == (kNinthGone ? 0u : (uint32_t)kMatchThreads)) /* lane 0 of the parse wave (of wave 0 where the ninth wave has ended: QZ_NINTH_EXIT) */
         __hip_atomic_store(args.nseq + blockIdx.x, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
