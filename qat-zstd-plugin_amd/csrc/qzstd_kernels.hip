@@ -20,12 +20,13 @@
  *     current tile;
  *   - the 8 matcher waves measure the candidate lengths (16 bytes, then 32 per step), apply the
  *     lazy start rules with three DPP shifts, and reduce every position to one packed word;
- *   - the serial greedy parse.  In the resident service's work items (one 4 KiB segment each) and at the chain
- *     levels a dedicated 9th wave runs it in lock-step with the matchers as a 4-instruction scalar pointer chase
+ *   - the serial greedy parse.  In the resident service's work items (one 4 KiB segment each) a dedicated 9th wave
+ *     runs it in lock-step with the matchers as a 4-instruction scalar pointer chase
  *     (bitset / readlane / compare / select), extends capped matches cooperatively when it takes them, and
  *     publishes per-window records; the matcher waves then emit their chosen {offset, litLength, matchLength}
- *     entries ranked by a popcount prefix.  In the LAUNCH kernels of levels 1-4 (round 6; qz_item: DEFER) the
- *     parse and the emission run AFTER the tile loop: the parse of a 4 KiB segment depends on nothing before
+ *     entries ranked by a popcount prefix.  In the LAUNCH kernels (round 6; qz_item: DEFER) the
+ *     parse and the emission run AFTER the tile loop, and the 9th wave ENDS before it (at the chain levels matcher
+ *     wave 0 takes its ordered inserts over): the parse of a 4 KiB segment depends on nothing before
  *     the segment and the candidates do not depend on the parse, so the loop only matches (one parse word per
  *     position to the launch's scratch) and then the waves parse the block's segments side by side
  *     (parse_plain_windows / parse_rep_span<true>) and emit one lane per sequence.
